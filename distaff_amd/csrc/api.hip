@@ -1,0 +1,628 @@
+// C-ABI of libdistaff_hip.so (include/distaff_hip.h): context, tables, the prover phases and proof assembly.
+// The phase order and every Fiat-Shamir dependency follow stark::prove (/root/reference/src/stark/prover.rs:17-168).
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include "ctx.h"
+#include "host_proof.h"
+#include "host_util.h"
+#include "host_vm.h"
+
+using namespace dsth;
+
+static std::string g_create_error;
+
+static double wall_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// ---- small host field helpers on limbs (fe.h compiles for the host too) ---------------------------------------------------------
+static fe h_root_of_unity(uint32_t log_order) {               // field.rs:228: G^(2^(40 - log_order))
+    const u128 G = (((u128)0x120532E7B364080Aull) << 64) | 0x86B8723E1920F4AAull;      // field.rs:14
+    u128 r = G;
+    for (uint32_t i = log_order; i < 40; i++) r = hf_mul(r, r);
+    return fe_from_u128(r);
+}
+static std::vector<fe> h_powers(fe base, size_t count) {
+    std::vector<fe> v(count);
+    u128 b = fe_to_u128(base), cur = 1;
+    for (size_t i = 0; i < count; i++) { v[i] = fe_from_u128(cur); cur = hf_mul(cur, b); }
+    return v;
+}
+static fe h_inv(fe a) { return fe_from_u128(hf_pow(fe_to_u128(a), FIELD_P - 2)); }
+static fe h_pow(fe a, u128 e) { return fe_from_u128(hf_pow(fe_to_u128(a), e)); }
+
+template <class T>
+static int dev_alloc(dst_ctx* c, T** p, size_t count) {
+    HIP_TRY(c, hipMalloc((void**)p, count * sizeof(T) > 0 ? count * sizeof(T) : 16));
+    return DST_OK;
+}
+template <class T>
+static int dev_upload(dst_ctx* c, T** p, const std::vector<T>& v) {
+    int r = dev_alloc(c, p, v.size());
+    if (r) return r;
+    HIP_TRY(c, hipMemcpy(*p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return DST_OK;
+}
+
+// periodic constants of the AIR over a cycle of 16*8 steps: interpolate each 16-entry row, evaluate at w_128^s
+// (constraints/utils.rs:87-113; decoder/mod.rs:95-100,219-223; stack/mod.rs:67-70)
+static std::vector<fe> build_periodic_table() {
+    const size_t cyc = 128;
+    std::vector<fe> out(cyc * 23);
+    u128 w16 = fe_to_u128(h_root_of_unity(4)), w128 = fe_to_u128(h_root_of_unity(7));
+    u128 w16_inv = hf_pow(w16, 15), inv16 = hf_pow(16, FIELD_P - 2);
+    static const uint8_t masks[3][16] = {{0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}, {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0}, {0, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1}};
+    for (int row = 0; row < 23; row++) {
+        u128 vals[16], coef[16];
+        for (int i = 0; i < 16; i++) vals[i] = row < 8 ? limbs(SPONGE_ARK[row][i]) : row < 20 ? limbs(HASHER_ARK[row - 8][i]) : (u128)masks[row - 20][i];
+        for (int j = 0; j < 16; j++) {
+            u128 acc = 0;
+            for (int i = 0; i < 16; i++) acc = hf_add(acc, hf_mul(vals[i], hf_pow(w16_inv, (u128)((i * j) % 16))));
+            coef[j] = hf_mul(acc, inv16);
+        }
+        for (size_t s = 0; s < cyc; s++) {
+            u128 x = hf_pow(w128, s), acc = 0, pw = 1;
+            for (int j = 0; j < 16; j++) { acc = hf_add(acc, hf_mul(coef[j], pw)); pw = hf_mul(pw, x); }
+            out[s * 23 + row] = fe_from_u128(acc);
+        }
+    }
+    return out;
+}
+
+static void free_all(dst_ctx* c) {
+    void* ptrs[] = {c->tw_lo, c->tw_hi, c->itw_lo, c->itw_hi, c->w1f, c->w2f, c->w1i, c->w2i, c->prescale, c->periodic, c->trace, c->polys, c->lde, c->tmp,
+                    c->trace_leaves, c->trace_nodes, c->ceval, c->cwork, c->cpoly, c->cevals, c->cnodes, c->comp_poly, c->comp, c->scratch, c->d_u64, c->d_stage};
+    for (void* p : ptrs) if (p) hipFree(p);
+    for (int d = 0; d < DST_MAX_FRI_LAYERS; d++) {
+        if (d > 0 && c->fri_e[d]) hipFree(c->fri_e[d]);
+        if (c->fri_leaves[d]) hipFree(c->fri_leaves[d]);
+        if (c->fri_nodes[d]) hipFree(c->fri_nodes[d]);
+    }
+    if (c->stream) hipStreamDestroy(c->stream);
+}
+
+static int ctx_init(dst_ctx* c) {
+    const dst_params& p = c->prm;
+    if (p.log_trace_length < 6 || p.log_trace_length > 26) { c->err = "log_trace_length must be in [6, 26]"; return DST_ERR_ARG; }
+    if (p.log_blowup < 4 || p.log_blowup > 8) { c->err = "extension factor must be in [16, 256]"; return DST_ERR_ARG; }
+    if (p.ctx_depth > 16 || p.loop_depth > 8) { c->err = "context / loop depth out of range"; return DST_ERR_ARG; }
+    if (p.width >= 128 || p.width <= 15 + p.ctx_depth + p.loop_depth) { c->err = "register count out of range"; return DST_ERR_ARG; }
+    if (p.num_queries == 0 || p.num_queries > 128 || p.grinding_factor > 32) { c->err = "invalid proof options"; return DST_ERR_ARG; }
+    if (p.world == 0 || p.rank >= p.world || (p.world & (p.world - 1)) || p.world > (1u << p.log_blowup) / 8) { c->err = "invalid rank / world"; return DST_ERR_ARG; }
+    if (p.log_trace_length + p.log_blowup > 40) { c->err = "LDE domain exceeds 2^40"; return DST_ERR_ARG; }
+    c->log_n = p.log_trace_length; c->log_b = p.log_blowup; c->log_N = c->log_n + c->log_b;
+    c->n = (size_t)1 << c->log_n; c->B = (size_t)1 << c->log_b; c->N = c->n * c->B; c->W = p.width;
+    c->Bc = c->B / p.world; c->j0 = c->Bc * p.rank;
+    c->stack_depth = p.width - 15 - p.ctx_depth - p.loop_depth;
+    if (c->stack_depth > 32) { c->err = "user stack deeper than 32 registers"; return DST_ERR_ARG; }
+    c->device = p.device;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamCreate(&c->stream));
+
+    // NTT plan: n = n1 * n2, tiles bounded by 64 KiB of LDS
+    NttPlan& pl = c->plan;
+    pl.log_n = c->log_n; pl.log_n1 = (c->log_n + 1) / 2; pl.log_n2 = c->log_n / 2;
+    auto tile_for = [](uint32_t log_len, uint32_t other_len_log) {
+        uint32_t t = 4;
+        while (t > 1 && (((size_t)1 << log_len) * t * sizeof(fe) > 65536 || t > (1u << other_len_log))) t >>= 1;
+        return t;
+    };
+    pl.tile_a = tile_for(pl.log_n1, pl.log_n2);
+    pl.tile_b = tile_for(pl.log_n2, pl.log_n1);
+
+    // twiddle tables
+    fe wN = h_root_of_unity(c->log_N), wN_inv = h_inv(wN);
+    c->tw_lo_bits = (c->log_N + 1) / 2;
+    uint32_t hi_bits = c->log_N - c->tw_lo_bits;
+    int r;
+    if ((r = dev_upload(c, &c->tw_lo, h_powers(wN, (size_t)1 << c->tw_lo_bits)))) return r;
+    if ((r = dev_upload(c, &c->tw_hi, h_powers(h_pow(wN, (u128)1 << c->tw_lo_bits), (size_t)1 << hi_bits)))) return r;
+    if ((r = dev_upload(c, &c->itw_lo, h_powers(wN_inv, (size_t)1 << c->tw_lo_bits)))) return r;
+    if ((r = dev_upload(c, &c->itw_hi, h_powers(h_pow(wN_inv, (u128)1 << c->tw_lo_bits), (size_t)1 << hi_bits)))) return r;
+    fe w1 = h_root_of_unity(pl.log_n1), w2 = h_root_of_unity(pl.log_n2);
+    if ((r = dev_upload(c, &c->w1f, h_powers(w1, (size_t)1 << (pl.log_n1 - 1))))) return r;
+    if ((r = dev_upload(c, &c->w2f, h_powers(w2, (size_t)1 << (pl.log_n2 - 1))))) return r;
+    if ((r = dev_upload(c, &c->w1i, h_powers(h_inv(w1), (size_t)1 << (pl.log_n1 - 1))))) return r;
+    if ((r = dev_upload(c, &c->w2i, h_powers(h_inv(w2), (size_t)1 << (pl.log_n2 - 1))))) return r;
+    if ((r = dev_upload(c, &c->prescale, h_powers(h_root_of_unity(c->log_b + pl.log_n1), (size_t)1 << (c->log_b + pl.log_n1))))) return r;
+    if ((r = dev_upload(c, &c->periodic, build_periodic_table()))) return r;
+    c->n_inv = fe_from_u128(hf_pow((u128)c->n, FIELD_P - 2));
+    c->eight_inv = fe_from_u128(hf_pow(8, FIELD_P - 2));
+    c->four_inv = fe_from_u128(hf_pow(4, FIELD_P - 2));
+    c->iota = h_root_of_unity(2);
+    c->g_trace = h_root_of_unity(c->log_n);
+    c->x_last = h_inv(c->g_trace);
+
+    // data buffers
+    const size_t n = c->n, Nl = c->Bc * n;
+    if ((r = dev_alloc(c, &c->trace, c->W * n))) return r;
+    if ((r = dev_alloc(c, &c->polys, c->W * n))) return r;
+    if ((r = dev_alloc(c, &c->lde, c->W * Nl))) return r;
+    if ((r = dev_alloc(c, &c->tmp, c->Bc * 4 * n))) return r;
+    if ((r = dev_alloc(c, &c->trace_leaves, Nl))) return r;
+    if ((r = dev_alloc(c, &c->trace_nodes, Nl))) return r;
+    if ((r = dev_alloc(c, &c->ceval, 3 * 8 * n))) return r;
+    if ((r = dev_alloc(c, &c->cwork, 4 * 8 * n))) return r;
+    if ((r = dev_alloc(c, &c->cpoly, 8 * n))) return r;
+    if ((r = dev_alloc(c, &c->cevals, Nl))) return r;
+    if ((r = dev_alloc(c, &c->cnodes, Nl / 2))) return r;
+    if ((r = dev_alloc(c, &c->comp_poly, 8 * n))) return r;
+    if ((r = dev_alloc(c, &c->comp, Nl))) return r;
+    c->scratch_elems = (size_t)1 << 21;
+    if ((r = dev_alloc(c, &c->scratch, c->scratch_elems))) return r;
+    if ((r = dev_alloc(c, &c->d_u64, 64))) return r;
+    c->stage_bytes = (size_t)8 << 20;
+    if ((r = dev_alloc(c, &c->d_stage, c->stage_bytes))) return r;
+    // FRI layers: sizes N, N/4, ... while > 256; the last one (<= 256) is the remainder (fri/prover.rs:21, fri/mod.rs:13)
+    size_t sz = c->N;
+    int d = 0;
+    for (;; d++) {
+        if (d >= DST_MAX_FRI_LAYERS) { c->err = "too many FRI layers"; return DST_ERR_ARG; }
+        c->fri_size[d] = sz;
+        if (d == 0) c->fri_e[0] = c->comp;
+        else if ((r = dev_alloc(c, &c->fri_e[d], sz))) return r;
+        if ((r = dev_alloc(c, &c->fri_leaves[d], sz / 4))) return r;
+        if ((r = dev_alloc(c, &c->fri_nodes[d], sz / 4))) return r;
+        if (sz <= 256) break;
+        sz /= 4;
+    }
+    c->num_fri_layers = d + 1;
+    return DST_OK;
+}
+
+static const fe* as_fe(const uint8_t* p) { return reinterpret_cast<const fe*>(p); }
+static std::vector<fe> copy_fe(const uint8_t* p, size_t count) { std::vector<fe> v(count); memcpy(v.data(), p, count * 16); return v; }
+
+extern "C" {
+
+int dst_ctx_create(const dst_params* params, dst_ctx** out) {
+    if (!params || !out) { g_create_error = "null argument"; return DST_ERR_ARG; }
+    dst_ctx* c = new dst_ctx();
+    c->prm = *params;
+    int r = ctx_init(c);
+    if (r != DST_OK) { g_create_error = c->err; free_all(c); delete c; *out = nullptr; return r; }
+    *out = c;
+    return DST_OK;
+}
+void dst_ctx_destroy(dst_ctx* c) { if (!c) return; hipSetDevice(c->device); free_all(c); delete c; }
+const char* dst_last_error(const dst_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
+int dst_phase_ms(const dst_ctx* c, double out_ms[9]) { if (!c || !out_ms) return DST_ERR_ARG; for (int i = 0; i < 9; i++) out_ms[i] = c->phase_ms[i]; return DST_OK; }
+
+int dst_trace_upload(dst_ctx* c, const uint8_t* const* cols) {
+    if (!c || !cols) return DST_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (size_t i = 0; i < c->W; i++) HIP_TRY(c, hipMemcpyAsync(c->trace + i * c->n, cols[i], c->n * 16, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->have_trace = true; c->committed = c->constraints_done = c->composed = false;
+    return DST_OK;
+}
+int dst_trace_upload_contiguous(dst_ctx* c, const uint8_t* cols) {
+    if (!c || !cols) return DST_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipMemcpy(c->trace, cols, c->W * c->n * 16, hipMemcpyHostToDevice));
+    c->have_trace = true; c->committed = c->constraints_done = c->composed = false;
+    return DST_OK;
+}
+
+// ---- steps 1-2 ------------------------------------------------------------------------------------------------------------------
+int dst_commit_trace(dst_ctx* c, uint8_t trace_root[32]) {
+    if (!c || !trace_root) return DST_ERR_ARG;
+    if (!c->have_trace) { c->err = "dst_commit_trace: no trace uploaded"; return DST_ERR_STATE; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    double t0 = wall_ms();
+    k_intt_columns(c, c->trace, c->polys, c->W);                 // interpolate_fft_twiddles (trace_table.rs:159)
+    k_lde_columns(c, c->polys, c->lde, c->W);                    // eval_fft_twiddles over the LDE domain (trace_table.rs:166)
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double t1 = wall_ms();
+    k_trace_leaves(c);                                           // trace_table.rs:174-185
+    k_merkle_levels(c, c->trace_leaves, c->trace_nodes, c->Bc * c->n);
+    HIP_TRY(c, hipMemcpyAsync(c->trace_root, c->trace_nodes + 1, 32, hipMemcpyDeviceToHost, c->stream));
+    // last state of the un-extended trace: op counter and program hash (evaluator.rs:37,73-74)
+    fe last[3];
+    for (int i = 0; i < 3; i++) HIP_TRY(c, hipMemcpyAsync(&last[i], c->trace + (size_t)i * c->n + (c->n - 1), 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    c->op_count = (uint64_t)fe_to_u128(last[0]);
+    c->program_hash[0] = last[1]; c->program_hash[1] = last[2];
+    memcpy(trace_root, c->trace_root, 32);
+    c->phase_ms[0] = t1 - t0; c->phase_ms[1] = wall_ms() - t1;
+    c->committed = true; c->constraints_done = c->composed = false;
+    return DST_OK;
+}
+
+// ---- steps 3-5 ------------------------------------------------------------------------------------------------------------------
+// constraint degrees in constraint-index order (decoder/mod.rs:31-47, stack/mod.rs:40-41) and the coefficient each
+// constraint receives when they are visited in degree-group order (evaluator.rs:335-358,385-406; coefficients.rs:140-185)
+static void transition_coefficients(const dst_ctx* c, const fe* draws344, std::vector<fe>& tc) {
+    const size_t cl = c->prm.ctx_depth > 1 ? c->prm.ctx_depth : 1, ll = c->prm.loop_depth > 1 ? c->prm.loop_depth : 1;
+    const size_t sl = c->stack_depth > 8 ? c->stack_depth : 8;
+    std::vector<int> deg = {2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 8, 8, 6, 4, 6, 7, 6, 6, 4};
+    deg.resize(20 + cl + ll, 4);
+    deg.resize(20 + cl + ll + 2 + c->stack_depth, 7);
+    // compacted coefficient list (build_transition_coefficients)
+    const fe* t = draws344 + 188;
+    std::vector<fe> cc;
+    auto take = [&](size_t from, size_t cnt) { for (size_t i = 0; i < cnt; i++) cc.push_back(t[from + i]); };
+    take(0, 40); take(40, 2 * cl); take(72, 2 * ll); take(88, 4); take(92, 2 * sl);
+    const size_t nc = deg.size();
+    tc.assign(2 * nc, fe_zero());
+    size_t i = 0;
+    for (int d = 0; d <= 8; d++)
+        for (size_t k = 0; k < nc; k++)
+            if (deg[k] == d) { tc[k] = cc[2 * i]; tc[nc + k] = cc[2 * i + 1]; i++; }
+}
+
+int dst_eval_constraints(dst_ctx* c, const dst_public* pub, const uint8_t* coeffs, uint8_t constraint_root[32], int64_t* bad_step) {
+    if (!c || !pub || !coeffs || !constraint_root) return DST_ERR_ARG;
+    if (!c->committed) { c->err = "dst_eval_constraints: trace not committed"; return DST_ERR_STATE; }
+    if (pub->num_inputs > 8 || pub->num_outputs > 8) { c->err = "too many public inputs / outputs"; return DST_ERR_ARG; }
+    if (c->prm.world != 1) { c->err = "dst_eval_constraints: multi-GPU combination is driven by the host (see distaff_amd/sharded.py)"; return DST_ERR_ARG; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    c->pub = *pub;
+    double t0 = wall_ms();
+    std::vector<fe> draws = copy_fe(coeffs, 344), tc;
+    transition_coefficients(c, draws.data(), tc);
+    fe* d_coef = c->scratch + c->scratch_elems - 1024;           // tail of the scratch area
+    fe* d_tc = d_coef + 344;
+    HIP_TRY(c, hipMemcpyAsync(d_coef, draws.data(), 344 * 16, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_tc, tc.data(), tc.size() * 16, hipMemcpyHostToDevice, c->stream));
+    int r = k_eval_constraints(c, d_coef, d_tc, bad_step);        // prover.rs:53-64
+    if (r == DST_ERR_AIR) { c->err = "transition constraints were not satisfied"; return r; }
+    if (r != DST_OK) return r;
+    double t1 = wall_ms();
+    // combine_polys (constraint_table.rs:54-88)
+    const size_t n = c->n, D = 8 * n;
+    fe* ip = c->cwork; fe* fp = c->cwork + D; fe* tp = c->cwork + 2 * D; fe* work = c->cwork + 3 * D;
+    k_intt8_cosets(c, c->ceval, ip, work);
+    k_syn_div(c, ip, D, fe_one());
+    k_intt8_cosets(c, c->ceval + D, fp, work);
+    k_syn_div(c, fp, D, c->x_last);
+    k_intt8_cosets(c, c->ceval + 2 * D, tp, work);
+    k_syn_div_expanded(c, tp, c->cpoly, D, n, c->x_last);
+    k_add(c, c->cpoly, ip, D);
+    k_add(c, c->cpoly, fp, D);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    double t2 = wall_ms();
+    // constraint_poly.eval + Merkle tree over raw evaluation pairs (prover.rs:82-86)
+    k_lde_fold8(c, c->cpoly, c->cevals);
+    k_constraint_tree(c);
+    HIP_TRY(c, hipMemcpyAsync(c->constraint_root, c->cnodes + 1, 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    memcpy(constraint_root, c->constraint_root, 32);
+    c->phase_ms[2] = t1 - t0; c->phase_ms[3] = t2 - t1; c->phase_ms[4] = wall_ms() - t2;
+    c->constraints_done = true; c->composed = false;
+    return DST_OK;
+}
+
+// ---- step 6 ---------------------------------------------------------------------------------------------------------------------
+int dst_compose(dst_ctx* c, const uint8_t* draws_bytes, uint8_t* trace_at_z1, uint8_t* trace_at_z2) {
+    if (!c || !draws_bytes || !trace_at_z1 || !trace_at_z2) return DST_ERR_ARG;
+    if (!c->constraints_done) { c->err = "dst_compose: constraints not evaluated"; return DST_ERR_STATE; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    double t0 = wall_ms();
+    const size_t n = c->n, D = 8 * n, W = c->W;
+    std::vector<fe> draws = copy_fe(draws_bytes, 516);
+    const fe z = draws[0];
+    const fe next_z = fe_mul(z, c->g_trace);
+    const fe k1 = draws[513], k2 = draws[514], k3 = draws[515];
+    fe* d_draws = c->scratch + c->scratch_elems - 1024;           // [516] draws, then [W] T(z), [W] T(z*g), [1] C(z)
+    fe* d_tz1 = d_draws + 520; fe* d_tz2 = d_tz1 + 128; fe* d_cz = d_tz2 + 128;
+    HIP_TRY(c, hipMemcpyAsync(d_draws, draws.data(), 516 * 16, hipMemcpyHostToDevice, c->stream));
+    // trace_table.rs:206-261
+    k_horner(c, c->polys, W, n, z, d_tz1);
+    k_horner(c, c->polys, W, n, next_z, d_tz2);
+    fe* t1 = c->cwork; fe* t2 = c->cwork + n; fe* cp = c->cwork + D;
+    k_lincomb(c, c->polys, W, n, d_draws + 1, t1);
+    k_sub_dot_at0(c, t1, d_tz1, d_draws + 1, W);
+    k_lincomb(c, c->polys, W, n, d_draws + 257, t2);
+    k_sub_dot_at0(c, t2, d_tz2, d_draws + 257, W);
+    k_syn_div(c, t1, n, z);
+    k_syn_div(c, t2, n, next_z);
+    k_add(c, t1, t2, n);
+    HIP_TRY(c, hipMemsetAsync(c->comp_poly, 0, D * 16, c->stream));
+    const size_t inc = 6 * n + 1;                                // get_incremental_trace_degree (utils/mod.rs:20)
+    k_axpy(c, c->comp_poly, t1, k1, n);
+    k_axpy(c, c->comp_poly + inc, t1, k2, n);
+    // constraint_poly.rs:39-52 merge_into
+    k_horner(c, c->cpoly, 1, D, z, d_cz);
+    HIP_TRY(c, hipMemcpyAsync(cp, c->cpoly, D * 16, hipMemcpyDeviceToDevice, c->stream));
+    k_sub_at0(c, cp, d_cz);
+    k_syn_div(c, cp, D, z);
+    k_axpy(c, c->comp_poly, cp, k3, D);
+    // evaluate over the LDE domain (prover.rs:98-101)
+    k_lde_fold8(c, c->comp_poly, c->comp);
+    c->deep_z1.resize(W * 16); c->deep_z2.resize(W * 16);
+    HIP_TRY(c, hipMemcpyAsync(c->deep_z1.data(), d_tz1, W * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->deep_z2.data(), d_tz2, W * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    memcpy(trace_at_z1, c->deep_z1.data(), W * 16);
+    memcpy(trace_at_z2, c->deep_z2.data(), W * 16);
+    c->phase_ms[5] = wall_ms() - t0;
+    c->composed = true; c->fri_committed = 0; c->fri_folded = 0; c->fri_roots.clear();
+    return DST_OK;
+}
+
+// ---- step 7 ---------------------------------------------------------------------------------------------------------------------
+int dst_fri_commit_layer(dst_ctx* c, uint8_t layer_root[32], int* more) {
+    if (!c || !layer_root || !more) return DST_ERR_ARG;
+    if (!c->composed) { c->err = "dst_fri_commit_layer: composition not built"; return DST_ERR_STATE; }
+    int d = c->fri_committed;
+    if (d >= c->num_fri_layers || d != c->fri_folded) { c->err = "dst_fri_commit_layer: fold the previous layer first"; return DST_ERR_STATE; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    double t0 = wall_ms();
+    if (d == 0) k_fri_leaves_layer0(c); else k_fri_leaves(c, d);
+    k_merkle_levels(c, c->fri_leaves[d], c->fri_nodes[d], c->fri_size[d] / 4);
+    uint8_t root[32];
+    HIP_TRY(c, hipMemcpyAsync(root, c->fri_nodes[d] + 1, 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    memcpy(layer_root, root, 32);
+    c->fri_roots.push_back(std::vector<uint8_t>(root, root + 32));
+    c->fri_committed = d + 1;
+    *more = (d + 1 < c->num_fri_layers) ? 1 : 0;
+    if (d == 0) c->phase_ms[6] = 0;
+    c->phase_ms[6] += wall_ms() - t0;
+    return DST_OK;
+}
+int dst_fri_fold(dst_ctx* c, const uint8_t special_x[16]) {
+    if (!c || !special_x) return DST_ERR_ARG;
+    int d = c->fri_folded;
+    if (d + 1 != c->fri_committed || d + 1 >= c->num_fri_layers) { c->err = "dst_fri_fold: nothing to fold"; return DST_ERR_STATE; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    double t0 = wall_ms();
+    k_fri_fold(c, d, fe_from_bytes(special_x));
+    c->fri_folded = d + 1;
+    c->phase_ms[6] += wall_ms() - t0;        // launch only; the next commit synchronises
+    return DST_OK;
+}
+
+// ---- step 8 ---------------------------------------------------------------------------------------------------------------------
+int dst_pow_grind(dst_ctx* c, const uint8_t seed[32], uint32_t grinding_factor, uint8_t out_seed[32], uint64_t* nonce) {
+    if (!c || !seed || !out_seed || !nonce || grinding_factor > 64) return DST_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    int r = k_pow(c, seed, grinding_factor, nonce);
+    if (r != DST_OK) return r;
+    uint8_t buf[64];
+    memset(buf, 0, 64);
+    memcpy(buf, seed, 32);
+    memcpy(buf + 32, nonce, 8);
+    blake3_short(buf, 64, out_seed);
+    return DST_OK;
+}
+
+// ---- step 9 ---------------------------------------------------------------------------------------------------------------------
+// runs a gather of `count` items through the staging buffer and returns them on the host
+static int fetch(dst_ctx* c, const void* src, size_t item_bytes, const std::vector<uint64_t>& idx, std::vector<uint8_t>& out) {
+    out.resize(idx.size() * item_bytes);
+    if (idx.empty()) return DST_OK;
+    size_t idx_bytes = (idx.size() * 8 + 15) / 16 * 16;
+    if (idx_bytes + out.size() > c->stage_bytes) { c->err = "staging buffer too small"; return DST_ERR_ARG; }
+    uint64_t* d_idx = (uint64_t*)c->d_stage;
+    uint8_t* d_out = c->d_stage + idx_bytes;
+    HIP_TRY(c, hipMemcpyAsync(d_idx, idx.data(), idx.size() * 8, hipMemcpyHostToDevice, c->stream));
+    k_gather(c, src, item_bytes, d_idx, idx.size(), d_out);
+    HIP_TRY(c, hipMemcpyAsync(out.data(), d_out, out.size(), hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DST_OK;
+}
+// element index of natural position `pos` inside a coset-major [Bc][n] array
+static inline uint64_t cm_index(const dst_ctx* c, uint64_t pos) { return ((pos & (c->B - 1)) - c->j0) * c->n + (pos >> c->log_b); }
+
+// writes one BatchMerkleProof's `nodes` (Vec<Vec<[u8;32]>>) given leaf and node sources
+static int emit_batch_nodes(dst_ctx* c, const BatchPlan& plan, const void* leaves_dev, const void* nodes_dev, bool raw_pair_leaves, Writer& w) {
+    std::vector<uint64_t> leaf_idx, node_idx;
+    for (auto& l : plan.nodes) for (auto& r : l) (r.is_leaf ? leaf_idx : node_idx).push_back(r.index);
+    std::vector<uint8_t> leaf_data, node_data;
+    int rc;
+    if (raw_pair_leaves) {
+        // constraint tree: leaf u = evaluations at natural positions 2u, 2u+1 of the coset-major cevals
+        std::vector<uint64_t> el;
+        for (uint64_t u : leaf_idx) { el.push_back(cm_index(c, 2 * u)); el.push_back(cm_index(c, 2 * u + 1)); }
+        if ((rc = fetch(c, leaves_dev, 16, el, leaf_data))) return rc;
+    } else if ((rc = fetch(c, leaves_dev, 32, leaf_idx, leaf_data))) return rc;
+    if ((rc = fetch(c, nodes_dev, 32, node_idx, node_data))) return rc;
+    size_t li = 0, ni = 0;
+    w.u64(plan.nodes.size());
+    for (auto& l : plan.nodes) {
+        w.u64(l.size());
+        for (auto& r : l) {
+            if (r.is_leaf) { w.raw(leaf_data.data() + 32 * li, 32); li++; }
+            else { w.raw(node_data.data() + 32 * ni, 32); ni++; }
+        }
+    }
+    return DST_OK;
+}
+
+int dst_build_proof(dst_ctx* c, const uint64_t* positions_in, uint32_t num_positions, uint64_t pow_nonce, uint8_t* out, size_t cap, size_t* out_len) {
+    if (!c || !positions_in || !out_len) return DST_ERR_ARG;
+    if (!c->composed || c->fri_committed != c->num_fri_layers) { c->err = "dst_build_proof: FRI commit phase not finished"; return DST_ERR_STATE; }
+    if (c->prm.world != 1) { c->err = "dst_build_proof: single-GPU contexts only"; return DST_ERR_ARG; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    double t0 = wall_ms();
+    std::vector<uint64_t> positions(positions_in, positions_in + num_positions);
+    for (uint64_t p : positions) if (p >= c->N) { c->err = "query position out of range"; return DST_ERR_ARG; }
+    Writer w;
+    int rc;
+    // StarkProof (proof.rs:11-22): trace_root, trace_info, trace_nodes, trace_evaluations, constraint_root, constraint_proof,
+    // deep_values, degree_proof, pow_nonce, options
+    w.raw(c->trace_root, 32);
+    uint8_t domain_depth = (uint8_t)c->log_N;
+    w.u8(domain_depth); w.u8((uint8_t)c->prm.ctx_depth); w.u8((uint8_t)c->prm.loop_depth); w.u8((uint8_t)c->stack_depth); w.u32((uint32_t)c->op_count);
+    BatchPlan tp = plan_batch(positions, c->N);
+    if ((rc = emit_batch_nodes(c, tp, c->trace_leaves, c->trace_nodes, false, w))) return rc;
+    {   // trace_evaluations: Vec<Vec<u128>>, one row of W registers per position (trace_table.rs:127)
+        size_t bytes = positions.size() * c->W * 16, idx_bytes = (positions.size() * 8 + 15) / 16 * 16;
+        if (idx_bytes + bytes > c->stage_bytes) { c->err = "staging buffer too small"; return DST_ERR_ARG; }
+        HIP_TRY(c, hipMemcpyAsync(c->d_stage, positions.data(), positions.size() * 8, hipMemcpyHostToDevice, c->stream));
+        k_gather_rows(c, (const uint64_t*)c->d_stage, positions.size(), (fe*)(c->d_stage + idx_bytes));
+        std::vector<uint8_t> rows(bytes);
+        HIP_TRY(c, hipMemcpyAsync(rows.data(), c->d_stage + idx_bytes, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        w.u64(positions.size());
+        for (size_t p = 0; p < positions.size(); p++) { w.u64(c->W); w.raw(rows.data() + p * c->W * 16, c->W * 16); }
+    }
+    w.raw(c->constraint_root, 32);
+    {   // constraint_proof: BatchMerkleProof { values, nodes, depth } over positions / 2 (utils/mod.rs:46)
+        std::vector<uint64_t> cpos = constraint_positions(positions);
+        BatchPlan cp = plan_batch(cpos, c->N / 2);
+        std::vector<uint64_t> el;
+        for (uint64_t u : cp.values) { el.push_back(cm_index(c, 2 * u)); el.push_back(cm_index(c, 2 * u + 1)); }
+        std::vector<uint8_t> vals;
+        if ((rc = fetch(c, c->cevals, 16, el, vals))) return rc;
+        w.u64(cp.values.size()); w.raw(vals.data(), vals.size());
+        if ((rc = emit_batch_nodes(c, cp, c->cevals, c->cnodes, true, w))) return rc;
+        w.u8(cp.depth);
+    }
+    w.u64(c->W); w.raw(c->deep_z1.data(), c->W * 16);             // DeepValues (proof.rs:24-28)
+    w.u64(c->W); w.raw(c->deep_z2.data(), c->W * 16);
+    {   // FriProof { layers, rem_root, rem_values } (fri/prover.rs:55-95)
+        std::vector<uint64_t> pos = positions;
+        int L = c->num_fri_layers;
+        w.u64((uint64_t)(L - 1));
+        for (int d = 0; d + 1 < L; d++) {
+            uint64_t size = c->fri_size[d], R = size / 4;
+            pos = augmented_positions(pos, size);
+            BatchPlan fp = plan_batch(pos, R);
+            w.raw(c->fri_roots[d].data(), 32);
+            std::vector<uint64_t> el;
+            for (uint64_t r : pos) for (uint64_t s = 0; s < 4; s++) { uint64_t i = r + s * R; el.push_back(d == 0 ? cm_index(c, i) : i); }
+            std::vector<uint8_t> vals;
+            if ((rc = fetch(c, c->fri_e[d], 16, el, vals))) return rc;
+            w.u64(pos.size()); w.raw(vals.data(), vals.size());   // values: Vec<[u128; 4]>
+            if ((rc = emit_batch_nodes(c, fp, c->fri_leaves[d], c->fri_nodes[d], false, w))) return rc;
+            w.u8(fp.depth);
+        }
+        w.raw(c->fri_roots[L - 1].data(), 32);
+        size_t rem = c->fri_size[L - 1];
+        std::vector<uint8_t> remv(rem * 16);
+        if (L - 1 == 0) {   // cannot happen for n >= 64 (N >= 1024), kept for completeness
+            std::vector<uint64_t> el; for (uint64_t i = 0; i < rem; i++) el.push_back(cm_index(c, i));
+            if ((rc = fetch(c, c->fri_e[0], 16, el, remv))) return rc;
+        } else {
+            HIP_TRY(c, hipMemcpyAsync(remv.data(), c->fri_e[L - 1], rem * 16, hipMemcpyDeviceToHost, c->stream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+        }
+        w.u64(rem); w.raw(remv.data(), remv.size());
+    }
+    w.u64(pow_nonce);
+    w.u8((uint8_t)c->log_b); w.u8((uint8_t)c->prm.num_queries); w.u8((uint8_t)c->prm.grinding_factor); w.u8(0);   // options.rs:16-27,107
+    HIP_TRY(c, hipGetLastError());
+    *out_len = w.b.size();
+    c->phase_ms[8] = wall_ms() - t0;
+    if (!out) return DST_OK;
+    if (cap < w.b.size()) { c->err = "proof buffer too small"; return DST_ERR_ARG; }
+    memcpy(out, w.b.data(), w.b.size());
+    return DST_OK;
+}
+
+// ---- the whole prover -----------------------------------------------------------------------------------------------------------
+int dst_prove(dst_ctx* c, const dst_public* pub, uint8_t* proof_out, size_t cap, size_t* proof_len) {
+    if (!c || !pub || !proof_len) return DST_ERR_ARG;
+    int rc;
+    uint8_t trace_root[32], constraint_root[32];
+    if ((rc = dst_commit_trace(c, trace_root))) return rc;
+    std::vector<fe> coef(344);
+    prng_vector(trace_root, 344, coef.data());                   // ConstraintCoefficients::new (coefficients.rs:66)
+    int64_t bad = -1;
+    if ((rc = dst_eval_constraints(c, pub, (const uint8_t*)coef.data(), constraint_root, &bad))) return rc;
+    std::vector<fe> draws(516);
+    prng_vector(constraint_root, 516, draws.data());             // z = draw 0; CompositionCoefficients (coefficients.rs:82)
+    std::vector<uint8_t> z1(c->W * 16), z2(c->W * 16);
+    if ((rc = dst_compose(c, (const uint8_t*)draws.data(), z1.data(), z2.data()))) return rc;
+    std::vector<uint8_t> roots;
+    for (;;) {                                                   // fri::reduce (fri/prover.rs:11-53)
+        uint8_t root[32]; int more = 0;
+        if ((rc = dst_fri_commit_layer(c, root, &more))) return rc;
+        roots.insert(roots.end(), root, root + 32);
+        if (!more) break;
+        fe sx = prng(root);
+        if ((rc = dst_fri_fold(c, (const uint8_t*)&sx))) return rc;
+    }
+    double t0 = wall_ms();
+    uint8_t seed0[32], seed1[32];
+    if (!blake3_short(roots.data(), roots.size(), seed0)) { c->err = "too many FRI roots"; return DST_ERR_ARG; }   // prover.rs:120-127
+    uint64_t nonce = 0;
+    if ((rc = dst_pow_grind(c, seed0, c->prm.grinding_factor, seed1, &nonce))) return rc;
+    std::vector<uint64_t> positions;
+    if (query_positions(seed1, c->N, (uint32_t)c->B, c->prm.num_queries, positions)) { c->err = "could not generate enough query positions"; return DST_ERR_ARG; }
+    c->phase_ms[7] = wall_ms() - t0;
+    return dst_build_proof(c, positions.data(), (uint32_t)positions.size(), nonce, proof_out, cap, proof_len);
+}
+
+// ---- host helpers ----------------------------------------------------------------------------------------------------------------
+void dst_prng_vector(const uint8_t seed[32], uint32_t count, uint8_t* out) {
+    std::vector<fe> v(count);
+    prng_vector(seed, count, v.data());
+    memcpy(out, v.data(), (size_t)count * 16);
+}
+int dst_query_positions(const uint8_t seed[32], uint64_t domain_size, uint32_t blowup, uint32_t num_queries, uint64_t* out) {
+    std::vector<uint64_t> p;
+    if (query_positions(seed, domain_size, blowup, num_queries, p)) return DST_ERR_ARG;
+    memcpy(out, p.data(), p.size() * 8);
+    return (int)p.size();
+}
+void dst_blake3(const uint8_t* in, size_t len, uint8_t out[32]) { if (!blake3_short(in, len, out)) memset(out, 0, 32); }
+
+int dst_fibonacci_trace(uint32_t log_n, uint8_t* cols, uint8_t program_hash[32], uint8_t result[16]) {
+    if (!cols || !program_hash || !result || log_n < 7 || log_n > 26) return DST_ERR_ARG;
+    u128 ph[2], res;
+    int r = fibonacci_trace(log_n, (u128*)cols, ph, &res);
+    if (r) return DST_ERR_ARG;
+    memcpy(program_hash, ph, 32);
+    memcpy(result, &res, 16);
+    return DST_OK;
+}
+
+// ---- inspection --------------------------------------------------------------------------------------------------------------------
+int dst_read_buffer(dst_ctx* c, uint32_t what, uint32_t arg, uint8_t* out, size_t cap, size_t* len) {
+    if (!c || !len) return DST_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = c->n, Nl = c->Bc * n;
+    const void* src = nullptr; size_t bytes = 0;
+    const fe* coset_major = nullptr; size_t cosets = 0;
+    switch (what) {
+        case DST_BUF_POLYS: src = c->polys; bytes = c->W * n * 16; break;
+        case DST_BUF_LDE: if (arg >= c->W) return DST_ERR_ARG; coset_major = c->lde + (size_t)arg * Nl; cosets = c->Bc; break;
+        case DST_BUF_TRACE_LEAVES: src = c->trace_leaves; bytes = Nl * 32; break;
+        case DST_BUF_TRACE_NODES: src = c->trace_nodes; bytes = Nl * 32; break;
+        case DST_BUF_CEVAL_I: case DST_BUF_CEVAL_F: case DST_BUF_CEVAL_T: coset_major = c->ceval + (size_t)(what - DST_BUF_CEVAL_I) * 8 * n; cosets = 8; break;
+        case DST_BUF_CPOLY: src = c->cpoly; bytes = 8 * n * 16; break;
+        case DST_BUF_CEVALS: coset_major = c->cevals; cosets = c->Bc; break;
+        case DST_BUF_CNODES: src = c->cnodes; bytes = Nl / 2 * 32; break;
+        case DST_BUF_COMP_POLY: src = c->comp_poly; bytes = 8 * n * 16; break;
+        case DST_BUF_COMP_EVALS: coset_major = c->comp; cosets = c->Bc; break;
+        case DST_BUF_FRI_EVALS:
+            if ((int)arg >= c->num_fri_layers) return DST_ERR_ARG;
+            if (arg == 0) { coset_major = c->comp; cosets = c->Bc; } else { src = c->fri_e[arg]; bytes = c->fri_size[arg] * 16; }
+            break;
+        case DST_BUF_FRI_NODES: if ((int)arg >= c->num_fri_layers) return DST_ERR_ARG; src = c->fri_nodes[arg]; bytes = c->fri_size[arg] / 4 * 32; break;
+        case DST_BUF_FRI_LEAVES: if ((int)arg >= c->num_fri_layers) return DST_ERR_ARG; src = c->fri_leaves[arg]; bytes = c->fri_size[arg] / 4 * 32; break;
+        default: c->err = "unknown buffer id"; return DST_ERR_ARG;
+    }
+    if (coset_major) bytes = cosets * n * 16;
+    *len = bytes;
+    if (!out) return DST_OK;
+    if (cap < bytes) { c->err = "output buffer too small"; return DST_ERR_ARG; }
+    if (coset_major) {
+        fe* tmp = nullptr;
+        HIP_TRY(c, hipMalloc((void**)&tmp, bytes));
+        k_coset_to_natural(c, coset_major, cosets, tmp);
+        hipError_t e = hipMemcpyAsync(out, tmp, bytes, hipMemcpyDeviceToHost, c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        hipFree(tmp);
+        HIP_TRY(c, e);
+    } else {
+        HIP_TRY(c, hipMemcpyAsync(out, src, bytes, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+    }
+    return DST_OK;
+}
+
+int dst_bench_mulmod(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms) {
+    if (!c || !ms) return DST_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return k_bench_mulmod(c, lanes, iters, ms);
+}
+
+}  // extern "C"

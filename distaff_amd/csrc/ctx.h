@@ -1,0 +1,144 @@
+// Internal definitions shared by the kernel translation units and the C-ABI layer of libdistaff_hip.so.
+//
+// HBM layout (all field elements are 16-byte `fe`, digests 32-byte `digest`):
+//   trace   [W][n]        register traces as uploaded (column-major, the reference's Vec<Vec<u128>>)
+//   polys   [W][n]        the same registers in coefficient form (TraceTable.polys, trace_table.rs:11)
+//   lde     [W][Bc][n]    "coset-major" low-degree extension: lde[c][j][k] = T_c(w_N^(B*k + j0 + j)), i.e. the value the
+//                         reference keeps at registers[c][B*k + j0 + j].  A coset is a contiguous size-n array, so the
+//                         size-n NTT that produces it, the constraint kernel (rows i and i+B are (j,k),(j,k+1)) and the
+//                         FRI fold (i, i+N/4, ... share j) all stream with unit stride.
+//   Merkle leaves / nodes are kept in the reference's natural leaf order (leaf i = B*k + j), heap-indexed
+//   (nodes[1] = root, merkle.rs:269-294); kernels that read coset-major data and emit natural-order digests go
+//   through an LDS tile transpose so that both sides are coalesced.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "fe.h"
+#include "../../include/distaff_hip.h"
+
+struct __attribute__((aligned(16))) digest { uint32_t w[8]; };
+
+#define DST_MAX_FRI_LAYERS 24
+
+// ids for dst_read_buffer
+enum {
+    DST_BUF_POLYS = 0,        // [W][n]
+    DST_BUF_LDE = 1,          // arg = register: natural order [N] (converted from coset-major on the device)
+    DST_BUF_TRACE_LEAVES = 2, // [N] x 32
+    DST_BUF_TRACE_NODES = 3,  // [N] x 32 (heap)
+    DST_BUF_CEVAL_I = 4,      // combined boundary (first step) evaluations over the 8n domain, natural order
+    DST_BUF_CEVAL_F = 5,
+    DST_BUF_CEVAL_T = 6,
+    DST_BUF_CPOLY = 7,        // constraint polynomial, 8n coefficients
+    DST_BUF_CEVALS = 8,       // constraint polynomial over the LDE domain, natural order [N]
+    DST_BUF_CNODES = 9,       // constraint tree nodes [N/2] x 32 (heap)
+    DST_BUF_COMP_POLY = 10,   // composition polynomial, 8n coefficients
+    DST_BUF_COMP_EVALS = 11,  // composition evaluations, natural order [N]
+    DST_BUF_FRI_EVALS = 12,   // arg = layer: evaluations of that layer, natural order
+    DST_BUF_FRI_NODES = 13,   // arg = layer: tree nodes (heap)
+    DST_BUF_FRI_LEAVES = 14,  // arg = layer: hashed rows
+};
+
+struct NttPlan {
+    uint32_t log_n = 0, log_n1 = 0, log_n2 = 0;      // n = n1 * n2, n1 >= n2
+    uint32_t tile_a = 1, tile_b = 1;                 // columns per workgroup tile in pass A / pass B
+};
+
+struct dst_ctx {
+    dst_params prm{};
+    std::string err;
+    int device = 0;
+    hipStream_t stream = nullptr;
+
+    // derived sizes
+    uint32_t log_n = 0, log_b = 0, log_N = 0;
+    size_t n = 0, B = 0, N = 0, W = 0;
+    size_t Bc = 0, j0 = 0;              // local cosets
+    size_t stack_depth = 0;
+    NttPlan plan;
+
+    // tables (device)
+    fe *tw_lo = nullptr, *tw_hi = nullptr;       // w_N^t, two-level: e = (hi << lo_bits) | lo
+    fe *itw_lo = nullptr, *itw_hi = nullptr;     // w_N^-t
+    uint32_t tw_lo_bits = 0;
+    fe *w1f = nullptr, *w2f = nullptr, *w1i = nullptr, *w2i = nullptr;   // stage twiddles w_{n1}^t, w_{n2}^t and inverses
+    fe *prescale = nullptr;                      // w_{B*n1}^t, t < B*n1
+    fe *periodic = nullptr;                      // [128][23] extended Rescue round constants + cycle masks
+    fe n_inv{}, eight_inv{}, four_inv{}, iota{}, g_trace{}, x_last{};   // 1/n, 1/8, 1/4, w_N^(N/4), w_n, w_n^(n-1)
+
+    // data (device)
+    fe *trace = nullptr, *polys = nullptr, *lde = nullptr, *tmp = nullptr;
+    digest *trace_leaves = nullptr, *trace_nodes = nullptr;
+    fe *ceval = nullptr;                // [3][8c][n] combined constraint evaluations (i, f, t), coset-major over the 8n domain
+    fe *cwork = nullptr;                // scratch, 3 * 8n
+    fe *cpoly = nullptr;                // [8n]
+    fe *cevals = nullptr;               // [Bc][n]
+    digest *cnodes = nullptr;           // [N/2]
+    fe *comp_poly = nullptr;            // [8n]
+    fe *comp = nullptr;                 // [Bc][n]
+    fe *scratch = nullptr;              // misc scan / reduction scratch
+    size_t scratch_elems = 0;
+    int num_fri_layers = 0, fri_committed = 0, fri_folded = 0;
+    fe *fri_e[DST_MAX_FRI_LAYERS] = {nullptr};       // evaluations of layer d (d = 0 aliases comp, coset-major)
+    digest *fri_leaves[DST_MAX_FRI_LAYERS] = {nullptr};
+    digest *fri_nodes[DST_MAX_FRI_LAYERS] = {nullptr};
+    size_t fri_size[DST_MAX_FRI_LAYERS] = {0};       // N_d
+    uint64_t *d_u64 = nullptr;                        // small device scalars (pow result, AIR failure flag)
+    uint8_t *d_stage = nullptr;                       // staging buffer for gathers
+    size_t stage_bytes = 0;
+
+    // host copies kept for proof assembly
+    dst_public pub{};
+    uint8_t trace_root[32] = {0}, constraint_root[32] = {0};
+    std::vector<uint8_t> deep_z1, deep_z2;
+    std::vector<std::vector<uint8_t>> fri_roots;
+    uint64_t op_count = 0;
+    fe program_hash[2] = {};
+    bool have_trace = false, committed = false, constraints_done = false, composed = false;
+    double phase_ms[9] = {0};
+};
+
+#define HIP_TRY(ctx, expr)                                                                          \
+    do {                                                                                            \
+        hipError_t _e = (expr);                                                                     \
+        if (_e != hipSuccess) {                                                                     \
+            (ctx)->err = std::string(#expr) + ": " + hipGetErrorString(_e);                          \
+            return DST_ERR_HIP;                                                                     \
+        }                                                                                           \
+    } while (0)
+
+// ---- kernel launchers (kernels_*.hip) ------------------------------------------------------------------------------------
+// NTT / LDE
+void k_intt_columns(dst_ctx* c, const fe* src, fe* dst, size_t ncols);                  // size-n inverse NTT of ncols contiguous columns
+void k_lde_columns(dst_ctx* c, const fe* polys, fe* lde, size_t ncols);                 // n coefficients -> coset-major [Bc][n] per column
+void k_lde_fold8(dst_ctx* c, const fe* poly8n, fe* out);                                // 8n coefficients -> coset-major [Bc][n]
+void k_intt8_cosets(dst_ctx* c, fe* vals /* [8][n] coset-major, in place scratch */, fe* out8n, fe* work);
+void k_coset_to_natural(dst_ctx* c, const fe* src, size_t cosets, fe* dst);             // [cosets][n] -> natural [n*cosets]
+// hashing
+void k_trace_leaves(dst_ctx* c);
+void k_merkle_levels(dst_ctx* c, const digest* leaves, digest* nodes, size_t num_leaves);
+void k_constraint_tree(dst_ctx* c);
+void k_fri_leaves_layer0(dst_ctx* c);
+void k_fri_leaves(dst_ctx* c, int layer);
+// AIR
+int k_eval_constraints(dst_ctx* c, const fe* coeffs_dev, const fe* tc_dev, int64_t* bad_step);
+// polynomial helpers
+void k_syn_div(dst_ctx* c, fe* a, size_t len, fe b);                                    // polynom.rs:190 semantics, in place
+void k_syn_div_expanded(dst_ctx* c, const fe* a, fe* out, size_t len, size_t degree, fe exception);
+void k_horner(dst_ctx* c, const fe* polys, size_t ncols, size_t len, fe x, fe* out_dev);
+void k_lincomb(dst_ctx* c, const fe* cols, size_t ncols, size_t len, const fe* coeffs_dev, fe* out);
+void k_axpy(dst_ctx* c, fe* y, const fe* x, fe a, size_t len);                           // y += a * x
+void k_add(dst_ctx* c, fe* y, const fe* x, size_t len);                                  // y += x
+void k_sub_dot_at0(dst_ctx* c, fe* y, const fe* values_dev, const fe* coeffs_dev, size_t count);   // y[0] -= sum values[k]*coeffs[k]
+void k_sub_at0(dst_ctx* c, fe* y, const fe* v_dev);                                                   // y[0] -= v[0]
+// FRI
+void k_fri_fold(dst_ctx* c, int layer, fe special_x);
+// PoW
+int k_pow(dst_ctx* c, const uint8_t seed[32], uint32_t grinding, uint64_t* nonce);
+// gathers for openings
+void k_gather(dst_ctx* c, const void* src, size_t item_bytes, const uint64_t* idx_dev, size_t count, void* dst);
+void k_gather_rows(dst_ctx* c, const uint64_t* positions_dev, size_t count, fe* out);
+int k_bench_mulmod(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms);

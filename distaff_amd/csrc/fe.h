@@ -1,0 +1,173 @@
+// Field arithmetic for the 128-bit STARK field of Distaff, p = 2^128 - 45*2^40 + 1, written for CDNA4 VALU:
+// an element is four little-endian 32-bit limbs (one 16-byte global/LDS access), products are formed with
+// 32x32+64 multiply-adds (v_mad_u64_u32) and reduced with 2^128 = 45*2^40 - 1 (mod p), i.e. a multiply of the
+// high half by the 14-bit constant 45*2^8 plus a limb shift.  No 64x64 multiplies, no divisions, no MFMA.
+// Semantics mirror /root/reference/src/math/field.rs (add :27, sub :33, mul :38, exp :201, inv :83): canonical
+// inputs in [0, p) give canonical outputs.  The same code compiles for the host (tables are built there).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define FE_HD __host__ __device__ __forceinline__
+#else
+#define FE_HD inline
+#endif
+
+struct __attribute__((aligned(16))) fe { uint32_t v[4]; };
+
+#define FE_P0 0x00000001u
+#define FE_P1 0xFFFFD300u
+#define FE_P2 0xFFFFFFFFu
+#define FE_P3 0xFFFFFFFFu
+// C128 = 2^128 mod p = 45*2^40 - 1 = 0x00002CFF_FFFFFFFF
+#define FE_C0 0xFFFFFFFFu
+#define FE_C1 0x00002CFFu
+#define FE_K  11520u            // 45 * 2^8: (hi * 45) << 40 == (hi * 11520) << 32
+
+FE_HD fe fe_make(uint32_t a, uint32_t b, uint32_t c, uint32_t d) { fe r; r.v[0] = a; r.v[1] = b; r.v[2] = c; r.v[3] = d; return r; }
+FE_HD fe fe_zero() { return fe_make(0, 0, 0, 0); }
+FE_HD fe fe_one() { return fe_make(1, 0, 0, 0); }
+FE_HD fe fe_from_u64(uint64_t x) { return fe_make((uint32_t)x, (uint32_t)(x >> 32), 0, 0); }
+FE_HD bool fe_is_zero(const fe& a) { return (a.v[0] | a.v[1] | a.v[2] | a.v[3]) == 0; }
+FE_HD bool fe_eq(const fe& a, const fe& b) { return ((a.v[0] ^ b.v[0]) | (a.v[1] ^ b.v[1]) | (a.v[2] ^ b.v[2]) | (a.v[3] ^ b.v[3])) == 0; }
+
+FE_HD fe fe_add(const fe& a, const fe& b) {
+    // s = a + b; t = s + C128; a + b >= p  <=>  a + b + C128 >= 2^128
+    uint64_t c = (uint64_t)a.v[0] + b.v[0];               uint32_t s0 = (uint32_t)c;
+    c = (uint64_t)a.v[1] + b.v[1] + (c >> 32);            uint32_t s1 = (uint32_t)c;
+    c = (uint64_t)a.v[2] + b.v[2] + (c >> 32);            uint32_t s2 = (uint32_t)c;
+    c = (uint64_t)a.v[3] + b.v[3] + (c >> 32);            uint32_t s3 = (uint32_t)c;
+    uint32_t cs = (uint32_t)(c >> 32);
+    uint64_t d = (uint64_t)s0 + FE_C0;                    uint32_t t0 = (uint32_t)d;
+    d = (uint64_t)s1 + FE_C1 + (d >> 32);                 uint32_t t1 = (uint32_t)d;
+    d = (uint64_t)s2 + (d >> 32);                         uint32_t t2 = (uint32_t)d;
+    d = (uint64_t)s3 + (d >> 32);                         uint32_t t3 = (uint32_t)d;
+    bool over = (cs | (uint32_t)(d >> 32)) != 0;
+    return over ? fe_make(t0, t1, t2, t3) : fe_make(s0, s1, s2, s3);
+}
+
+FE_HD fe fe_sub(const fe& a, const fe& b) {
+    // d = a - b; on borrow add p, i.e. subtract C128 modulo 2^128
+    int64_t c = (int64_t)(uint64_t)a.v[0] - b.v[0];                 uint32_t d0 = (uint32_t)c;
+    c = (int64_t)(uint64_t)a.v[1] - b.v[1] + (c >> 32);             uint32_t d1 = (uint32_t)c;
+    c = (int64_t)(uint64_t)a.v[2] - b.v[2] + (c >> 32);             uint32_t d2 = (uint32_t)c;
+    c = (int64_t)(uint64_t)a.v[3] - b.v[3] + (c >> 32);             uint32_t d3 = (uint32_t)c;
+    bool borrow = (c >> 32) != 0;
+    int64_t e = (int64_t)(uint64_t)d0 - FE_C0;                      uint32_t e0 = (uint32_t)e;
+    e = (int64_t)(uint64_t)d1 - FE_C1 + (e >> 32);                  uint32_t e1 = (uint32_t)e;
+    e = (int64_t)(uint64_t)d2 + (e >> 32);                          uint32_t e2 = (uint32_t)e;
+    e = (int64_t)(uint64_t)d3 + (e >> 32);                          uint32_t e3 = (uint32_t)e;
+    return borrow ? fe_make(e0, e1, e2, e3) : fe_make(d0, d1, d2, d3);
+}
+
+FE_HD fe fe_neg(const fe& a) { return fe_sub(fe_zero(), a); }
+FE_HD fe fe_double(const fe& a) { return fe_add(a, a); }
+
+// reduce an 8-limb product t (< p^2) to a canonical element
+FE_HD fe fe_reduce8(const uint32_t* t) {
+    // fold 1: v = lo + ((hi * K) << 32) - hi   (6 limbs, v < 2^174, never negative because hi*K*2^32 >= hi)
+    uint64_t c = (uint64_t)t[4] * FE_K;                 uint32_t m0 = (uint32_t)c;
+    c = (uint64_t)t[5] * FE_K + (c >> 32);              uint32_t m1 = (uint32_t)c;
+    c = (uint64_t)t[6] * FE_K + (c >> 32);              uint32_t m2 = (uint32_t)c;
+    c = (uint64_t)t[7] * FE_K + (c >> 32);              uint32_t m3 = (uint32_t)c;
+    uint32_t m4 = (uint32_t)(c >> 32);                  // < 2^14
+    // u = lo + (m << 32)
+    uint32_t u0 = t[0];
+    c = (uint64_t)t[1] + m0;                            uint32_t u1 = (uint32_t)c;
+    c = (uint64_t)t[2] + m1 + (c >> 32);                uint32_t u2 = (uint32_t)c;
+    c = (uint64_t)t[3] + m2 + (c >> 32);                uint32_t u3 = (uint32_t)c;
+    c = (uint64_t)m3 + (c >> 32);                       uint32_t u4 = (uint32_t)c;
+    uint32_t u5 = m4 + (uint32_t)(c >> 32);
+    // v = u - hi
+    int64_t b = (int64_t)(uint64_t)u0 - t[4];                       uint32_t v0 = (uint32_t)b;
+    b = (int64_t)(uint64_t)u1 - t[5] + (b >> 32);                   uint32_t v1 = (uint32_t)b;
+    b = (int64_t)(uint64_t)u2 - t[6] + (b >> 32);                   uint32_t v2 = (uint32_t)b;
+    b = (int64_t)(uint64_t)u3 - t[7] + (b >> 32);                   uint32_t v3 = (uint32_t)b;
+    b = (int64_t)(uint64_t)u4 + (b >> 32);                          uint32_t v4 = (uint32_t)b;
+    uint32_t v5 = u5 + (uint32_t)(b >> 32);
+    // fold 2: y = v_lo + ((vh * K) << 32) - vh, vh = v5:v4 < 2^46, vh*K < 2^60
+    uint64_t vh = ((uint64_t)v5 << 32) | v4;
+    uint64_t w = vh * FE_K;
+    uint32_t w0 = (uint32_t)w, w1 = (uint32_t)(w >> 32);
+    uint32_t y0 = v0;
+    c = (uint64_t)v1 + w0;                              uint32_t y1 = (uint32_t)c;
+    c = (uint64_t)v2 + w1 + (c >> 32);                  uint32_t y2 = (uint32_t)c;
+    c = (uint64_t)v3 + (c >> 32);                       uint32_t y3 = (uint32_t)c;
+    uint32_t y4 = (uint32_t)(c >> 32);                  // 0 or 1
+    b = (int64_t)(uint64_t)y0 - v4;                                 y0 = (uint32_t)b;
+    b = (int64_t)(uint64_t)y1 - v5 + (b >> 32);                     y1 = (uint32_t)b;
+    b = (int64_t)(uint64_t)y2 + (b >> 32);                          y2 = (uint32_t)b;
+    b = (int64_t)(uint64_t)y3 + (b >> 32);                          y3 = (uint32_t)b;
+    y4 += (uint32_t)(b >> 32);                          // borrow propagates into the single overflow bit
+    // fold 3: if y4 == 1 then y = y_lo + C128 (y_lo < 2^93 in that case: no further carry)
+    uint32_t k0 = y4 ? FE_C0 : 0u, k1 = y4 ? FE_C1 : 0u;
+    c = (uint64_t)y0 + k0;                              y0 = (uint32_t)c;
+    c = (uint64_t)y1 + k1 + (c >> 32);                  y1 = (uint32_t)c;
+    c = (uint64_t)y2 + (c >> 32);                       y2 = (uint32_t)c;
+    c = (uint64_t)y3 + (c >> 32);                       y3 = (uint32_t)c;
+    // final conditional subtraction of p: y >= p <=> y + C128 overflows 2^128
+    uint64_t d = (uint64_t)y0 + FE_C0;                  uint32_t z0 = (uint32_t)d;
+    d = (uint64_t)y1 + FE_C1 + (d >> 32);               uint32_t z1 = (uint32_t)d;
+    d = (uint64_t)y2 + (d >> 32);                       uint32_t z2 = (uint32_t)d;
+    d = (uint64_t)y3 + (d >> 32);                       uint32_t z3 = (uint32_t)d;
+    bool ge = (d >> 32) != 0;
+    return ge ? fe_make(z0, z1, z2, z3) : fe_make(y0, y1, y2, y3);
+}
+
+FE_HD fe fe_mul(const fe& a, const fe& b) {
+    uint32_t t[8];
+    uint64_t c;
+    // row 0
+    c = (uint64_t)a.v[0] * b.v[0];                              t[0] = (uint32_t)c;
+    c = (uint64_t)a.v[0] * b.v[1] + (c >> 32);                  t[1] = (uint32_t)c;
+    c = (uint64_t)a.v[0] * b.v[2] + (c >> 32);                  t[2] = (uint32_t)c;
+    c = (uint64_t)a.v[0] * b.v[3] + (c >> 32);                  t[3] = (uint32_t)c;
+    t[4] = (uint32_t)(c >> 32);
+#pragma unroll
+    for (int i = 1; i < 4; i++) {
+        c = (uint64_t)a.v[i] * b.v[0] + t[i];                       t[i] = (uint32_t)c;
+        c = (uint64_t)a.v[i] * b.v[1] + t[i + 1] + (c >> 32);       t[i + 1] = (uint32_t)c;
+        c = (uint64_t)a.v[i] * b.v[2] + t[i + 2] + (c >> 32);       t[i + 2] = (uint32_t)c;
+        c = (uint64_t)a.v[i] * b.v[3] + t[i + 3] + (c >> 32);       t[i + 3] = (uint32_t)c;
+        t[i + 4] = (uint32_t)(c >> 32);
+    }
+    return fe_reduce8(t);
+}
+
+FE_HD fe fe_sqr(const fe& a) { return fe_mul(a, a); }
+
+// multiplication by a small constant (< 2^32)
+FE_HD fe fe_mul_small(const fe& a, uint32_t k) {
+    uint32_t t[8];
+    uint64_t c = (uint64_t)a.v[0] * k;                  t[0] = (uint32_t)c;
+    c = (uint64_t)a.v[1] * k + (c >> 32);               t[1] = (uint32_t)c;
+    c = (uint64_t)a.v[2] * k + (c >> 32);               t[2] = (uint32_t)c;
+    c = (uint64_t)a.v[3] * k + (c >> 32);               t[3] = (uint32_t)c;
+    t[4] = (uint32_t)(c >> 32); t[5] = 0; t[6] = 0; t[7] = 0;
+    return fe_reduce8(t);
+}
+
+FE_HD fe fe_cube(const fe& a) { return fe_mul(fe_sqr(a), a); }
+
+// b^e for a 128-bit exponent given as limbs (0^e = 0, b^0 = 1 for b != 0, as field.rs:201-203)
+FE_HD fe fe_pow(fe b, const fe& e) {
+    if (fe_is_zero(b)) return fe_zero();
+    fe r = fe_one();
+    for (int l = 0; l < 4; l++) {
+        uint32_t w = e.v[l];
+        bool rest = false;
+        for (int k = l + 1; k < 4; k++) rest |= e.v[k] != 0;
+        for (int i = 0; i < 32; i++) {
+            if (w & 1) r = fe_mul(r, b);
+            w >>= 1;
+            if (w == 0 && !rest) break;
+            b = fe_sqr(b);
+        }
+        if (!rest) break;
+    }
+    return r;
+}
+FE_HD fe fe_pow_u64(const fe& b, uint64_t e) { return fe_pow(b, fe_from_u64(e)); }
+FE_HD fe fe_inv(const fe& a) {          // a^(p-2); inv(0) = 0 (field.rs:84)
+    return fe_pow(a, fe_make(0xFFFFFFFFu, 0xFFFFD2FFu, 0xFFFFFFFFu, 0xFFFFFFFFu));   // exponent p - 2
+}

@@ -1,0 +1,222 @@
+// BLAKE3 leaf hashing and Merkle tree construction for gfx950.
+//
+// Replaces TraceTable::build_merkle_tree (/root/reference/src/stark/trace/trace_table.rs:174-185), MerkleTree::new /
+// build_merkle_nodes (src/crypto/merkle.rs:25,269-294), evaluations_to_leaves (src/stark/prover.rs:180-187) and
+// fri::utils::hash_values (src/stark/fri/utils.rs:16-22).  One lane hashes one leaf / one node; kernels that consume
+// coset-major evaluations emit natural-order digests through an LDS tile transpose, so that global reads are
+// KT*16-byte runs along k and global writes are JT*32-byte runs along the leaf index.
+#include "ctx.h"
+#include "blake3_dev.h"
+
+#define HASH_THREADS 256
+
+__device__ __forceinline__ void store_digest(digest* p, const uint32_t* cv) {
+    uint4* q = reinterpret_cast<uint4*>(p);
+    q[0] = make_uint4(cv[0], cv[1], cv[2], cv[3]);
+    q[1] = make_uint4(cv[4], cv[5], cv[6], cv[7]);
+}
+
+// BLAKE3 of `count` field elements read through `get(i)`; count * 16 <= 2032 bytes (one or two chunks)
+template <class Get>
+__device__ __forceinline__ void hash_elements(Get get, uint32_t count, uint32_t* out8) {
+    uint32_t cv[8], cv1[8];
+    const uint32_t first = count < 64u ? count : 64u;       // elements in chunk 0 (1024 bytes = 64 elements)
+    const bool two_chunks = count > 64u;
+    for (int pass = 0; pass < 2; pass++) {
+        const uint32_t base = pass == 0 ? 0u : 64u;
+        const uint32_t cnt = pass == 0 ? first : count - 64u;
+        uint32_t* c = pass == 0 ? cv : cv1;
+        b3_iv(c);
+        const uint32_t blocks = (cnt + 3u) / 4u;
+        for (uint32_t b = 0; b < blocks; b++) {
+            uint32_t m[16];
+#pragma unroll
+            for (uint32_t e = 0; e < 4; e++) {
+                uint32_t i = b * 4u + e;
+                fe v = i < cnt ? get(base + i) : fe_zero();
+                m[4 * e] = v.v[0]; m[4 * e + 1] = v.v[1]; m[4 * e + 2] = v.v[2]; m[4 * e + 3] = v.v[3];
+            }
+            uint32_t rem = cnt - b * 4u;
+            uint32_t block_len = rem >= 4u ? 64u : rem * 16u;
+            uint32_t flags = (b == 0 ? B3_CHUNK_START : 0u) | (b == blocks - 1 ? (B3_CHUNK_END | (two_chunks ? 0u : B3_ROOT)) : 0u);
+            b3_compress(c, m, (uint32_t)pass, 0, block_len, flags);
+        }
+        if (!two_chunks) break;
+    }
+    if (two_chunks) {
+        uint32_t m[16];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { m[i] = cv[i]; m[8 + i] = cv1[i]; }
+        b3_iv(cv);
+        b3_compress(cv, m, 0, 0, 64, B3_PARENT | B3_ROOT);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; i++) out8[i] = cv[i];
+}
+
+// ---- trace leaves: leaf(B*k + j) = BLAKE3(reg_0 || ... || reg_{W-1}) at that row --------------------------------------------
+// block = KT x JT lanes (kk fastest on the read side, jj fastest on the write side); grid = (n / KT, Bc / JT)
+__global__ void __launch_bounds__(HASH_THREADS) trace_leaves_kernel(const fe* __restrict__ lde, digest* __restrict__ leaves,
+                                                                   uint32_t W, size_t n, uint32_t Bc, uint32_t log_jt) {
+    __shared__ digest tile[HASH_THREADS];
+    const uint32_t JT = 1u << log_jt, KT = HASH_THREADS >> log_jt;
+    const uint32_t kk = threadIdx.x % KT, jj = threadIdx.x / KT;
+    const size_t k = (size_t)blockIdx.x * KT + kk;
+    const uint32_t j = blockIdx.y * JT + jj;
+    const fe* base = lde + (size_t)j * n + k;
+    const size_t col_stride = (size_t)Bc * n;
+    uint32_t h[8];
+    hash_elements([&](uint32_t c) { return base[(size_t)c * col_stride]; }, W, h);
+    store_digest(&tile[kk * JT + jj], h);
+    __syncthreads();
+    const uint32_t kk2 = threadIdx.x >> log_jt, jj2 = threadIdx.x & (JT - 1);
+    const size_t out = ((size_t)blockIdx.x * KT + kk2) * Bc + blockIdx.y * JT + jj2;
+    leaves[out] = tile[kk2 * JT + jj2];
+}
+
+void k_trace_leaves(dst_ctx* c) {
+    uint32_t jt = c->Bc < 32 ? (uint32_t)c->Bc : 32u, log_jt = 0;
+    while ((1u << log_jt) < jt) log_jt++;
+    uint32_t KT = HASH_THREADS >> log_jt;
+    dim3 g((unsigned)(c->n / KT), (unsigned)(c->Bc >> log_jt));
+    hipLaunchKernelGGL(trace_leaves_kernel, g, dim3(HASH_THREADS), 0, c->stream, (const fe*)c->lde, c->trace_leaves, (uint32_t)c->W, c->n, (uint32_t)c->Bc, log_jt);
+}
+
+// ---- generic Merkle levels: out[i] = H(children[2i] || children[2i+1]) -------------------------------------------------------
+__global__ void __launch_bounds__(HASH_THREADS) merkle_level_kernel(const digest* __restrict__ children, digest* __restrict__ out, size_t count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint4* p = reinterpret_cast<const uint4*>(children + 2 * i);
+    uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+    uint32_t m[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+    uint32_t h[8];
+    b3_hash64(m, h);
+    store_digest(out + i, h);
+}
+
+// the top of the tree in one workgroup: nodes[count .. 2*count) are already valid, fills nodes[1 .. count)
+__global__ void __launch_bounds__(HASH_THREADS) merkle_top_kernel(digest* nodes, uint32_t count) {
+    for (uint32_t cnt = count >> 1; cnt >= 1; cnt >>= 1) {
+        for (uint32_t i = threadIdx.x; i < cnt; i += HASH_THREADS) {
+            const uint4* p = reinterpret_cast<const uint4*>(nodes + 2 * (cnt + i));
+            uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+            uint32_t m[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+            uint32_t h[8];
+            b3_hash64(m, h);
+            store_digest(nodes + cnt + i, h);
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    if (threadIdx.x < 8) nodes[0].w[threadIdx.x] = 0;          // merkle.rs:275
+}
+
+// builds nodes[1 .. count) from an already filled level nodes[count .. 2*count)
+static void merkle_upper_levels(dst_ctx* c, digest* nodes, size_t count) {
+    while (count > 1024) {
+        size_t cnt = count >> 1;
+        hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((cnt + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream,
+                           (const digest*)(nodes + count), nodes + cnt, cnt);
+        count = cnt;
+    }
+    hipLaunchKernelGGL(merkle_top_kernel, dim3(1), dim3(HASH_THREADS), 0, c->stream, nodes, (uint32_t)count);
+}
+
+void k_merkle_levels(dst_ctx* c, const digest* leaves, digest* nodes, size_t num_leaves) {
+    size_t cnt = num_leaves >> 1;
+    hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((cnt + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream,
+                       leaves, nodes + cnt, cnt);
+    merkle_upper_levels(c, nodes, cnt);
+}
+
+// ---- constraint tree: leaves are raw evaluation pairs (prover.rs:180-187); the first node level hashes four consecutive
+//      natural-order evaluations B*k + 4q .. 4q+3, i.e. cosets 4q..4q+3 at index k ---------------------------------------------
+__global__ void __launch_bounds__(HASH_THREADS) constraint_level1_kernel(const fe* __restrict__ cevals, digest* __restrict__ out,
+                                                                        size_t n, uint32_t Bc, uint32_t log_qt) {
+    __shared__ digest tile[HASH_THREADS];
+    const uint32_t QT = 1u << log_qt, KT = HASH_THREADS >> log_qt;
+    const uint32_t kk = threadIdx.x % KT, qq = threadIdx.x / KT;
+    const size_t k = (size_t)blockIdx.x * KT + kk;
+    const uint32_t q = blockIdx.y * QT + qq;
+    const fe* base = cevals + (size_t)(4 * q) * n + k;
+    uint32_t m[16], h[8];
+#pragma unroll
+    for (uint32_t e = 0; e < 4; e++) {
+        fe v = base[(size_t)e * n];
+        m[4 * e] = v.v[0]; m[4 * e + 1] = v.v[1]; m[4 * e + 2] = v.v[2]; m[4 * e + 3] = v.v[3];
+    }
+    b3_hash64(m, h);
+    store_digest(&tile[kk * QT + qq], h);
+    __syncthreads();
+    const uint32_t kk2 = threadIdx.x >> log_qt, qq2 = threadIdx.x & (QT - 1);
+    const size_t o = ((size_t)blockIdx.x * KT + kk2) * (Bc / 4) + blockIdx.y * QT + qq2;
+    out[o] = tile[kk2 * QT + qq2];
+}
+
+void k_constraint_tree(dst_ctx* c) {
+    uint32_t qn = (uint32_t)(c->Bc / 4);
+    uint32_t qt = qn < 32 ? qn : 32u, log_qt = 0;
+    while ((1u << log_qt) < qt) log_qt++;
+    uint32_t KT = HASH_THREADS >> log_qt;
+    size_t level1 = c->N / 4;          // leaves = N/2, first node level = N/4 entries at nodes[N/4 ..)
+    dim3 g((unsigned)(c->n / KT), (unsigned)(qn >> log_qt));
+    hipLaunchKernelGGL(constraint_level1_kernel, g, dim3(HASH_THREADS), 0, c->stream, (const fe*)c->cevals, c->cnodes + level1, c->n, (uint32_t)c->Bc, log_qt);
+    merkle_upper_levels(c, c->cnodes, level1);
+}
+
+// ---- FRI leaves: leaf(r) = BLAKE3(e[r] || e[r+R] || e[r+2R] || e[r+3R]), R = N_d / 4 (quartic.rs:137, fri/utils.rs:16) ----------
+// layer 0 reads the coset-major composition evaluations: r = B*k + j with k < n/4, and r + s*R = B*(k + s*n/4) + j
+__global__ void __launch_bounds__(HASH_THREADS) fri_leaves0_kernel(const fe* __restrict__ comp, digest* __restrict__ leaves,
+                                                                  size_t n, uint32_t Bc, uint32_t log_jt) {
+    __shared__ digest tile[HASH_THREADS];
+    const uint32_t JT = 1u << log_jt, KT = HASH_THREADS >> log_jt;
+    const uint32_t kk = threadIdx.x % KT, jj = threadIdx.x / KT;
+    const size_t k = (size_t)blockIdx.x * KT + kk;
+    const uint32_t j = blockIdx.y * JT + jj;
+    const fe* base = comp + (size_t)j * n + k;
+    const size_t q = n / 4;
+    uint32_t m[16], h[8];
+#pragma unroll
+    for (uint32_t e = 0; e < 4; e++) {
+        fe v = base[(size_t)e * q];
+        m[4 * e] = v.v[0]; m[4 * e + 1] = v.v[1]; m[4 * e + 2] = v.v[2]; m[4 * e + 3] = v.v[3];
+    }
+    b3_hash64(m, h);
+    store_digest(&tile[kk * JT + jj], h);
+    __syncthreads();
+    const uint32_t kk2 = threadIdx.x >> log_jt, jj2 = threadIdx.x & (JT - 1);
+    const size_t o = ((size_t)blockIdx.x * KT + kk2) * Bc + blockIdx.y * JT + jj2;
+    leaves[o] = tile[kk2 * JT + jj2];
+}
+
+void k_fri_leaves_layer0(dst_ctx* c) {
+    uint32_t jt = c->Bc < 32 ? (uint32_t)c->Bc : 32u, log_jt = 0;
+    while ((1u << log_jt) < jt) log_jt++;
+    uint32_t KT = HASH_THREADS >> log_jt;
+    size_t kq = c->n / 4;
+    if (kq < KT) {   // tiny traces: shrink the tile along k by growing it along j is not possible; fall back to one k per block row
+        KT = (uint32_t)kq;
+    }
+    dim3 g((unsigned)(kq / KT), (unsigned)(c->Bc >> log_jt));
+    // note: when KT was reduced the kernel still derives KT from HASH_THREADS >> log_jt, so tiny sizes use the natural-order path instead
+    hipLaunchKernelGGL(fri_leaves0_kernel, g, dim3(HASH_THREADS), 0, c->stream, (const fe*)c->comp, c->fri_leaves[0], c->n, (uint32_t)c->Bc, log_jt);
+}
+
+__global__ void __launch_bounds__(HASH_THREADS) fri_leaves_kernel(const fe* __restrict__ e, digest* __restrict__ leaves, size_t R) {
+    size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    uint32_t m[16], h[8];
+#pragma unroll
+    for (uint32_t s = 0; s < 4; s++) {
+        fe v = e[r + (size_t)s * R];
+        m[4 * s] = v.v[0]; m[4 * s + 1] = v.v[1]; m[4 * s + 2] = v.v[2]; m[4 * s + 3] = v.v[3];
+    }
+    b3_hash64(m, h);
+    store_digest(leaves + r, h);
+}
+
+void k_fri_leaves(dst_ctx* c, int layer) {
+    size_t R = c->fri_size[layer] / 4;
+    hipLaunchKernelGGL(fri_leaves_kernel, dim3((unsigned)((R + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream,
+                       (const fe*)c->fri_e[layer], c->fri_leaves[layer], R);
+}

@@ -1,0 +1,242 @@
+// NTT / low-degree-extension kernels for gfx950.
+//
+// Replaces the recursive radix-2 `fft_in_place` (+ `permute`) of /root/reference/src/math/fft.rs:16-108 as it is used by
+// TraceTable::extend (src/stark/trace/trace_table.rs:143-169), ConstraintTable::combine_polys (constraint_table.rs:54-88),
+// ConstraintPoly::eval (constraint_poly.rs:28-37) and the composition evaluation (prover.rs:98-101).  Field results are
+// unique, so the algorithm is free: every transform here is a size-n = n1*n2 "four-step" NTT run as two HBM passes,
+//   pass A: for a tile of T adjacent columns m2, the n1-point NTT over the stride-n2 dimension, in LDS (radix-2 DIF),
+//           fused with the coset pre-scale w_N^(j*n2*m1) on load and the four-step twiddle w_N^(m2*(B*k1+j)) on store;
+//   pass B: for a tile of T adjacent rows k1, the n2-point NTT over the contiguous dimension, in LDS, stored as
+//           X[k1 + n1*k2] so that the output is in natural order.
+// The low-degree extension never materialises the zero-padded size-N input of the reference: the N = B*n evaluations
+// are B coset transforms of size n (coset j holds the reference's indices B*k + j), stored coset-major.
+// Loads/stores are T*16-byte segments (T = 4: 64 B); the working set of one workgroup is 2^log * T * 16 B of LDS.
+#include "ctx.h"
+
+#define NTT_THREADS 256
+
+struct NttArgs {
+    const fe* src; fe* dst;
+    size_t src_col_stride, src_coset_stride;   // elements
+    size_t dst_col_stride, dst_coset_stride;
+    const fe* stage_tw;        // w_len^t, t < len/2 (forward or inverse)
+    const fe* tw_lo; const fe* tw_hi;           // two-level table of the domain generator (forward or inverse, maybe pre-scaled)
+    const fe* prescale;        // w_{B*n1}^t or nullptr
+    uint32_t log_n1, log_n2, tile, lo_bits, log_N, log_b;
+    uint32_t j0;               // global index of the first local coset (0 when `coset_twiddle` is off)
+    uint32_t coset_twiddle;    // 1: four-step twiddle includes the coset offset j (LDE), 0: plain transform
+    uint32_t has_scale;        // 1: multiply the result by `scale` (1/n of inverse transforms)
+    fe scale;
+};
+
+__device__ __forceinline__ fe load_fe(const fe* p) { return *p; }
+
+__device__ __forceinline__ fe dom_pow(const fe* lo, const fe* hi, uint32_t lo_bits, uint64_t e) {
+    uint32_t l = (uint32_t)e & ((1u << lo_bits) - 1u), h = (uint32_t)(e >> lo_bits);
+    fe a = lo[l];
+    if (h == 0) return a;
+    return fe_mul(a, hi[h]);
+}
+
+// in-LDS radix-2 DIF over the first index of L[len][T]; output position r holds frequency bitrev(r)
+__device__ __forceinline__ void lds_ntt_dif(fe* L, const fe* __restrict__ W, uint32_t log_len, uint32_t T) {
+    const uint32_t half = 1u << (log_len - 1);
+    for (uint32_t s = 1; s <= log_len; s++) {
+        const uint32_t ld = log_len - s;             // log2 of butterfly distance
+        const uint32_t d = 1u << ld;
+        for (uint32_t w = threadIdx.x; w < half * T; w += NTT_THREADS) {
+            uint32_t t = w % T, q = w / T;
+            uint32_t pos = q & (d - 1), blk = q >> ld;
+            uint32_t i0 = (blk << (ld + 1)) + pos, i1 = i0 + d;
+            fe a = L[i0 * T + t], b = L[i1 * T + t];
+            L[i0 * T + t] = fe_add(a, b);
+            fe diff = fe_sub(a, b);
+            L[i1 * T + t] = (s == log_len) ? diff : fe_mul(diff, W[pos << (s - 1)]);
+        }
+        __syncthreads();
+    }
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
+
+// grid: (n2 / T, cosets, columns)
+__global__ void __launch_bounds__(NTT_THREADS) ntt_pass_a(NttArgs a) {
+    fe* L = reinterpret_cast<fe*>(ntt_smem);
+    const uint32_t T = a.tile, n1 = 1u << a.log_n1, n2 = 1u << a.log_n2;
+    const uint32_t m2_0 = blockIdx.x * T;
+    const uint32_t jl = blockIdx.y, jg = a.j0 + jl;
+    const fe* src = a.src + (size_t)blockIdx.z * a.src_col_stride + (size_t)jl * a.src_coset_stride;
+    fe* dst = a.dst + (size_t)blockIdx.z * a.dst_col_stride + (size_t)jl * a.dst_coset_stride;
+    const uint32_t pmask = (1u << (a.log_b + a.log_n1)) - 1u;
+    for (uint32_t idx = threadIdx.x; idx < n1 * T; idx += NTT_THREADS) {
+        uint32_t t = idx % T, m1 = idx / T;
+        fe v = src[(size_t)m1 * n2 + m2_0 + t];
+        if (a.prescale != nullptr && jg != 0) v = fe_mul(v, a.prescale[(jg * m1) & pmask]);
+        L[idx] = v;
+    }
+    __syncthreads();
+    lds_ntt_dif(L, a.stage_tw, a.log_n1, T);
+    const uint64_t nmask = (1ull << a.log_N) - 1ull;
+    for (uint32_t idx = threadIdx.x; idx < n1 * T; idx += NTT_THREADS) {
+        uint32_t t = idx % T, r = idx / T;
+        uint32_t k1 = __brev(r) >> (32 - a.log_n1);
+        uint32_t m2 = m2_0 + t;
+        uint64_t e = ((uint64_t)m2 * (((uint64_t)k1 << a.log_b) + (a.coset_twiddle ? jg : 0u))) & nmask;
+        fe v = L[idx];
+        if (e != 0) v = fe_mul(v, dom_pow(a.tw_lo, a.tw_hi, a.lo_bits, e));
+        dst[(size_t)k1 * n2 + m2] = v;
+    }
+}
+
+// grid: (n1 / T, cosets, columns)
+__global__ void __launch_bounds__(NTT_THREADS) ntt_pass_b(NttArgs a) {
+    fe* L = reinterpret_cast<fe*>(ntt_smem);
+    const uint32_t T = a.tile, n1 = 1u << a.log_n1, n2 = 1u << a.log_n2;
+    const uint32_t k1_0 = blockIdx.x * T;
+    const uint32_t jl = blockIdx.y;
+    const fe* src = a.src + (size_t)blockIdx.z * a.src_col_stride + (size_t)jl * a.src_coset_stride;
+    fe* dst = a.dst + (size_t)blockIdx.z * a.dst_col_stride + (size_t)jl * a.dst_coset_stride;
+    for (uint32_t idx = threadIdx.x; idx < n2 * T; idx += NTT_THREADS) {
+        uint32_t m2 = idx % n2, t = idx / n2;                       // contiguous reads along m2
+        L[m2 * T + t] = src[(size_t)(k1_0 + t) * n2 + m2];
+    }
+    __syncthreads();
+    lds_ntt_dif(L, a.stage_tw, a.log_n2, T);
+    for (uint32_t idx = threadIdx.x; idx < n2 * T; idx += NTT_THREADS) {
+        uint32_t t = idx % T, r = idx / T;
+        uint32_t k2 = a.log_n2 ? (__brev(r) >> (32 - a.log_n2)) : 0u;
+        fe v = L[idx];
+        if (a.has_scale) v = fe_mul(v, a.scale);
+        dst[(size_t)k2 * n1 + k1_0 + t] = v;
+    }
+}
+
+static void launch_two_pass(dst_ctx* c, const fe* src, size_t src_col_stride, size_t src_coset_stride,
+                            fe* dst, size_t dst_col_stride, size_t dst_coset_stride,
+                            size_t cosets, size_t cols, bool inverse, bool lde) {
+    const NttPlan& p = c->plan;
+    NttArgs a{};
+    a.log_n1 = p.log_n1; a.log_n2 = p.log_n2; a.log_N = c->log_N; a.log_b = c->log_b; a.lo_bits = c->tw_lo_bits;
+    a.j0 = lde ? (uint32_t)c->j0 : 0u; a.coset_twiddle = lde ? 1u : 0u;
+    a.tw_lo = inverse ? c->itw_lo : c->tw_lo;
+    a.tw_hi = inverse ? c->itw_hi : c->tw_hi;
+    a.prescale = lde ? c->prescale : nullptr;
+    a.has_scale = inverse ? 1u : 0u; a.scale = c->n_inv;
+    // pass A: src -> tmp
+    a.src = src; a.src_col_stride = src_col_stride; a.src_coset_stride = src_coset_stride;
+    a.dst = c->tmp; a.dst_coset_stride = c->n; a.dst_col_stride = c->n * cosets;
+    a.stage_tw = inverse ? c->w1i : c->w1f; a.tile = p.tile_a;
+    size_t lds_a = ((size_t)1 << p.log_n1) * p.tile_a * sizeof(fe);
+    dim3 ga((unsigned)((1u << p.log_n2) / p.tile_a), (unsigned)cosets, (unsigned)cols);
+    hipLaunchKernelGGL(ntt_pass_a, ga, dim3(NTT_THREADS), lds_a, c->stream, a);
+    // pass B: tmp -> dst
+    a.src = c->tmp; a.src_coset_stride = c->n; a.src_col_stride = c->n * cosets;
+    a.dst = dst; a.dst_col_stride = dst_col_stride; a.dst_coset_stride = dst_coset_stride;
+    a.stage_tw = inverse ? c->w2i : c->w2f; a.tile = p.tile_b;
+    size_t lds_b = ((size_t)1 << p.log_n2) * p.tile_b * sizeof(fe);
+    dim3 gb((unsigned)((1u << p.log_n1) / p.tile_b), (unsigned)cosets, (unsigned)cols);
+    hipLaunchKernelGGL(ntt_pass_b, gb, dim3(NTT_THREADS), lds_b, c->stream, a);
+}
+
+// how many (coset x column) size-n arrays fit in c->tmp
+static size_t tmp_capacity_arrays(const dst_ctx* c) { return c->Bc * 4; }
+
+void k_intt_columns(dst_ctx* c, const fe* src, fe* dst, size_t ncols) {
+    size_t cap = tmp_capacity_arrays(c);
+    for (size_t done = 0; done < ncols;) {
+        size_t cols = ncols - done < cap ? ncols - done : cap;
+        launch_two_pass(c, src + done * c->n, c->n, 0, dst + done * c->n, c->n, 0, 1, cols, true, false);
+        done += cols;
+    }
+}
+
+void k_lde_columns(dst_ctx* c, const fe* polys, fe* lde, size_t ncols) {
+    size_t cap = tmp_capacity_arrays(c) / c->Bc;
+    for (size_t done = 0; done < ncols;) {
+        size_t cols = ncols - done < cap ? ncols - done : cap;
+        launch_two_pass(c, polys + done * c->n, c->n, 0, lde + done * c->Bc * c->n, c->Bc * c->n, c->n, c->Bc, cols, false, true);
+        done += cols;
+    }
+}
+
+// ---- 8n coefficients -> coset-major evaluations -------------------------------------------------------------------------
+// d_j[m0] = w_N^(j*m0) * sum_{m1<8} c[m0 + n*m1] * w_B^(j*m1); followed by a plain size-n NTT per coset.
+__global__ void fold8_kernel(const fe* __restrict__ poly, fe* __restrict__ out, const fe* tw_lo, const fe* tw_hi, uint32_t lo_bits,
+                             uint32_t log_n, uint32_t log_N, uint32_t j0) {
+    const size_t n = (size_t)1 << log_n;
+    const uint64_t nmask = ((uint64_t)1 << log_N) - 1;
+    size_t m0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m0 >= n) return;
+    uint32_t jg = j0 + blockIdx.y;
+    fe acc = poly[m0];
+    for (uint32_t m1 = 1; m1 < 8; m1++) {
+        uint64_t e = ((uint64_t)jg * m1 << log_n) & nmask;
+        fe v = poly[m0 + n * m1];
+        acc = fe_add(acc, e ? fe_mul(v, dom_pow(tw_lo, tw_hi, lo_bits, e)) : v);
+    }
+    uint64_t e0 = ((uint64_t)jg * m0) & nmask;
+    if (e0) acc = fe_mul(acc, dom_pow(tw_lo, tw_hi, lo_bits, e0));
+    out[(size_t)blockIdx.y * n + m0] = acc;
+}
+
+void k_lde_fold8(dst_ctx* c, const fe* poly8n, fe* out) {
+    // stage the folded inputs in `out` itself, then transform each coset in place (pass A reads out, pass B writes out)
+    dim3 g((unsigned)((c->n + 255) / 256), (unsigned)c->Bc);
+    hipLaunchKernelGGL(fold8_kernel, g, dim3(256), 0, c->stream, poly8n, out, c->tw_lo, c->tw_hi, c->tw_lo_bits, c->log_n, c->log_N, (uint32_t)c->j0);
+    launch_two_pass(c, out, 0, c->n, out, 0, c->n, c->Bc, 1, false, false);
+}
+
+// ---- inverse transform of size 8n from coset-major input ------------------------------------------------------------------
+// v[q][k] = V(w_8n^(8k+q)); c[m0 + n*m1] = (1/8n) sum_q w_8^(-q*m1) * w_8n^(-q*m0) * (sum_k v[q][k] w_n^(-k*m0)).
+__global__ void cross8_kernel(const fe* __restrict__ work, fe* __restrict__ out, const fe* itw_lo, const fe* itw_hi, uint32_t lo_bits,
+                              uint32_t log_n, uint32_t log_N, uint32_t log_b, fe eight_inv) {
+    const size_t n = (size_t)1 << log_n;
+    const uint64_t nmask = ((uint64_t)1 << log_N) - 1;
+    size_t m0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m0 >= n) return;
+    fe x[8];
+#pragma unroll
+    for (uint32_t q = 0; q < 8; q++) {
+        fe v = work[(size_t)q * n + m0];
+        uint64_t e = (((uint64_t)q * m0) << (log_b - 3)) & nmask;          // w_8n = w_N^(B/8)
+        x[q] = e ? fe_mul(v, dom_pow(itw_lo, itw_hi, lo_bits, e)) : v;
+    }
+    // 8-point DFT with root r = w_8^-1 = w_N^-(N/8): X[m1] = sum_q x[q] r^(q*m1)
+    fe r1 = dom_pow(itw_lo, itw_hi, lo_bits, (uint64_t)1 << (log_N - 3));
+    fe r2 = fe_sqr(r1), r3 = fe_mul(r2, r1);
+    // DIF radix-2, three stages
+    fe a0 = fe_add(x[0], x[4]), a4 = fe_sub(x[0], x[4]);
+    fe a1 = fe_add(x[1], x[5]), a5 = fe_mul(fe_sub(x[1], x[5]), r1);
+    fe a2 = fe_add(x[2], x[6]), a6 = fe_mul(fe_sub(x[2], x[6]), r2);
+    fe a3 = fe_add(x[3], x[7]), a7 = fe_mul(fe_sub(x[3], x[7]), r3);
+    fe b0 = fe_add(a0, a2), b2 = fe_sub(a0, a2);
+    fe b1 = fe_add(a1, a3), b3 = fe_mul(fe_sub(a1, a3), r2);
+    fe b4 = fe_add(a4, a6), b6 = fe_sub(a4, a6);
+    fe b5 = fe_add(a5, a7), b7 = fe_mul(fe_sub(a5, a7), r2);
+    fe X0 = fe_add(b0, b1), X4 = fe_sub(b0, b1);
+    fe X2 = fe_add(b2, b3), X6 = fe_sub(b2, b3);
+    fe X1 = fe_add(b4, b5), X5 = fe_sub(b4, b5);
+    fe X3 = fe_add(b6, b7), X7 = fe_sub(b6, b7);
+    out[m0] = fe_mul(X0, eight_inv);         out[m0 + n] = fe_mul(X1, eight_inv);
+    out[m0 + 2 * n] = fe_mul(X2, eight_inv); out[m0 + 3 * n] = fe_mul(X3, eight_inv);
+    out[m0 + 4 * n] = fe_mul(X4, eight_inv); out[m0 + 5 * n] = fe_mul(X5, eight_inv);
+    out[m0 + 6 * n] = fe_mul(X6, eight_inv); out[m0 + 7 * n] = fe_mul(X7, eight_inv);
+}
+
+void k_intt8_cosets(dst_ctx* c, fe* vals, fe* out8n, fe* work) {
+    launch_two_pass(c, vals, 0, c->n, work, 0, c->n, 8, 1, true, false);
+    hipLaunchKernelGGL(cross8_kernel, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream, (const fe*)work, out8n,
+                       c->itw_lo, c->itw_hi, c->tw_lo_bits, c->log_n, c->log_N, c->log_b, c->eight_inv);
+}
+
+// ---- layout conversion (inspection only) ------------------------------------------------------------------------------------
+__global__ void coset_to_natural_kernel(const fe* __restrict__ src, fe* __restrict__ dst, size_t n, size_t cosets) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * cosets) return;
+    size_t k = i / cosets, j = i % cosets;
+    dst[i] = src[j * n + k];
+}
+void k_coset_to_natural(dst_ctx* c, const fe* src, size_t cosets, fe* dst) {
+    size_t total = c->n * cosets;
+    hipLaunchKernelGGL(coset_to_natural_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, src, dst, c->n, cosets);
+}

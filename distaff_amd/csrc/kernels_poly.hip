@@ -1,0 +1,360 @@
+// Polynomial helpers, FRI folding, proof-of-work and gather kernels for gfx950.
+//
+// Replaces, with parallel formulations that give the same field elements:
+//   polynom::syn_div_in_place (/root/reference/src/math/polynom.rs:190-197)      -> scaled suffix scan
+//   polynom::syn_div_expanded_in_place (polynom.rs:202-236)                       -> strided suffix sums + one axpy
+//   polynom::eval (polynom.rs:9-17, Horner)                                       -> power-table product + tree reduction
+//   parallel::mul_acc / add_in_place (src/math/parallel.rs:132,37)                -> axpy / add / linear-combination kernels
+//   fri::reduce's quartic::interpolate_batch + evaluate_batch (src/stark/fri/prover.rs:23-31, src/math/quartic.rs:20,37)
+//                                                                                 -> closed-form 4-point fold
+//   utils::find_pow_nonce (src/stark/utils/proof_of_work.rs:4-32)                 -> batched nonce search with atomicMin
+#include "ctx.h"
+#include "blake3_dev.h"
+
+#define PT 256
+
+// ---- power tables of an arbitrary base: lo[t] = b^t (t < 2^lb), hi[h] = b^(h << lb) ------------------------------------------
+__global__ void pow_table_kernel(fe* lo, fe* hi, fe b, uint32_t lb, uint32_t hb) {
+    uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < (1u << lb)) lo[t] = fe_pow_u64(b, t);
+    if (t < (1u << hb)) hi[t] = fe_is_zero(b) ? (t == 0 ? fe_one() : fe_zero()) : fe_pow_u64(b, (uint64_t)t << lb);
+    if (t == 0) { lo[0] = fe_one(); hi[0] = fe_one(); }
+}
+struct PowTab { const fe* lo; const fe* hi; uint32_t lb; };
+__device__ __forceinline__ fe ptab(const PowTab& p, uint64_t e) {
+    uint32_t l = (uint32_t)e & ((1u << p.lb) - 1u), h = (uint32_t)(e >> p.lb);
+    fe v = p.lo[l];
+    return h ? fe_mul(v, p.hi[h]) : v;
+}
+// builds the tables for `b` into scratch memory at `where` (needs 2^lb + 2^hb elements)
+static PowTab build_pow_table(dst_ctx* c, fe* where, fe b, size_t max_exp) {
+    uint32_t bits = 1; while (((size_t)1 << bits) < max_exp + 1) bits++;
+    uint32_t lb = (bits + 1) / 2, hb = bits - lb;
+    fe* lo = where; fe* hi = where + ((size_t)1 << lb);
+    uint32_t cnt = 1u << lb;
+    hipLaunchKernelGGL(pow_table_kernel, dim3((cnt + PT - 1) / PT), dim3(PT), 0, c->stream, lo, hi, b, lb, hb);
+    PowTab t; t.lo = lo; t.hi = hi; t.lb = lb;
+    return t;
+}
+static size_t pow_table_elems(size_t max_exp) {
+    uint32_t bits = 1; while (((size_t)1 << bits) < max_exp + 1) bits++;
+    uint32_t lb = (bits + 1) / 2, hb = bits - lb;
+    return ((size_t)1 << lb) + ((size_t)1 << hb);
+}
+
+// ---- additive exclusive suffix scan: data[i] <- sum_{t > i} data[t] --------------------------------------------------------------
+#define SCAN_CHUNK 1024     // elements per workgroup (4 per lane)
+__global__ void __launch_bounds__(PT) scan_block_kernel(fe* data, size_t len, fe* block_sums) {
+    __shared__ fe sh[PT];
+    const size_t base = (size_t)blockIdx.x * SCAN_CHUNK;
+    fe v[4], run = fe_zero();
+    // lane owns 4 consecutive elements; local exclusive suffix within the lane
+#pragma unroll
+    for (int e = 3; e >= 0; e--) {
+        size_t i = base + (size_t)threadIdx.x * 4 + e;
+        fe x = i < len ? data[i] : fe_zero();
+        v[e] = run;
+        run = fe_add(run, x);
+    }
+    sh[threadIdx.x] = run;
+    __syncthreads();
+    // exclusive suffix scan of lane totals (Hillis-Steele on 256 entries)
+    fe incl = run;
+    for (int off = 1; off < PT; off <<= 1) {
+        fe other = (threadIdx.x + off < PT) ? sh[threadIdx.x + off] : fe_zero();
+        __syncthreads();
+        incl = fe_add(incl, other);
+        sh[threadIdx.x] = incl;
+        __syncthreads();
+    }
+    fe excl = (threadIdx.x + 1 < PT) ? sh[threadIdx.x + 1] : fe_zero();
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+        size_t i = base + (size_t)threadIdx.x * 4 + e;
+        if (i < len) data[i] = fe_add(v[e], excl);
+    }
+    if (threadIdx.x == 0 && block_sums) block_sums[blockIdx.x] = sh[0];
+}
+__global__ void scan_add_offsets_kernel(fe* data, size_t len, const fe* block_offsets) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    data[i] = fe_add(data[i], block_offsets[i / SCAN_CHUNK]);
+}
+// scratch must hold ceil(len / 1024) + ceil(len / 1024^2) + ... elements
+static void suffix_scan(dst_ctx* c, fe* data, size_t len, fe* scratch) {
+    size_t blocks = (len + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    if (blocks == 1) {
+        hipLaunchKernelGGL(scan_block_kernel, dim3(1), dim3(PT), 0, c->stream, data, len, (fe*)nullptr);
+        return;
+    }
+    hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)blocks), dim3(PT), 0, c->stream, data, len, scratch);
+    suffix_scan(c, scratch, blocks, scratch + blocks);
+    hipLaunchKernelGGL(scan_add_offsets_kernel, dim3((unsigned)((len + PT - 1) / PT)), dim3(PT), 0, c->stream, data, len, (const fe*)scratch);
+}
+
+// ---- synthetic division by (x - b): a[i] <- sum_{t > i} a[t] * b^(t - i - 1) ---------------------------------------------------
+__global__ void scale_by_powers_kernel(fe* a, size_t len, PowTab p, uint64_t offset) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    uint64_t e = i + offset;
+    if (e) a[i] = fe_mul(a[i], ptab(p, e));
+}
+__global__ void shift_down_kernel(const fe* src, fe* dst, size_t len) {      // b == 0: quotient is a shift
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    dst[i] = i + 1 < len ? src[i + 1] : fe_zero();
+}
+void k_syn_div(dst_ctx* c, fe* a, size_t len, fe b) {
+    unsigned g = (unsigned)((len + PT - 1) / PT);
+    fe* scr = c->scratch;
+    if (fe_is_zero(b)) {
+        hipLaunchKernelGGL(shift_down_kernel, dim3(g), dim3(PT), 0, c->stream, (const fe*)a, scr, len);
+        hipMemcpyAsync(a, scr, len * sizeof(fe), hipMemcpyDeviceToDevice, c->stream);
+        return;
+    }
+    size_t te = pow_table_elems(len + 1);
+    PowTab fw = build_pow_table(c, scr, b, len + 1);
+    PowTab bw = build_pow_table(c, scr + te, fe_inv(b), len + 1);
+    hipLaunchKernelGGL(scale_by_powers_kernel, dim3(g), dim3(PT), 0, c->stream, a, len, fw, (uint64_t)0);
+    suffix_scan(c, a, len, scr + 2 * te);
+    hipLaunchKernelGGL(scale_by_powers_kernel, dim3(g), dim3(PT), 0, c->stream, a, len, bw, (uint64_t)1);
+}
+
+// ---- division by (x^degree - 1) / (x - e) (polynom.rs:202-236) -------------------------------------------------------------------
+// r[i] = sum_{s >= 0} a[i + s*degree]; out[i] = r[degree + i - 1] - e * r[degree + i] for i <= len - degree, 0 above
+__global__ void syn_div_expanded_kernel(const fe* __restrict__ a, fe* __restrict__ out, size_t len, size_t degree, fe e) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    if (i > len - degree) { out[i] = fe_zero(); return; }
+    // r[t] for t = degree + i - 1 and t = degree + i (r[len] = 0)
+    fe r0 = fe_zero(), r1 = fe_zero();
+    for (size_t t = degree + i - 1; t < len; t += degree) r0 = fe_add(r0, a[t]);
+    for (size_t t = degree + i; t < len; t += degree) r1 = fe_add(r1, a[t]);
+    out[i] = fe_sub(r0, fe_mul(e, r1));
+}
+void k_syn_div_expanded(dst_ctx* c, const fe* a, fe* out, size_t len, size_t degree, fe exception) {
+    hipLaunchKernelGGL(syn_div_expanded_kernel, dim3((unsigned)((len + PT - 1) / PT)), dim3(PT), 0, c->stream, a, out, len, degree, exception);
+}
+
+// ---- evaluation of `ncols` polynomials of `len` coefficients at x -----------------------------------------------------------------
+__global__ void __launch_bounds__(PT) horner_partial_kernel(const fe* __restrict__ polys, size_t len, PowTab p, fe* __restrict__ partial) {
+    __shared__ fe sh[PT];
+    const fe* poly = polys + (size_t)blockIdx.y * len;
+    fe acc = fe_zero();
+    for (size_t i = (size_t)blockIdx.x * PT + threadIdx.x; i < len; i += (size_t)gridDim.x * PT) {
+        fe v = poly[i];
+        acc = fe_add(acc, i ? fe_mul(v, ptab(p, i)) : v);
+    }
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = PT / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] = fe_add(sh[threadIdx.x], sh[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = sh[0];
+}
+__global__ void __launch_bounds__(PT) reduce_rows_kernel(const fe* __restrict__ partial, size_t per_row, fe* __restrict__ out) {
+    __shared__ fe sh[PT];
+    fe acc = fe_zero();
+    for (size_t i = threadIdx.x; i < per_row; i += PT) acc = fe_add(acc, partial[(size_t)blockIdx.x * per_row + i]);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int off = PT / 2; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off) sh[threadIdx.x] = fe_add(sh[threadIdx.x], sh[threadIdx.x + off]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[blockIdx.x] = sh[0];
+}
+// results land in device memory `out_dev[ncols]`
+void k_horner(dst_ctx* c, const fe* polys, size_t ncols, size_t len, fe x, fe* out_dev) {
+    fe* scr = c->scratch;
+    size_t te = pow_table_elems(len);
+    PowTab p = build_pow_table(c, scr, x, len);
+    size_t blocks = (len + PT * 8 - 1) / (PT * 8);
+    if (blocks > 512) blocks = 512;
+    fe* partial = scr + te;
+    hipLaunchKernelGGL(horner_partial_kernel, dim3((unsigned)blocks, (unsigned)ncols), dim3(PT), 0, c->stream, polys, len, p, partial);
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)ncols), dim3(PT), 0, c->stream, (const fe*)partial, blocks, out_dev);
+}
+
+// ---- out[i] = sum_k coeffs[k] * cols[k][i] ------------------------------------------------------------------------------------------
+__global__ void lincomb_kernel(const fe* __restrict__ cols, size_t ncols, size_t len, const fe* __restrict__ coeffs, fe* __restrict__ out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= len) return;
+    fe acc = fe_zero();
+    for (size_t k = 0; k < ncols; k++) acc = fe_add(acc, fe_mul(cols[k * len + i], coeffs[k]));
+    out[i] = acc;
+}
+void k_lincomb(dst_ctx* c, const fe* cols, size_t ncols, size_t len, const fe* coeffs_dev, fe* out) {
+    hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)((len + PT - 1) / PT)), dim3(PT), 0, c->stream, cols, ncols, len, coeffs_dev, out);
+}
+__global__ void axpy_kernel(fe* y, const fe* x, fe a, size_t len) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < len) y[i] = fe_add(y[i], fe_mul(x[i], a));
+}
+void k_axpy(dst_ctx* c, fe* y, const fe* x, fe a, size_t len) {
+    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((len + PT - 1) / PT)), dim3(PT), 0, c->stream, y, x, a, len);
+}
+__global__ void add_kernel(fe* y, const fe* x, size_t len) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < len) y[i] = fe_add(y[i], x[i]);
+}
+void k_add(dst_ctx* c, fe* y, const fe* x, size_t len) {
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)((len + PT - 1) / PT)), dim3(PT), 0, c->stream, y, x, len);
+}
+// y[0] -= sum_k coeffs[k] * values[k]   (the constant terms T_k(z) * cc_k of trace_table.rs:226-233)
+__global__ void sub_dot_at0_kernel(fe* y, const fe* values, const fe* coeffs, size_t count) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        fe acc = y[0];
+        for (size_t k = 0; k < count; k++) acc = fe_sub(acc, fe_mul(values[k], coeffs[k]));
+        y[0] = acc;
+    }
+}
+void k_sub_dot_at0(dst_ctx* c, fe* y, const fe* values_dev, const fe* coeffs_dev, size_t count) {
+    hipLaunchKernelGGL(sub_dot_at0_kernel, dim3(1), dim3(64), 0, c->stream, y, values_dev, coeffs_dev, count);
+}
+__global__ void sub_at0_kernel(fe* y, const fe* v) { if (threadIdx.x == 0 && blockIdx.x == 0) y[0] = fe_sub(y[0], v[0]); }
+void k_sub_at0(dst_ctx* c, fe* y, const fe* v_dev) { hipLaunchKernelGGL(sub_at0_kernel, dim3(1), dim3(64), 0, c->stream, y, v_dev); }
+
+// ---- FRI fold -----------------------------------------------------------------------------------------------------------------------
+// row r of a layer of size M (R = M/4 rows) sits on xs = x * {1, i, -1, -i} with x = w_N^(r * stride) and i = w_N^(N/4);
+// the degree-3 interpolant evaluated at alpha is (1/4) * sum_j (alpha / x)^j * sum_k y_k i^(-jk).
+struct FoldArgs { const fe* itw_lo; const fe* itw_hi; uint32_t lo_bits; uint32_t log_N; fe alpha, iota, quarter; };
+__device__ __forceinline__ fe fold_row(const FoldArgs& a, const fe& y0, const fe& y1, const fe& y2, const fe& y3, uint64_t exp_x) {
+    uint64_t e = exp_x & (((uint64_t)1 << a.log_N) - 1);
+    uint32_t l = (uint32_t)e & ((1u << a.lo_bits) - 1u), h = (uint32_t)(e >> a.lo_bits);
+    fe xinv = a.itw_lo[l];
+    if (h) xinv = fe_mul(xinv, a.itw_hi[h]);
+    fe t = fe_mul(a.alpha, xinv);
+    fe s02 = fe_add(y0, y2), s13 = fe_add(y1, y3), d02 = fe_sub(y0, y2);
+    fe id13 = fe_mul(a.iota, fe_sub(y1, y3));
+    fe u0 = fe_add(s02, s13), u2 = fe_sub(s02, s13), u1 = fe_sub(d02, id13), u3 = fe_add(d02, id13);
+    fe t2 = fe_sqr(t), t3 = fe_mul(t2, t);
+    fe acc = fe_add(fe_add(u0, fe_mul(t, u1)), fe_add(fe_mul(t2, u2), fe_mul(t3, u3)));
+    return fe_mul(acc, a.quarter);
+}
+// layer 0 -> 1: coset-major input comp[Bc][n]; r = B*k + j, k < n/4; output natural order via an LDS tile transpose
+__global__ void __launch_bounds__(PT) fri_fold0_kernel(const fe* __restrict__ comp, fe* __restrict__ out, size_t n, uint32_t Bc, uint32_t log_b,
+                                                      uint32_t log_jt, uint32_t j0, FoldArgs a) {
+    __shared__ fe tile[PT];
+    const uint32_t JT = 1u << log_jt, KT = PT >> log_jt;
+    const uint32_t kk = threadIdx.x % KT, jj = threadIdx.x / KT;
+    const size_t k = (size_t)blockIdx.x * KT + kk;
+    const uint32_t j = blockIdx.y * JT + jj;
+    const fe* base = comp + (size_t)j * n + k;
+    const size_t q = n / 4;
+    uint64_t r = ((uint64_t)k << log_b) + j0 + j;
+    tile[kk * JT + jj] = fold_row(a, base[0], base[q], base[2 * q], base[3 * q], r);
+    __syncthreads();
+    const uint32_t kk2 = threadIdx.x >> log_jt, jj2 = threadIdx.x & (JT - 1);
+    out[((size_t)blockIdx.x * KT + kk2) * Bc + blockIdx.y * JT + jj2] = tile[kk2 * JT + jj2];
+}
+__global__ void __launch_bounds__(PT) fri_fold_kernel(const fe* __restrict__ e, fe* __restrict__ out, size_t R, uint32_t log_stride, FoldArgs a) {
+    size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    out[r] = fold_row(a, e[r], e[r + R], e[r + 2 * R], e[r + 3 * R], (uint64_t)r << log_stride);
+}
+void k_fri_fold(dst_ctx* c, int layer, fe special_x) {
+    FoldArgs a;
+    a.itw_lo = c->itw_lo; a.itw_hi = c->itw_hi; a.lo_bits = c->tw_lo_bits; a.log_N = c->log_N;
+    a.alpha = special_x; a.iota = c->iota; a.quarter = c->four_inv;
+    size_t R = c->fri_size[layer] / 4;
+    if (layer == 0) {
+        uint32_t jt = c->Bc < 32 ? (uint32_t)c->Bc : 32u, log_jt = 0;
+        while ((1u << log_jt) < jt) log_jt++;
+        uint32_t KT = PT >> log_jt;
+        dim3 g((unsigned)((c->n / 4) / KT), (unsigned)(c->Bc >> log_jt));
+        hipLaunchKernelGGL(fri_fold0_kernel, g, dim3(PT), 0, c->stream, (const fe*)c->comp, c->fri_e[1], c->n, (uint32_t)c->Bc, c->log_b, log_jt, (uint32_t)c->j0, a);
+    } else {
+        hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((R + PT - 1) / PT)), dim3(PT), 0, c->stream, (const fe*)c->fri_e[layer], c->fri_e[layer + 1], R,
+                           (uint32_t)(2 * layer), a);
+    }
+}
+
+// ---- proof of work ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PT) pow_kernel(const uint32_t* __restrict__ seed8, uint64_t base, uint32_t grinding, unsigned long long* best) {
+    uint64_t nonce = base + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t m[16], h[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) m[i] = seed8[i];
+    m[8] = (uint32_t)nonce; m[9] = (uint32_t)(nonce >> 32);
+#pragma unroll
+    for (int i = 10; i < 16; i++) m[i] = 0;
+    b3_hash64(m, h);
+    uint64_t w = ((uint64_t)h[1] << 32) | h[0];
+    uint32_t tz = w == 0 ? 64u : (uint32_t)__ffsll((long long)w) - 1u;
+    if (tz >= grinding) atomicMin(best, (unsigned long long)nonce);
+}
+int k_pow(dst_ctx* c, const uint8_t seed[32], uint32_t grinding, uint64_t* nonce) {
+    uint32_t* d_seed = (uint32_t*)(c->d_u64 + 2);
+    unsigned long long* d_best = (unsigned long long*)(c->d_u64 + 1);
+    HIP_TRY(c, hipMemcpyAsync(d_seed, seed, 32, hipMemcpyHostToDevice, c->stream));
+    unsigned long long init = ~0ull;
+    HIP_TRY(c, hipMemcpyAsync(d_best, &init, 8, hipMemcpyHostToDevice, c->stream));
+    const uint64_t batch = (uint64_t)1 << 22;
+    for (uint64_t base = 1;; base += batch) {
+        hipLaunchKernelGGL(pow_kernel, dim3((unsigned)(batch / PT)), dim3(PT), 0, c->stream, (const uint32_t*)d_seed, base, grinding, d_best);
+        unsigned long long best = 0;
+        HIP_TRY(c, hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (best != ~0ull) { *nonce = best; return DST_OK; }
+        if (base > ((uint64_t)1 << 40)) { c->err = "proof-of-work search exhausted"; return DST_ERR_ARG; }
+    }
+}
+
+// ---- gathers --------------------------------------------------------------------------------------------------------------------------------
+__global__ void gather_kernel(const uint4* __restrict__ src, uint32_t vecs_per_item, const uint64_t* __restrict__ idx, size_t count, uint4* __restrict__ dst) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * vecs_per_item) return;
+    size_t item = t / vecs_per_item, v = t % vecs_per_item;
+    dst[t] = src[idx[item] * vecs_per_item + v];
+}
+void k_gather(dst_ctx* c, const void* src, size_t item_bytes, const uint64_t* idx_dev, size_t count, void* dst) {
+    uint32_t vp = (uint32_t)(item_bytes / 16);
+    size_t total = count * vp;
+    if (!total) return;
+    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((total + PT - 1) / PT)), dim3(PT), 0, c->stream, (const uint4*)src, vp, idx_dev, count, (uint4*)dst);
+}
+// gather of one trace row per position from the coset-major LDE: out[p][c] = lde[c][j][k] with position = B*k + j
+__global__ void gather_rows_kernel(const fe* __restrict__ lde, size_t n, uint32_t Bc, uint32_t log_b, uint32_t j0, uint32_t W,
+                                   const uint64_t* __restrict__ positions, size_t count, fe* __restrict__ out) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count * W) return;
+    size_t p = t / W, col = t % W;
+    uint64_t pos = positions[p];
+    size_t k = pos >> log_b, j = (pos & ((1u << log_b) - 1)) - j0;
+    out[t] = lde[(col * Bc + j) * n + k];
+}
+void k_gather_rows(dst_ctx* c, const uint64_t* positions_dev, size_t count, fe* out) {
+    size_t total = count * c->W;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + PT - 1) / PT)), dim3(PT), 0, c->stream, (const fe*)c->lde, c->n, (uint32_t)c->Bc, c->log_b,
+                       (uint32_t)c->j0, (uint32_t)c->W, positions_dev, count, out);
+}
+
+// ---- mulmod micro-benchmark (bench.py's ALU ceiling) --------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(PT) mulmod_bench_kernel(fe* out, uint32_t iters) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    fe a = fe_make(g * 2654435761u + 12345u, g ^ 0x9E3779B9u, g + 77u, 0x12345678u);
+    fe b = fe_make(g + 1u, 0xABCDEF01u, g * 3u + 5u, 0x0FEDCBA9u);
+    fe c2 = fe_make(0x11111111u + g, 0x22222222u, 0x33333333u, 0x04444444u);
+    fe d = fe_make(0x55555555u, 0x66666666u + g, 0x77777777u, 0x08888888u);
+    for (uint32_t i = 0; i < iters; i++) {      // four independent dependency chains per lane
+        a = fe_mul(a, b); b = fe_mul(b, c2); c2 = fe_mul(c2, d); d = fe_mul(d, a);
+    }
+    out[g] = fe_add(fe_add(a, b), fe_add(c2, d));
+}
+int k_bench_mulmod(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms) {
+    if (lanes * sizeof(fe) > c->scratch_elems * sizeof(fe)) lanes = c->scratch_elems;
+    lanes = lanes / PT * PT;
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreate(&e0)); HIP_TRY(c, hipEventCreate(&e1));
+    hipLaunchKernelGGL(mulmod_bench_kernel, dim3((unsigned)(lanes / PT)), dim3(PT), 0, c->stream, c->scratch, 4u);   // warm-up
+    HIP_TRY(c, hipEventRecord(e0, c->stream));
+    hipLaunchKernelGGL(mulmod_bench_kernel, dim3((unsigned)(lanes / PT)), dim3(PT), 0, c->stream, c->scratch, iters);
+    HIP_TRY(c, hipEventRecord(e1, c->stream));
+    HIP_TRY(c, hipEventSynchronize(e1));
+    float f = 0; HIP_TRY(c, hipEventElapsedTime(&f, e0, e1));
+    *ms = f;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return DST_OK;
+}

@@ -1,0 +1,227 @@
+"""ctypes binding of libdistaff_hip.so (the product).  Nothing here falls back to a CPU implementation: if the shared
+library is missing, or a call needs a GPU that is not there, an exception is raised.
+
+Field elements cross the C-ABI as 16 little-endian bytes (the memory image of the reference's ``u128``); on the Python side
+bulk data are numpy ``uint64`` arrays whose last axis has length 2 (low word, high word).
+"""
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdistaff_hip.so")
+
+DST_OK, DST_ERR_ARG, DST_ERR_HIP, DST_ERR_AIR, DST_ERR_STATE = 0, -1, -2, -3, -4
+
+# ids of dst_read_buffer (distaff_amd/csrc/ctx.h)
+BUF = {"polys": 0, "lde": 1, "trace_leaves": 2, "trace_nodes": 3, "ceval_i": 4, "ceval_f": 5, "ceval_t": 6, "cpoly": 7, "cevals": 8,
+       "cnodes": 9, "comp_poly": 10, "comp_evals": 11, "fri_evals": 12, "fri_nodes": 13, "fri_leaves": 14}
+
+EXPORTS = ["dst_ctx_create", "dst_ctx_destroy", "dst_last_error", "dst_phase_ms", "dst_trace_upload", "dst_trace_upload_contiguous",
+           "dst_commit_trace", "dst_eval_constraints", "dst_compose", "dst_fri_commit_layer", "dst_fri_fold", "dst_pow_grind",
+           "dst_build_proof", "dst_prove", "dst_prng_vector", "dst_query_positions", "dst_blake3", "dst_fibonacci_trace",
+           "dst_read_buffer", "dst_bench_mulmod"]
+
+
+class DistaffError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("libdistaff_hip error %d: %s" % (code, message))
+        self.code = code
+
+
+class Params(ctypes.Structure):
+    _fields_ = [("log_trace_length", ctypes.c_uint32), ("log_blowup", ctypes.c_uint32), ("width", ctypes.c_uint32),
+                ("ctx_depth", ctypes.c_uint32), ("loop_depth", ctypes.c_uint32), ("num_queries", ctypes.c_uint32),
+                ("grinding_factor", ctypes.c_uint32), ("device", ctypes.c_int32), ("rank", ctypes.c_uint32), ("world", ctypes.c_uint32)]
+
+
+class Public(ctypes.Structure):
+    _fields_ = [("num_inputs", ctypes.c_uint32), ("num_outputs", ctypes.c_uint32),
+                ("inputs", (ctypes.c_uint8 * 16) * 8), ("outputs", (ctypes.c_uint8 * 16) * 8)]
+
+
+_lib = None
+
+
+def load():
+    """Loads the shared library (raises if it has not been built: run ``python -c 'import __graft_entry__ as g; g.build()'``)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError("libdistaff_hip.so is missing (%s): the HIP extension must be built, there is no CPU fallback" % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        _lib.dst_last_error.restype = ctypes.c_char_p
+        _lib.dst_last_error.argtypes = [ctypes.c_void_p]
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def int_to_bytes(v):
+    return int(v).to_bytes(16, "little")
+
+
+def ints_to_arr(values):
+    out = np.empty((len(values), 2), dtype=np.uint64)
+    for i, v in enumerate(values):
+        out[i, 0] = int(v) & 0xFFFFFFFFFFFFFFFF
+        out[i, 1] = int(v) >> 64
+    return out
+
+
+def arr_to_ints(a):
+    a = np.asarray(a, dtype=np.uint64).reshape(-1, 2)
+    return [int(lo) | (int(hi) << 64) for lo, hi in a]
+
+
+def make_public(inputs, outputs):
+    p = Public()
+    p.num_inputs, p.num_outputs = len(inputs), len(outputs)
+    for i, v in enumerate(inputs):
+        p.inputs[i][:] = list(int_to_bytes(v))
+    for i, v in enumerate(outputs):
+        p.outputs[i][:] = list(int_to_bytes(v))
+    return p
+
+
+def prng_vector(seed, count):
+    """field::prng_vector (src/math/field.rs:271) -- host side, StdRng(ChaCha20) + Uniform restatement inside the library."""
+    out = np.zeros((count, 2), dtype=np.uint64)
+    load().dst_prng_vector(bytes(seed), ctypes.c_uint32(count), _ptr(out))
+    return out
+
+
+def query_positions(seed, domain_size, blowup, num_queries):
+    out = np.zeros(num_queries, dtype=np.uint64)
+    k = load().dst_query_positions(bytes(seed), ctypes.c_uint64(domain_size), ctypes.c_uint32(blowup), ctypes.c_uint32(num_queries), _ptr(out))
+    if k < 0:
+        raise DistaffError(k, "could not generate enough query positions")
+    return [int(x) for x in out[:k]]
+
+
+def blake3(data):
+    out = ctypes.create_string_buffer(32)
+    load().dst_blake3(bytes(data), ctypes.c_size_t(len(data)), out)
+    return out.raw
+
+
+def fibonacci_trace(log_n):
+    """Fibonacci example trace filling 2^log_n rows: returns (columns [20, n, 2] uint64, program_hash bytes, result int)."""
+    n = 1 << log_n
+    cols = np.zeros((20, n, 2), dtype=np.uint64)
+    ph = ctypes.create_string_buffer(32)
+    res = ctypes.create_string_buffer(16)
+    r = load().dst_fibonacci_trace(ctypes.c_uint32(log_n), _ptr(cols), ph, res)
+    if r != DST_OK:
+        raise DistaffError(r, "dst_fibonacci_trace failed")
+    return cols, ph.raw, int.from_bytes(res.raw, "little")
+
+
+class Context:
+    """One proving job on one GPU (``dst_ctx``): owns the device buffers; phases mirror stark::prove (prover.rs:17-168)."""
+
+    def __init__(self, log_n, width, ctx_depth, loop_depth, log_blowup=5, num_queries=50, grinding=20, device=0, rank=0, world=1):
+        self.lib = load()
+        self.params = Params(log_n, log_blowup, width, ctx_depth, loop_depth, num_queries, grinding, device, rank, world)
+        self.n, self.B, self.W = 1 << log_n, 1 << log_blowup, width
+        self.N = self.n * self.B
+        h = ctypes.c_void_p()
+        r = self.lib.dst_ctx_create(ctypes.byref(self.params), ctypes.byref(h))
+        if r != DST_OK:
+            raise DistaffError(r, self.lib.dst_last_error(None).decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.dst_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+    def _check(self, r):
+        if r != DST_OK:
+            raise DistaffError(r, self.lib.dst_last_error(self._h).decode())
+
+    def upload(self, columns):
+        cols = np.ascontiguousarray(columns, dtype=np.uint64)
+        assert cols.shape == (self.W, self.n, 2), cols.shape
+        self._check(self.lib.dst_trace_upload_contiguous(self._h, _ptr(cols)))
+
+    def commit_trace(self):
+        root = ctypes.create_string_buffer(32)
+        self._check(self.lib.dst_commit_trace(self._h, root))
+        return root.raw
+
+    def eval_constraints(self, inputs, outputs, coeffs):
+        c = np.ascontiguousarray(coeffs, dtype=np.uint64)
+        assert c.shape == (344, 2)
+        root = ctypes.create_string_buffer(32)
+        bad = ctypes.c_int64(-1)
+        pub = make_public(inputs, outputs)
+        r = self.lib.dst_eval_constraints(self._h, ctypes.byref(pub), _ptr(c), root, ctypes.byref(bad))
+        self.bad_step = bad.value
+        self._check(r)
+        return root.raw
+
+    def compose(self, draws):
+        d = np.ascontiguousarray(draws, dtype=np.uint64)
+        assert d.shape == (516, 2)
+        z1 = np.zeros((self.W, 2), dtype=np.uint64)
+        z2 = np.zeros((self.W, 2), dtype=np.uint64)
+        self._check(self.lib.dst_compose(self._h, _ptr(d), _ptr(z1), _ptr(z2)))
+        return z1, z2
+
+    def fri_commit_layer(self):
+        root = ctypes.create_string_buffer(32)
+        more = ctypes.c_int(0)
+        self._check(self.lib.dst_fri_commit_layer(self._h, root, ctypes.byref(more)))
+        return root.raw, bool(more.value)
+
+    def fri_fold(self, special_x):
+        self._check(self.lib.dst_fri_fold(self._h, int_to_bytes(special_x)))
+
+    def pow_grind(self, seed, grinding):
+        out = ctypes.create_string_buffer(32)
+        nonce = ctypes.c_uint64(0)
+        self._check(self.lib.dst_pow_grind(self._h, bytes(seed), ctypes.c_uint32(grinding), out, ctypes.byref(nonce)))
+        return out.raw, nonce.value
+
+    def build_proof(self, positions, pow_nonce):
+        pos = np.asarray(positions, dtype=np.uint64)
+        ln = ctypes.c_size_t(0)
+        self._check(self.lib.dst_build_proof(self._h, _ptr(pos), ctypes.c_uint32(len(positions)), ctypes.c_uint64(pow_nonce), None, ctypes.c_size_t(0), ctypes.byref(ln)))
+        buf = ctypes.create_string_buffer(ln.value)
+        self._check(self.lib.dst_build_proof(self._h, _ptr(pos), ctypes.c_uint32(len(positions)), ctypes.c_uint64(pow_nonce), buf, ctypes.c_size_t(ln.value), ctypes.byref(ln)))
+        return buf.raw[:ln.value]
+
+    def prove(self, inputs, outputs, cap=1 << 22):
+        """stark::prove on the uploaded trace; returns the serialised StarkProof."""
+        pub = make_public(inputs, outputs)
+        buf = ctypes.create_string_buffer(cap)
+        ln = ctypes.c_size_t(0)
+        self._check(self.lib.dst_prove(self._h, ctypes.byref(pub), buf, ctypes.c_size_t(cap), ctypes.byref(ln)))
+        return buf.raw[:ln.value]
+
+    def phase_ms(self):
+        ms = (ctypes.c_double * 9)()
+        self._check(self.lib.dst_phase_ms(self._h, ms))
+        return list(ms)
+
+    def read(self, what, arg=0):
+        ln = ctypes.c_size_t(0)
+        self._check(self.lib.dst_read_buffer(self._h, ctypes.c_uint32(BUF[what]), ctypes.c_uint32(arg), None, ctypes.c_size_t(0), ctypes.byref(ln)))
+        buf = np.zeros(ln.value, dtype=np.uint8)
+        self._check(self.lib.dst_read_buffer(self._h, ctypes.c_uint32(BUF[what]), ctypes.c_uint32(arg), _ptr(buf), ctypes.c_size_t(ln.value), ctypes.byref(ln)))
+        return buf
+
+    def read_elements(self, what, arg=0):
+        return self.read(what, arg).view(np.uint64).reshape(-1, 2)
+
+    def bench_mulmod(self, lanes=1 << 20, iters=256):
+        ms = ctypes.c_double(0)
+        self._check(self.lib.dst_bench_mulmod(self._h, ctypes.c_uint64(lanes), ctypes.c_uint32(iters), ctypes.byref(ms)))
+        return ms.value

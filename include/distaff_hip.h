@@ -1,0 +1,121 @@
+/* libdistaff_hip.so -- C-ABI of the MI355X-native STARK prover backend for Distaff.
+ *
+ * The reference (GuildOfWeavers/distaff v0.5.1, pure Rust) has no FFI layer; the drop-in seam is the body of
+ * `stark::prove` (/root/reference/src/stark/prover.rs:17), which is called from exactly one place
+ * (/root/reference/src/lib.rs:62).  A Rust maintainer replaces that body with calls to the entry points below
+ * (INTEGRATION.md shows the `extern "C"` block); Fiat-Shamir dependencies between the nine prover steps force the
+ * boundary to be phase-wise, and `dst_prove` chains the phases with the library's own restatement of the
+ * reference's challenge derivation.
+ *
+ * Conventions
+ *   - a field element is 16 bytes, little-endian, canonical (< p = 2^128 - 45*2^40 + 1); this is the memory image of
+ *     the reference's `u128` (/root/reference/src/utils/mod.rs:35-41).  Pointers need only byte alignment.
+ *   - a digest is 32 bytes (BLAKE3, the only serialisable `HashFunction`: src/stark/options.rs:97-120).
+ *   - every function returns DST_OK (0) or a negative error code and never aborts the process (the reference
+ *     panics instead: src/lib.rs:32,49,56, src/stark/constraints/evaluator.rs:155); `dst_last_error` gives the text.
+ *   - a context owns all device memory and one HIP stream; it is not thread-safe; calls are synchronous (they
+ *     return after the stream has drained) unless stated otherwise.  Host buffers are caller-owned and are only
+ *     read or written during the call.
+ */
+#ifndef DISTAFF_HIP_H
+#define DISTAFF_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DST_OK 0
+#define DST_ERR_ARG (-1)      /* invalid argument / call order */
+#define DST_ERR_HIP (-2)      /* HIP runtime error (no device, out of memory, launch failure) */
+#define DST_ERR_AIR (-3)      /* transition constraints not satisfied by the trace (reference panic: evaluator.rs:155) */
+#define DST_ERR_STATE (-4)    /* phase called out of order */
+
+typedef struct dst_ctx dst_ctx;
+
+/* Shape of one proving job; mirrors TraceTable::new (src/stark/trace/trace_table.rs:23-58) + ProofOptions (options.rs:16-27). */
+typedef struct dst_params {
+    uint32_t log_trace_length;   /* n = 2^log_trace_length rows, >= 4 (TraceTable asserts a power of two; MIN_TRACE_LENGTH = 16) */
+    uint32_t log_blowup;         /* extension_factor = 2^log_blowup, 16 <= factor <= 256 (options.rs:39-41) */
+    uint32_t width;              /* number of registers W < 128 (lib.rs:83) */
+    uint32_t ctx_depth;          /* context stack registers (<= 16) */
+    uint32_t loop_depth;         /* loop stack registers (<= 8) */
+    uint32_t num_queries;        /* 1..128 (options.rs:43-44) */
+    uint32_t grinding_factor;    /* <= 32 (options.rs:46) */
+    int32_t  device;             /* HIP device ordinal */
+    /* multi-GPU sharding of the LDE domain by cosets (DESIGN.md "Multi-GPU"): this context owns cosets
+       [rank * B / world, (rank + 1) * B / world); world = 1 means the whole job. */
+    uint32_t rank, world;
+} dst_params;
+
+/* Public inputs / outputs of the boundary constraints (src/stark/constraints/evaluator.rs:35-79). */
+typedef struct dst_public {
+    uint32_t num_inputs, num_outputs;       /* <= 8 each (lib.rs:136-137) */
+    uint8_t inputs[8][16];
+    uint8_t outputs[8][16];
+} dst_public;
+
+/* ---- lifetime ---------------------------------------------------------------------------------------------------- */
+int dst_ctx_create(const dst_params* params, dst_ctx** out);
+void dst_ctx_destroy(dst_ctx* ctx);
+const char* dst_last_error(const dst_ctx* ctx);      /* ctx may be NULL: returns the creation-time error */
+/* milliseconds spent in each of the reference's nine prover steps during the last proof (prover.rs:28,36,66,74,87,103,112,134,167) */
+int dst_phase_ms(const dst_ctx* ctx, double out_ms[9]);
+
+/* ---- step 0: trace upload (host -> HBM).  cols[c] points to n*16 bytes of register c, i.e. the reference's
+ *      column-major `Vec<Vec<u128>>` (trace_table.rs:10).  Not part of the timed prover region. ------------------------ */
+int dst_trace_upload(dst_ctx* ctx, const uint8_t* const* cols);
+/* same, from one contiguous [W][n] buffer */
+int dst_trace_upload_contiguous(dst_ctx* ctx, const uint8_t* cols);
+
+/* ---- steps 1-2: TraceTable::extend + build_merkle_tree (prover.rs:22-35; trace_table.rs:143,174) ---------------------- */
+int dst_commit_trace(dst_ctx* ctx, uint8_t trace_root[32]);
+
+/* ---- steps 3-5: constraint evaluation, combination, constraint LDE + Merkle tree (prover.rs:43-86) ----------------------
+ * coeffs = the 344 draws of ConstraintCoefficients::new(trace_root) in draw order (utils/coefficients.rs:66).
+ * On DST_ERR_AIR *bad_step receives the first trace step whose transition constraints do not vanish. */
+int dst_eval_constraints(dst_ctx* ctx, const dst_public* pub, const uint8_t* coeffs /* 344*16 */, uint8_t constraint_root[32], int64_t* bad_step);
+
+/* ---- step 6: DEEP composition (prover.rs:94-101, 189-201).  draws = the 516 draws of prng_vector(constraint_root):
+ * draws[0] = z, then CompositionCoefficients (coefficients.rs:80-104).  Outputs the DeepValues (proof.rs:24-28). --------- */
+int dst_compose(dst_ctx* ctx, const uint8_t* draws /* 516*16 */, uint8_t* trace_at_z1 /* W*16 */, uint8_t* trace_at_z2 /* W*16 */);
+
+/* ---- step 7: FRI commit phase (fri/prover.rs:11-53).  Call dst_fri_commit_layer (root of the current layer), then
+ * dst_fri_fold with special_x = prng(root); repeat while dst_fri_commit_layer reports more = 1.  The last committed
+ * layer (<= 256 evaluations) is the remainder. -------------------------------------------------------------------------- */
+int dst_fri_commit_layer(dst_ctx* ctx, uint8_t layer_root[32], int* more);
+int dst_fri_fold(dst_ctx* ctx, const uint8_t special_x[16]);
+
+/* ---- step 8: proof of work (utils/proof_of_work.rs:4-32): smallest nonce >= 1 whose digest has >= grinding_factor
+ * trailing zero bits in its first little-endian u64. ------------------------------------------------------------------- */
+int dst_pow_grind(dst_ctx* ctx, const uint8_t seed[32], uint32_t grinding_factor, uint8_t out_seed[32], uint64_t* nonce);
+
+/* ---- step 9: openings (prover.rs:143-165).  Serialises the whole StarkProof in the reference's wire format
+ * (bincode, src/main.rs:44) for the given query positions.  Two-call protocol: pass out = NULL to get the size. --------- */
+int dst_build_proof(dst_ctx* ctx, const uint64_t* positions, uint32_t num_positions, uint64_t pow_nonce,
+                    uint8_t* out, size_t cap, size_t* out_len);
+
+/* ---- the whole of stark::prove (prover.rs:17-168) on a trace already uploaded with dst_trace_upload ------------------- */
+int dst_prove(dst_ctx* ctx, const dst_public* pub, uint8_t* proof_out, size_t cap, size_t* proof_len);
+
+/* ---- host-side helpers that the Rust host would otherwise take from `rand` (they run on the CPU) -------------------- */
+void dst_prng_vector(const uint8_t seed[32], uint32_t count, uint8_t* out /* count*16 */);          /* field.rs:271 */
+int dst_query_positions(const uint8_t seed[32], uint64_t domain_size, uint32_t blowup, uint32_t num_queries, uint64_t* out); /* utils/mod.rs:25 */
+void dst_blake3(const uint8_t* in, size_t len, uint8_t out[32]);                                     /* crypto/hash.rs:205 (host) */
+
+/* ---- benchmark inputs: the Fibonacci example trace (src/examples/fibonacci.rs:32-47) filling exactly 2^log_n rows
+ * (W = 20, ctx_depth 1, loop_depth 0).  cols = [20][n] elements; outputs the program hash and the result. -------------- */
+int dst_fibonacci_trace(uint32_t log_n, uint8_t* cols, uint8_t program_hash[32], uint8_t result[16]);
+
+/* ---- inspection (tests and profiling): copies an internal device buffer to the host.  `what` ids are listed in
+ * distaff_amd/csrc/ctx.h (DST_BUF_*).  Two-call protocol: out = NULL returns the size through *len. ------------------- */
+int dst_read_buffer(dst_ctx* ctx, uint32_t what, uint32_t arg, uint8_t* out, size_t cap, size_t* len);
+/* micro-benchmark hook used by bench.py's roofline section: runs `iters` dependent modular multiplications per lane
+ * on `lanes` lanes and returns the elapsed milliseconds. */
+int dst_bench_mulmod(dst_ctx* ctx, uint64_t lanes, uint32_t iters, double* ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,168 @@
+"""GPU parity tests proper: every phase of the HIP prover path (through the C-ABI of libdistaff_hip.so) against the CPU
+oracle on the same inputs and the same Fiat-Shamir challenges -- bit-exact, as the path is integer arithmetic."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _ctx(D, trace, **kw):
+    log_n = trace.length.bit_length() - 1
+    return D.Context(log_n, trace.width, trace.ctx_depth, trace.loop_depth, **kw)
+
+
+def _check_all_phases(O, D, trace, num_outputs=1, log_blowup=5, num_queries=50, grinding=12):
+    ext = 1 << log_blowup
+    op = O.Prover.from_trace(trace, num_outputs, ext=ext, num_queries=num_queries, grinding=grinding)
+    for k in range(1, 10):
+        op.step(k)
+    ctx = _ctx(D, trace, log_blowup=log_blowup, num_queries=num_queries, grinding=grinding)
+    ctx.upload(trace.columns)
+    W, n, N = trace.width, trace.length, trace.length * ext
+
+    # steps 1-2
+    root = ctx.commit_trace()
+    assert (ctx.read_elements("polys").reshape(W, n, 2) == op.get("polys")).all(), "polys"
+    regs = op.get("registers")
+    for c in range(W):
+        assert (ctx.read_elements("lde", c) == regs[c]).all(), "lde register %d" % c
+    assert ctx.read("trace_leaves").tobytes() == op.get_bytes("trace_leaves"), "trace leaves"
+    assert ctx.read("trace_nodes").tobytes()[32:] == op.get_bytes("trace_nodes")[32:], "trace nodes"
+    assert root == op.get_bytes("roots")[:32]
+
+    # steps 3-5 with the oracle's coefficient draws
+    croot = ctx.eval_constraints(trace.public_inputs, op.outputs, op.get("constraint_draws"))
+    for name, oname in (("ceval_i", "i_evaluations"), ("ceval_f", "f_evaluations"), ("ceval_t", "t_evaluations")):
+        assert (ctx.read_elements(name) == op.get(oname)).all(), name
+    assert (ctx.read_elements("cpoly") == op.get("constraint_poly")).all(), "constraint poly"
+    assert (ctx.read_elements("cevals") == op.get("constraint_evaluations")).all(), "constraint evaluations"
+    assert ctx.read("cnodes").tobytes()[32:] == op.get_bytes("constraint_nodes")[32:], "constraint nodes"
+    assert croot == op.get_bytes("roots")[32:]
+
+    # step 6
+    z1, z2 = ctx.compose(op.get("deep_draws"))
+    assert (z1 == op.get("trace_at_z1")).all() and (z2 == op.get("trace_at_z2")).all(), "deep values"
+    assert (ctx.read_elements("comp_poly") == op.get("composition_poly")).all(), "composition poly"
+    assert (ctx.read_elements("comp_evals") == op.get("composed_evaluations")).all(), "composition evaluations"
+
+    # step 7
+    xs = O.to_ints(op.get("fri_special_xs")) if op.get_u64("fri_layers")[0] > 1 else []
+    layers = op.get_u64("fri_layers")[0]
+    roots = b""
+    for d in range(layers):
+        r, more = ctx.fri_commit_layer()
+        roots += r
+        assert ctx.read("fri_nodes", d).tobytes()[32:] == op.get_bytes("fri_nodes", d)[32:], "fri nodes %d" % d
+        assert more == (d + 1 < layers)
+        if more:
+            ctx.fri_fold(xs[d])
+            nxt = op.get("fri_values", d + 1)          # rows (e[r], e[r+R], e[r+2R], e[r+3R]) of the next layer
+            R = nxt.shape[0]
+            got = ctx.read_elements("fri_evals", d + 1).reshape(4, R, 2).transpose(1, 0, 2)
+            assert (got == nxt).all(), "fri layer %d" % (d + 1)
+    assert roots == op.get_bytes("fri_roots")
+
+    # step 8
+    seeds = op.get_bytes("query_seeds")
+    seed1, nonce = ctx.pow_grind(seeds[:32], grinding)
+    assert nonce == op.get_u64("pow_nonce")[0] and seed1 == seeds[32:]
+    assert D.query_positions(seed1, N, ext, num_queries) == op.get_u64("positions")
+
+    # step 9: the serialised proof is byte-identical and the oracle's verifier accepts it
+    proof = ctx.build_proof(op.get_u64("positions"), nonce)
+    assert proof == op.get_bytes("proof"), "proof bytes"
+    assert O.verify(proof, trace.program_hash, trace.public_inputs, op.outputs) == (True, "")
+
+    # dst_prove (library-side Fiat-Shamir) reproduces the same proof
+    ctx.upload(trace.columns)
+    assert ctx.prove(trace.public_inputs, op.outputs) == proof
+    ctx.close()
+
+
+@pytest.mark.parametrize("log_n", [7, 10, 12])
+def test_fibonacci_all_phases(oracle, log_n):
+    import distaff_amd as D
+    _check_all_phases(oracle, D, oracle.fibonacci_trace(1 << log_n))
+
+
+def test_other_program_shapes(oracle):
+    import distaff_amd as D
+    O = oracle
+    _check_all_phases(O, D, O.Trace("begin add push.5 mul push.7 end", [1, 2]), num_outputs=2)             # W = 17, no context register
+    _check_all_phases(O, D, O.Trace("begin add block push.5 mul push.7 end end", [1, 2]), num_outputs=2)  # W = 18
+    _check_all_phases(O, D, O.Trace("begin push.3 push.4 push.5 push.6 push.7 push.8 push.9 push.10 push.11 mul add block swap.2 dup.2 drop add end mul end", [1, 2]),
+                      num_outputs=3)                                                                      # stack deeper than 8
+
+
+def test_blowup_16_and_64(oracle):
+    import distaff_amd as D
+    _check_all_phases(oracle, D, oracle.fibonacci_trace(256), log_blowup=4, num_queries=100)       # config 5's options
+    _check_all_phases(oracle, D, oracle.fibonacci_trace(128), log_blowup=6, num_queries=30)
+
+
+def test_config2_random_columns_lde_and_merkle(oracle):
+    """BASELINE config 2 shape at a size the oracle finishes in seconds: 20 uniform columns, LDE + Merkle commit only."""
+    import distaff_amd as D
+    O = oracle
+    n, W = 1 << 12, 20
+    P = O.P
+    def splitmix(seed):
+        x = seed
+        while True:
+            x = (x + 0x9E3779B97F4A7C15) & (2**64 - 1)
+            z = x
+            z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & (2**64 - 1)
+            z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & (2**64 - 1)
+            yield z ^ (z >> 31)
+    cols = []
+    for c in range(W):
+        g = splitmix(0x44697374616666 + c)
+        col = []
+        while len(col) < n:
+            v = next(g) | (next(g) << 64)
+            if v < P:
+                col.append(v)
+        cols.append(col)
+    columns = O.to_arr(cols)
+    op = O.Prover(columns, 1, 0, [], [], ext=32)
+    op.step(1); op.step(2)
+    ctx = D.Context(12, W, 1, 0)
+    ctx.upload(columns)
+    root = ctx.commit_trace()
+    assert root == op.get_bytes("roots")[:32]
+    assert ctx.read("trace_leaves").tobytes() == op.get_bytes("trace_leaves")
+    regs = op.get("registers")
+    for c in (0, 7, 19):
+        assert (ctx.read_elements("lde", c) == regs[c]).all()
+    ctx.close()
+
+
+def test_invalid_trace_reports_air_error(oracle):
+    import distaff_amd as D
+    O = oracle
+    t = O.fibonacci_trace(128)
+    cols = t.columns.copy()
+    cols[16, 40, 0] += 1
+    ctx = _ctx(D, t)
+    ctx.upload(cols)
+    root = ctx.commit_trace()
+    with pytest.raises(D.DistaffError) as e:
+        ctx.eval_constraints([1, 0], [1], D.prng_vector(root, 344))
+    assert e.value.code == -3 and ctx.bad_step in (39, 40)
+    ctx.close()
+
+
+def test_wide_rows_two_chunk_leaves(oracle):
+    """W > 64 registers: a trace row spans two BLAKE3 chunks (W*16 > 1024 bytes)."""
+    import distaff_amd as D
+    O = oracle
+    rng = np.random.default_rng(1)
+    W, n = 100, 64
+    cols = rng.integers(0, 2**62, size=(W, n, 2), dtype=np.uint64)
+    op = O.Prover(cols, 16, 8, [], [], ext=16)
+    op.step(1); op.step(2)
+    ctx = D.Context(6, W, 16, 8, log_blowup=4)
+    ctx.upload(cols)
+    assert ctx.commit_trace() == op.get_bytes("roots")[:32]
+    assert ctx.read("trace_leaves").tobytes() == op.get_bytes("trace_leaves")
+    ctx.close()
