@@ -157,7 +157,7 @@ def test_wide_rows_two_chunk_leaves(oracle):
     import distaff_amd as D
     O = oracle
     rng = np.random.default_rng(1)
-    W, n = 100, 64
+    W, n = 71, 64                     # 15 decoder + 16 context + 8 loop + 32 stack registers: 1136-byte rows
     cols = rng.integers(0, 2**62, size=(W, n, 2), dtype=np.uint64)
     op = O.Prover(cols, 16, 8, [], [], ext=16)
     op.step(1); op.step(2)
