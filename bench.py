@@ -1,0 +1,146 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X STARK prover path (BASELINE.json: prover wall-time + trace-cells/sec on a 2^20-step trace).
+
+A "step" is one complete `stark::prove` (LDE + trace Merkle + constraint evaluation + combination + constraint LDE/Merkle +
+DEEP composition + FRI + proof-of-work + openings, default ProofOptions) over one Fibonacci execution trace that is already
+resident in HBM (the upload is not timed: the PCIe-inclusive rate is in DESIGN.md).  Prints ONE JSON line on rank 0.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+W_FIB = 20                     # registers of the Fibonacci trace
+
+
+def cpu_baseline(log_n):
+    """Times the CPU oracle (single-threaded restatement of the reference algorithm) on a bounded sample of the workload."""
+    import oracle as O
+    t = O.fibonacci_trace(1 << log_n)
+    p = O.Prover.from_trace(t, 1)
+    t0 = time.time()
+    p.prove()
+    dt = time.time() - t0
+    return {"value": (1 << log_n) * t.width / dt, "unit": "trace-cells/s", "cores": 1, "kind": "port",
+            "sample": "one full prove() of a 2^%d-step Fibonacci trace (same program and ProofOptions), %.1f s, oracle/liboracle.so -O3, 1 of %d host cores"
+                      % (log_n, dt, os.cpu_count() or 1),
+            "prove_ms": dt * 1e3, "phase_ms": [round(x, 1) for x in p.phase_ms]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=int(os.environ.get("BENCH_LOG_N", "20")))
+    ap.add_argument("--cpu-log-n", type=int, default=int(os.environ.get("BENCH_CPU_LOG_N", "15")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import distaff_amd as D
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP prover has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    log_n = args.log_n
+    n = 1 << log_n
+    cols, program_hash, result = D.fibonacci_trace(log_n)          # host: VM trace of `begin repeat.K swap dup.2 drop add end end`
+    ctx = D.Context(log_n, W_FIB, 1, 0, device=local_rank)          # default ProofOptions: blowup 32, 50 queries, grinding 20
+    ctx.upload(cols)                                                # inputs resident in HBM before the timed region
+
+    proof = None
+    for _ in range(args.warmup):
+        proof = ctx.prove([1, 0], [result])
+    ctx.set_profiling(True)
+    ctx.kernel_stats(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    phase_sum = [0.0] * 9
+    for _ in range(args.steps):
+        proof = ctx.prove([1, 0], [result])
+        for i, v in enumerate(ctx.phase_ms()):
+            phase_sum[i] += v
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    stats = ctx.kernel_stats(reset=True)
+    ctx.set_profiling(False)
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / args.steps * 1e3
+    cells = n * W_FIB
+    value = cells * world / (elapsed / args.steps)
+    # dominant kernel by device time, measured with HIP events on the launch stream inside the timed region
+    dom = max(stats.items(), key=lambda kv: kv[1]["ms"]) if stats else (None, None)
+    roofline = None
+    if dom[0]:
+        name, st = dom
+        per_launch_ms = st["ms"] / st["launches"]
+        per_launch_bytes = st["bytes"] / st["launches"]
+        achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "launches_per_step": st["launches"] / args.steps, "avg_launch_ms": round(per_launch_ms, 4),
+                    "algorithmic_bytes_per_launch": per_launch_bytes,
+                    "note": "the path is 128-bit modular integer arithmetic on the VALU: see alu_roofline and DESIGN.md"}
+    # ALU ceiling: dependent-chain modular multiplications per second measured on this device with the same fe_mul
+    mm_ms = ctx.bench_mulmod(1 << 22, 256)
+    mulmod_peak = (1 << 22) * 256 * 4 / (mm_ms * 1e-3)
+    out = {
+        "metric": "trace_cells_per_sec", "value": value, "unit": "trace-cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "u128 (prime field 2^128-45*2^40+1, 4x u32 limbs)", "data": "synthetic",
+        "config": {"workload": "Fibonacci program (src/examples/fibonacci.rs), 2^%d-step trace, W=20 registers, full stark::prove with default "
+                               "ProofOptions (blowup 32, 50 queries, grinding 20, blake3)" % log_n,
+                   "trace_steps": n, "registers": W_FIB, "blowup": 32, "queries": 50, "grinding": 20,
+                   "parallelism": "1 GPU" if world == 1 else "%d independent prover replicas, one trace per GPU (coset-sharded single proof: see DESIGN.md)" % world},
+        "prover_ms": ms_per_step,
+        "phase_ms": {k: round(v / args.steps, 3) for k, v in zip(
+            ["lde", "trace_merkle", "constraint_eval", "combine", "constraint_lde_merkle", "deep_composition", "fri", "pow_queries", "openings"], phase_sum)},
+        "proof_bytes": len(proof),
+        "roofline": roofline,
+        "alu_roofline": {"unit": "mulmod/s", "peak_measured": mulmod_peak, "kernel": "mulmod_bench_kernel (4 dependent chains per lane)"},
+        "kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3), "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
+                    for k, v in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])},
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_log_n)
+    print(json.dumps(out), flush=True)
+    ctx.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -619,6 +619,32 @@ int dst_read_buffer(dst_ctx* c, uint32_t what, uint32_t arg, uint8_t* out, size_
     return DST_OK;
 }
 
+int dst_set_profiling(dst_ctx* c, int enabled) { if (!c) return DST_ERR_ARG; c->profile = enabled != 0; return DST_OK; }
+int dst_kernel_stats(dst_ctx* c, char* json_out, size_t cap, int reset) {
+    if (!c || !json_out) return DST_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    for (auto& e : c->kpending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, e.e0, e.e1) == hipSuccess) { auto& st = c->kstats[e.name]; st.launches++; st.ms += ms; st.bytes += e.bytes; }
+        hipEventDestroy(e.e0); hipEventDestroy(e.e1);
+    }
+    c->kpending.clear();
+    std::string js = "{";
+    bool first = true;
+    for (auto& kv : c->kstats) {
+        char buf[256];
+        snprintf(buf, sizeof(buf), "%s\"%s\": {\"launches\": %llu, \"ms\": %.6f, \"bytes\": %.0f}", first ? "" : ", ", kv.first.c_str(),
+                 (unsigned long long)kv.second.launches, kv.second.ms, kv.second.bytes);
+        js += buf; first = false;
+    }
+    js += "}";
+    if (reset) c->kstats.clear();
+    if (js.size() + 1 > cap) { c->err = "stats buffer too small"; return DST_ERR_ARG; }
+    memcpy(json_out, js.c_str(), js.size() + 1);
+    return DST_OK;
+}
+
 int dst_bench_mulmod(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms) {
     if (!c || !ms) return DST_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));

@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include <string.h>
 #include <string>
+#include <map>
 #include <vector>
 #include "fe.h"
 #include "../../include/distaff_hip.h"
@@ -99,6 +100,26 @@ struct dst_ctx {
     fe program_hash[2] = {};
     bool have_trace = false, committed = false, constraints_done = false, composed = false;
     double phase_ms[9] = {0};
+
+    // optional per-kernel timing with HIP events recorded on `stream` (dst_set_profiling / dst_kernel_stats)
+    bool profile = false;
+    struct KEvent { hipEvent_t e0, e1; std::string name; double bytes; };
+    std::vector<KEvent> kpending;
+    struct KStat { uint64_t launches = 0; double ms = 0, bytes = 0; };
+    std::map<std::string, KStat> kstats;
+};
+
+// brackets one kernel launch with events when profiling is on; `bytes` = algorithmic HBM bytes of that launch
+struct KScope {
+    dst_ctx* c; bool on;
+    dst_ctx::KEvent ev;
+    KScope(dst_ctx* ctx, const char* name, double bytes) : c(ctx), on(ctx->profile) {
+        if (!on) return;
+        ev.name = name; ev.bytes = bytes;
+        if (hipEventCreate(&ev.e0) != hipSuccess || hipEventCreate(&ev.e1) != hipSuccess) { on = false; return; }
+        (void)hipEventRecord(ev.e0, c->stream);
+    }
+    ~KScope() { if (on) { (void)hipEventRecord(ev.e1, c->stream); c->kpending.push_back(ev); } }
 };
 
 #define HIP_TRY(ctx, expr)                                                                          \

@@ -451,7 +451,7 @@ __global__ void __launch_bounds__(AIR_THREADS) air_kernel(AirArgs a) {
 template <int CL, int LL, int SL>
 static void launch_air(dst_ctx* c, const AirArgs& a, uint32_t Q) {
     dim3 g((unsigned)((c->n + AIR_THREADS - 1) / AIR_THREADS), Q);
-    hipLaunchKernelGGL((air_kernel<CL, LL, SL>), g, dim3(AIR_THREADS), 0, c->stream, a);
+    { KScope ks_(c, "air_kernel", 16.0 * c->n * Q * (c->W + 3)); hipLaunchKernelGGL((air_kernel<CL, LL, SL>), g, dim3(AIR_THREADS), 0, c->stream, a); }
 }
 
 static bool g_consts_loaded[64] = {false};

@@ -79,7 +79,7 @@ void k_trace_leaves(dst_ctx* c) {
     while ((1u << log_jt) < jt) log_jt++;
     uint32_t KT = HASH_THREADS >> log_jt;
     dim3 g((unsigned)(c->n / KT), (unsigned)(c->Bc >> log_jt));
-    hipLaunchKernelGGL(trace_leaves_kernel, g, dim3(HASH_THREADS), 0, c->stream, (const fe*)c->lde, c->trace_leaves, (uint32_t)c->W, c->n, (uint32_t)c->Bc, log_jt);
+    { KScope ks_(c, "trace_leaves_kernel", (16.0 * c->W + 32.0) * c->Bc * c->n); hipLaunchKernelGGL(trace_leaves_kernel, g, dim3(HASH_THREADS), 0, c->stream, (const fe*)c->lde, c->trace_leaves, (uint32_t)c->W, c->n, (uint32_t)c->Bc, log_jt); }
 }
 
 // ---- generic Merkle levels: out[i] = H(children[2i] || children[2i+1]) -------------------------------------------------------
@@ -115,17 +115,17 @@ __global__ void __launch_bounds__(HASH_THREADS) merkle_top_kernel(digest* nodes,
 static void merkle_upper_levels(dst_ctx* c, digest* nodes, size_t count) {
     while (count > 1024) {
         size_t cnt = count >> 1;
-        hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((cnt + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream,
-                           (const digest*)(nodes + count), nodes + cnt, cnt);
+        { KScope ks_(c, "merkle_level_kernel", 96.0 * cnt); hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((cnt + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream,
+                           (const digest*)(nodes + count), nodes + cnt, cnt); }
         count = cnt;
     }
-    hipLaunchKernelGGL(merkle_top_kernel, dim3(1), dim3(HASH_THREADS), 0, c->stream, nodes, (uint32_t)count);
+    { KScope ks_(c, "merkle_top_kernel", 96.0 * count); hipLaunchKernelGGL(merkle_top_kernel, dim3(1), dim3(HASH_THREADS), 0, c->stream, nodes, (uint32_t)count); }
 }
 
 void k_merkle_levels(dst_ctx* c, const digest* leaves, digest* nodes, size_t num_leaves) {
     size_t cnt = num_leaves >> 1;
-    hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((cnt + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream,
-                       leaves, nodes + cnt, cnt);
+    { KScope ks_(c, "merkle_level_kernel", 96.0 * cnt); hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((cnt + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream,
+                       leaves, nodes + cnt, cnt); }
     merkle_upper_levels(c, nodes, cnt);
 }
 
@@ -160,7 +160,7 @@ void k_constraint_tree(dst_ctx* c) {
     uint32_t KT = HASH_THREADS >> log_qt;
     size_t level1 = c->N / 4;          // leaves = N/2, first node level = N/4 entries at nodes[N/4 ..)
     dim3 g((unsigned)(c->n / KT), (unsigned)(qn >> log_qt));
-    hipLaunchKernelGGL(constraint_level1_kernel, g, dim3(HASH_THREADS), 0, c->stream, (const fe*)c->cevals, c->cnodes + level1, c->n, (uint32_t)c->Bc, log_qt);
+    { KScope ks_(c, "constraint_level1_kernel", 96.0 * level1); hipLaunchKernelGGL(constraint_level1_kernel, g, dim3(HASH_THREADS), 0, c->stream, (const fe*)c->cevals, c->cnodes + level1, c->n, (uint32_t)c->Bc, log_qt); }
     merkle_upper_levels(c, c->cnodes, level1);
 }
 
@@ -199,7 +199,7 @@ void k_fri_leaves_layer0(dst_ctx* c) {
     }
     dim3 g((unsigned)(kq / KT), (unsigned)(c->Bc >> log_jt));
     // note: when KT was reduced the kernel still derives KT from HASH_THREADS >> log_jt, so tiny sizes use the natural-order path instead
-    hipLaunchKernelGGL(fri_leaves0_kernel, g, dim3(HASH_THREADS), 0, c->stream, (const fe*)c->comp, c->fri_leaves[0], c->n, (uint32_t)c->Bc, log_jt);
+    { KScope ks_(c, "fri_leaves0_kernel", 96.0 * kq * c->Bc); hipLaunchKernelGGL(fri_leaves0_kernel, g, dim3(HASH_THREADS), 0, c->stream, (const fe*)c->comp, c->fri_leaves[0], c->n, (uint32_t)c->Bc, log_jt); }
 }
 
 __global__ void __launch_bounds__(HASH_THREADS) fri_leaves_kernel(const fe* __restrict__ e, digest* __restrict__ leaves, size_t R) {
@@ -217,6 +217,6 @@ __global__ void __launch_bounds__(HASH_THREADS) fri_leaves_kernel(const fe* __re
 
 void k_fri_leaves(dst_ctx* c, int layer) {
     size_t R = c->fri_size[layer] / 4;
-    hipLaunchKernelGGL(fri_leaves_kernel, dim3((unsigned)((R + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream,
-                       (const fe*)c->fri_e[layer], c->fri_leaves[layer], R);
+    { KScope ks_(c, "fri_leaves_kernel", 96.0 * R); hipLaunchKernelGGL(fri_leaves_kernel, dim3((unsigned)((R + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream,
+                       (const fe*)c->fri_e[layer], c->fri_leaves[layer], R); }
 }

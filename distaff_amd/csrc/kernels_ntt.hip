@@ -128,14 +128,14 @@ static void launch_two_pass(dst_ctx* c, const fe* src, size_t src_col_stride, si
     a.stage_tw = inverse ? c->w1i : c->w1f; a.tile = p.tile_a;
     size_t lds_a = ((size_t)1 << p.log_n1) * p.tile_a * sizeof(fe);
     dim3 ga((unsigned)((1u << p.log_n2) / p.tile_a), (unsigned)cosets, (unsigned)cols);
-    hipLaunchKernelGGL(ntt_pass_a, ga, dim3(NTT_THREADS), lds_a, c->stream, a);
+    { KScope ks_(c, "ntt_pass_a", 16.0 * c->n * cols * (lde ? (1 + cosets) : 2 * cosets)); hipLaunchKernelGGL(ntt_pass_a, ga, dim3(NTT_THREADS), lds_a, c->stream, a); }
     // pass B: tmp -> dst
     a.src = c->tmp; a.src_coset_stride = c->n; a.src_col_stride = c->n * cosets;
     a.dst = dst; a.dst_col_stride = dst_col_stride; a.dst_coset_stride = dst_coset_stride;
     a.stage_tw = inverse ? c->w2i : c->w2f; a.tile = p.tile_b;
     size_t lds_b = ((size_t)1 << p.log_n2) * p.tile_b * sizeof(fe);
     dim3 gb((unsigned)((1u << p.log_n1) / p.tile_b), (unsigned)cosets, (unsigned)cols);
-    hipLaunchKernelGGL(ntt_pass_b, gb, dim3(NTT_THREADS), lds_b, c->stream, a);
+    { KScope ks_(c, "ntt_pass_b", 32.0 * c->n * cols * cosets); hipLaunchKernelGGL(ntt_pass_b, gb, dim3(NTT_THREADS), lds_b, c->stream, a); }
 }
 
 // how many (coset x column) size-n arrays fit in c->tmp
@@ -182,7 +182,7 @@ __global__ void fold8_kernel(const fe* __restrict__ poly, fe* __restrict__ out, 
 void k_lde_fold8(dst_ctx* c, const fe* poly8n, fe* out) {
     // stage the folded inputs in `out` itself, then transform each coset in place (pass A reads out, pass B writes out)
     dim3 g((unsigned)((c->n + 255) / 256), (unsigned)c->Bc);
-    hipLaunchKernelGGL(fold8_kernel, g, dim3(256), 0, c->stream, poly8n, out, c->tw_lo, c->tw_hi, c->tw_lo_bits, c->log_n, c->log_N, (uint32_t)c->j0);
+    { KScope ks_(c, "fold8_kernel", 16.0 * c->n * (8 + c->Bc)); hipLaunchKernelGGL(fold8_kernel, g, dim3(256), 0, c->stream, poly8n, out, c->tw_lo, c->tw_hi, c->tw_lo_bits, c->log_n, c->log_N, (uint32_t)c->j0); }
     launch_two_pass(c, out, 0, c->n, out, 0, c->n, c->Bc, 1, false, false);
 }
 
@@ -225,8 +225,8 @@ __global__ void cross8_kernel(const fe* __restrict__ work, fe* __restrict__ out,
 
 void k_intt8_cosets(dst_ctx* c, fe* vals, fe* out8n, fe* work) {
     launch_two_pass(c, vals, 0, c->n, work, 0, c->n, 8, 1, true, false);
-    hipLaunchKernelGGL(cross8_kernel, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream, (const fe*)work, out8n,
-                       c->itw_lo, c->itw_hi, c->tw_lo_bits, c->log_n, c->log_N, c->log_b, c->eight_inv);
+    { KScope ks_(c, "cross8_kernel", 256.0 * c->n); hipLaunchKernelGGL(cross8_kernel, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream, (const fe*)work, out8n,
+                       c->itw_lo, c->itw_hi, c->tw_lo_bits, c->log_n, c->log_N, c->log_b, c->eight_inv); }
 }
 
 // ---- layout conversion (inspection only) ------------------------------------------------------------------------------------
@@ -238,5 +238,5 @@ __global__ void coset_to_natural_kernel(const fe* __restrict__ src, fe* __restri
 }
 void k_coset_to_natural(dst_ctx* c, const fe* src, size_t cosets, fe* dst) {
     size_t total = c->n * cosets;
-    hipLaunchKernelGGL(coset_to_natural_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, src, dst, c->n, cosets);
+    { KScope ks_(c, "coset_to_natural_kernel", 32.0 * total); hipLaunchKernelGGL(coset_to_natural_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, src, dst, c->n, cosets); }
 }

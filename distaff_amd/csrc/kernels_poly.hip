@@ -32,7 +32,7 @@ static PowTab build_pow_table(dst_ctx* c, fe* where, fe b, size_t max_exp) {
     uint32_t lb = (bits + 1) / 2, hb = bits - lb;
     fe* lo = where; fe* hi = where + ((size_t)1 << lb);
     uint32_t cnt = 1u << lb;
-    hipLaunchKernelGGL(pow_table_kernel, dim3((cnt + PT - 1) / PT), dim3(PT), 0, c->stream, lo, hi, b, lb, hb);
+    { KScope ks_(c, "pow_table_kernel", 0.0); hipLaunchKernelGGL(pow_table_kernel, dim3((cnt + PT - 1) / PT), dim3(PT), 0, c->stream, lo, hi, b, lb, hb); }
     PowTab t; t.lo = lo; t.hi = hi; t.lb = lb;
     return t;
 }
@@ -84,12 +84,12 @@ __global__ void scan_add_offsets_kernel(fe* data, size_t len, const fe* block_of
 static void suffix_scan(dst_ctx* c, fe* data, size_t len, fe* scratch) {
     size_t blocks = (len + SCAN_CHUNK - 1) / SCAN_CHUNK;
     if (blocks == 1) {
-        hipLaunchKernelGGL(scan_block_kernel, dim3(1), dim3(PT), 0, c->stream, data, len, (fe*)nullptr);
+        { KScope ks_(c, "scan_block_kernel", 32.0 * len); hipLaunchKernelGGL(scan_block_kernel, dim3(1), dim3(PT), 0, c->stream, data, len, (fe*)nullptr); }
         return;
     }
-    hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)blocks), dim3(PT), 0, c->stream, data, len, scratch);
+    { KScope ks_(c, "scan_block_kernel", 32.0 * len); hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)blocks), dim3(PT), 0, c->stream, data, len, scratch); }
     suffix_scan(c, scratch, blocks, scratch + blocks);
-    hipLaunchKernelGGL(scan_add_offsets_kernel, dim3((unsigned)((len + PT - 1) / PT)), dim3(PT), 0, c->stream, data, len, (const fe*)scratch);
+    { KScope ks_(c, "scan_add_offsets_kernel", 32.0 * len); hipLaunchKernelGGL(scan_add_offsets_kernel, dim3((unsigned)((len + PT - 1) / PT)), dim3(PT), 0, c->stream, data, len, (const fe*)scratch); }
 }
 
 // ---- synthetic division by (x - b): a[i] <- sum_{t > i} a[t] * b^(t - i - 1) ---------------------------------------------------
@@ -108,16 +108,16 @@ void k_syn_div(dst_ctx* c, fe* a, size_t len, fe b) {
     unsigned g = (unsigned)((len + PT - 1) / PT);
     fe* scr = c->scratch;
     if (fe_is_zero(b)) {
-        hipLaunchKernelGGL(shift_down_kernel, dim3(g), dim3(PT), 0, c->stream, (const fe*)a, scr, len);
+        { KScope ks_(c, "shift_down_kernel", 32.0 * len); hipLaunchKernelGGL(shift_down_kernel, dim3(g), dim3(PT), 0, c->stream, (const fe*)a, scr, len); }
         hipMemcpyAsync(a, scr, len * sizeof(fe), hipMemcpyDeviceToDevice, c->stream);
         return;
     }
     size_t te = pow_table_elems(len + 1);
     PowTab fw = build_pow_table(c, scr, b, len + 1);
     PowTab bw = build_pow_table(c, scr + te, fe_inv(b), len + 1);
-    hipLaunchKernelGGL(scale_by_powers_kernel, dim3(g), dim3(PT), 0, c->stream, a, len, fw, (uint64_t)0);
+    { KScope ks_(c, "scale_by_powers_kernel", 32.0 * len); hipLaunchKernelGGL(scale_by_powers_kernel, dim3(g), dim3(PT), 0, c->stream, a, len, fw, (uint64_t)0); }
     suffix_scan(c, a, len, scr + 2 * te);
-    hipLaunchKernelGGL(scale_by_powers_kernel, dim3(g), dim3(PT), 0, c->stream, a, len, bw, (uint64_t)1);
+    { KScope ks_(c, "scale_by_powers_kernel", 32.0 * len); hipLaunchKernelGGL(scale_by_powers_kernel, dim3(g), dim3(PT), 0, c->stream, a, len, bw, (uint64_t)1); }
 }
 
 // ---- division by (x^degree - 1) / (x - e) (polynom.rs:202-236) -------------------------------------------------------------------
@@ -133,7 +133,7 @@ __global__ void syn_div_expanded_kernel(const fe* __restrict__ a, fe* __restrict
     out[i] = fe_sub(r0, fe_mul(e, r1));
 }
 void k_syn_div_expanded(dst_ctx* c, const fe* a, fe* out, size_t len, size_t degree, fe exception) {
-    hipLaunchKernelGGL(syn_div_expanded_kernel, dim3((unsigned)((len + PT - 1) / PT)), dim3(PT), 0, c->stream, a, out, len, degree, exception);
+    { KScope ks_(c, "syn_div_expanded_kernel", 32.0 * len); hipLaunchKernelGGL(syn_div_expanded_kernel, dim3((unsigned)((len + PT - 1) / PT)), dim3(PT), 0, c->stream, a, out, len, degree, exception); }
 }
 
 // ---- evaluation of `ncols` polynomials of `len` coefficients at x -----------------------------------------------------------------
@@ -173,8 +173,8 @@ void k_horner(dst_ctx* c, const fe* polys, size_t ncols, size_t len, fe x, fe* o
     size_t blocks = (len + PT * 8 - 1) / (PT * 8);
     if (blocks > 512) blocks = 512;
     fe* partial = scr + te;
-    hipLaunchKernelGGL(horner_partial_kernel, dim3((unsigned)blocks, (unsigned)ncols), dim3(PT), 0, c->stream, polys, len, p, partial);
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)ncols), dim3(PT), 0, c->stream, (const fe*)partial, blocks, out_dev);
+    { KScope ks_(c, "horner_partial_kernel", 16.0 * len * ncols); hipLaunchKernelGGL(horner_partial_kernel, dim3((unsigned)blocks, (unsigned)ncols), dim3(PT), 0, c->stream, polys, len, p, partial); }
+    { KScope ks_(c, "reduce_rows_kernel", 0.0); hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)ncols), dim3(PT), 0, c->stream, (const fe*)partial, blocks, out_dev); }
 }
 
 // ---- out[i] = sum_k coeffs[k] * cols[k][i] ------------------------------------------------------------------------------------------
@@ -186,21 +186,21 @@ __global__ void lincomb_kernel(const fe* __restrict__ cols, size_t ncols, size_t
     out[i] = acc;
 }
 void k_lincomb(dst_ctx* c, const fe* cols, size_t ncols, size_t len, const fe* coeffs_dev, fe* out) {
-    hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)((len + PT - 1) / PT)), dim3(PT), 0, c->stream, cols, ncols, len, coeffs_dev, out);
+    { KScope ks_(c, "lincomb_kernel", 16.0 * len * (ncols + 1)); hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)((len + PT - 1) / PT)), dim3(PT), 0, c->stream, cols, ncols, len, coeffs_dev, out); }
 }
 __global__ void axpy_kernel(fe* y, const fe* x, fe a, size_t len) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < len) y[i] = fe_add(y[i], fe_mul(x[i], a));
 }
 void k_axpy(dst_ctx* c, fe* y, const fe* x, fe a, size_t len) {
-    hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((len + PT - 1) / PT)), dim3(PT), 0, c->stream, y, x, a, len);
+    { KScope ks_(c, "axpy_kernel", 48.0 * len); hipLaunchKernelGGL(axpy_kernel, dim3((unsigned)((len + PT - 1) / PT)), dim3(PT), 0, c->stream, y, x, a, len); }
 }
 __global__ void add_kernel(fe* y, const fe* x, size_t len) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < len) y[i] = fe_add(y[i], x[i]);
 }
 void k_add(dst_ctx* c, fe* y, const fe* x, size_t len) {
-    hipLaunchKernelGGL(add_kernel, dim3((unsigned)((len + PT - 1) / PT)), dim3(PT), 0, c->stream, y, x, len);
+    { KScope ks_(c, "add_kernel", 48.0 * len); hipLaunchKernelGGL(add_kernel, dim3((unsigned)((len + PT - 1) / PT)), dim3(PT), 0, c->stream, y, x, len); }
 }
 // y[0] -= sum_k coeffs[k] * values[k]   (the constant terms T_k(z) * cc_k of trace_table.rs:226-233)
 __global__ void sub_dot_at0_kernel(fe* y, const fe* values, const fe* coeffs, size_t count) {
@@ -211,10 +211,10 @@ __global__ void sub_dot_at0_kernel(fe* y, const fe* values, const fe* coeffs, si
     }
 }
 void k_sub_dot_at0(dst_ctx* c, fe* y, const fe* values_dev, const fe* coeffs_dev, size_t count) {
-    hipLaunchKernelGGL(sub_dot_at0_kernel, dim3(1), dim3(64), 0, c->stream, y, values_dev, coeffs_dev, count);
+    { KScope ks_(c, "sub_dot_at0_kernel", 0.0); hipLaunchKernelGGL(sub_dot_at0_kernel, dim3(1), dim3(64), 0, c->stream, y, values_dev, coeffs_dev, count); }
 }
 __global__ void sub_at0_kernel(fe* y, const fe* v) { if (threadIdx.x == 0 && blockIdx.x == 0) y[0] = fe_sub(y[0], v[0]); }
-void k_sub_at0(dst_ctx* c, fe* y, const fe* v_dev) { hipLaunchKernelGGL(sub_at0_kernel, dim3(1), dim3(64), 0, c->stream, y, v_dev); }
+void k_sub_at0(dst_ctx* c, fe* y, const fe* v_dev) { { KScope ks_(c, "sub_at0_kernel", 0.0); hipLaunchKernelGGL(sub_at0_kernel, dim3(1), dim3(64), 0, c->stream, y, v_dev); } }
 
 // ---- FRI fold -----------------------------------------------------------------------------------------------------------------------
 // row r of a layer of size M (R = M/4 rows) sits on xs = x * {1, i, -1, -i} with x = w_N^(r * stride) and i = w_N^(N/4);
@@ -264,10 +264,10 @@ void k_fri_fold(dst_ctx* c, int layer, fe special_x) {
         while ((1u << log_jt) < jt) log_jt++;
         uint32_t KT = PT >> log_jt;
         dim3 g((unsigned)((c->n / 4) / KT), (unsigned)(c->Bc >> log_jt));
-        hipLaunchKernelGGL(fri_fold0_kernel, g, dim3(PT), 0, c->stream, (const fe*)c->comp, c->fri_e[1], c->n, (uint32_t)c->Bc, c->log_b, log_jt, (uint32_t)c->j0, a);
+        { KScope ks_(c, "fri_fold0_kernel", 80.0 * (c->n / 4) * c->Bc); hipLaunchKernelGGL(fri_fold0_kernel, g, dim3(PT), 0, c->stream, (const fe*)c->comp, c->fri_e[1], c->n, (uint32_t)c->Bc, c->log_b, log_jt, (uint32_t)c->j0, a); }
     } else {
-        hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((R + PT - 1) / PT)), dim3(PT), 0, c->stream, (const fe*)c->fri_e[layer], c->fri_e[layer + 1], R,
-                           (uint32_t)(2 * layer), a);
+        { KScope ks_(c, "fri_fold_kernel", 80.0 * R); hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((R + PT - 1) / PT)), dim3(PT), 0, c->stream, (const fe*)c->fri_e[layer], c->fri_e[layer + 1], R,
+                           (uint32_t)(2 * layer), a); }
     }
 }
 
@@ -293,7 +293,7 @@ int k_pow(dst_ctx* c, const uint8_t seed[32], uint32_t grinding, uint64_t* nonce
     HIP_TRY(c, hipMemcpyAsync(d_best, &init, 8, hipMemcpyHostToDevice, c->stream));
     const uint64_t batch = (uint64_t)1 << 22;
     for (uint64_t base = 1;; base += batch) {
-        hipLaunchKernelGGL(pow_kernel, dim3((unsigned)(batch / PT)), dim3(PT), 0, c->stream, (const uint32_t*)d_seed, base, grinding, d_best);
+        { KScope ks_(c, "pow_kernel", 0.0); hipLaunchKernelGGL(pow_kernel, dim3((unsigned)(batch / PT)), dim3(PT), 0, c->stream, (const uint32_t*)d_seed, base, grinding, d_best); }
         unsigned long long best = 0;
         HIP_TRY(c, hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -313,7 +313,7 @@ void k_gather(dst_ctx* c, const void* src, size_t item_bytes, const uint64_t* id
     uint32_t vp = (uint32_t)(item_bytes / 16);
     size_t total = count * vp;
     if (!total) return;
-    hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((total + PT - 1) / PT)), dim3(PT), 0, c->stream, (const uint4*)src, vp, idx_dev, count, (uint4*)dst);
+    { KScope ks_(c, "gather_kernel", 0.0); hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((total + PT - 1) / PT)), dim3(PT), 0, c->stream, (const uint4*)src, vp, idx_dev, count, (uint4*)dst); }
 }
 // gather of one trace row per position from the coset-major LDE: out[p][c] = lde[c][j][k] with position = B*k + j
 __global__ void gather_rows_kernel(const fe* __restrict__ lde, size_t n, uint32_t Bc, uint32_t log_b, uint32_t j0, uint32_t W,
@@ -327,8 +327,8 @@ __global__ void gather_rows_kernel(const fe* __restrict__ lde, size_t n, uint32_
 }
 void k_gather_rows(dst_ctx* c, const uint64_t* positions_dev, size_t count, fe* out) {
     size_t total = count * c->W;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + PT - 1) / PT)), dim3(PT), 0, c->stream, (const fe*)c->lde, c->n, (uint32_t)c->Bc, c->log_b,
-                       (uint32_t)c->j0, (uint32_t)c->W, positions_dev, count, out);
+    { KScope ks_(c, "gather_rows_kernel", 0.0); hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)((total + PT - 1) / PT)), dim3(PT), 0, c->stream, (const fe*)c->lde, c->n, (uint32_t)c->Bc, c->log_b,
+                       (uint32_t)c->j0, (uint32_t)c->W, positions_dev, count, out); }
 }
 
 // ---- mulmod micro-benchmark (bench.py's ALU ceiling) --------------------------------------------------------------------------------------
@@ -348,9 +348,9 @@ int k_bench_mulmod(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms) {
     lanes = lanes / PT * PT;
     hipEvent_t e0, e1;
     HIP_TRY(c, hipEventCreate(&e0)); HIP_TRY(c, hipEventCreate(&e1));
-    hipLaunchKernelGGL(mulmod_bench_kernel, dim3((unsigned)(lanes / PT)), dim3(PT), 0, c->stream, c->scratch, 4u);   // warm-up
+    { KScope ks_(c, "mulmod_bench_kernel", 0.0); hipLaunchKernelGGL(mulmod_bench_kernel, dim3((unsigned)(lanes / PT)), dim3(PT), 0, c->stream, c->scratch, 4u); }   // warm-up
     HIP_TRY(c, hipEventRecord(e0, c->stream));
-    hipLaunchKernelGGL(mulmod_bench_kernel, dim3((unsigned)(lanes / PT)), dim3(PT), 0, c->stream, c->scratch, iters);
+    { KScope ks_(c, "mulmod_bench_kernel", 0.0); hipLaunchKernelGGL(mulmod_bench_kernel, dim3((unsigned)(lanes / PT)), dim3(PT), 0, c->stream, c->scratch, iters); }
     HIP_TRY(c, hipEventRecord(e1, c->stream));
     HIP_TRY(c, hipEventSynchronize(e1));
     float f = 0; HIP_TRY(c, hipEventElapsedTime(&f, e0, e1));

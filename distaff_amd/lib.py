@@ -21,7 +21,7 @@ BUF = {"polys": 0, "lde": 1, "trace_leaves": 2, "trace_nodes": 3, "ceval_i": 4, 
 EXPORTS = ["dst_ctx_create", "dst_ctx_destroy", "dst_last_error", "dst_phase_ms", "dst_trace_upload", "dst_trace_upload_contiguous",
            "dst_commit_trace", "dst_eval_constraints", "dst_compose", "dst_fri_commit_layer", "dst_fri_fold", "dst_pow_grind",
            "dst_build_proof", "dst_prove", "dst_prng_vector", "dst_query_positions", "dst_blake3", "dst_fibonacci_trace",
-           "dst_read_buffer", "dst_bench_mulmod"]
+           "dst_read_buffer", "dst_bench_mulmod", "dst_set_profiling", "dst_kernel_stats"]
 
 
 class DistaffError(RuntimeError):
@@ -220,6 +220,15 @@ class Context:
 
     def read_elements(self, what, arg=0):
         return self.read(what, arg).view(np.uint64).reshape(-1, 2)
+
+    def set_profiling(self, enabled=True):
+        self._check(self.lib.dst_set_profiling(self._h, int(enabled)))
+
+    def kernel_stats(self, reset=True):
+        import json
+        buf = ctypes.create_string_buffer(1 << 16)
+        self._check(self.lib.dst_kernel_stats(self._h, buf, ctypes.c_size_t(1 << 16), int(reset)))
+        return json.loads(buf.value.decode())
 
     def bench_mulmod(self, lanes=1 << 20, iters=256):
         ms = ctypes.c_double(0)

@@ -114,6 +114,10 @@ int dst_read_buffer(dst_ctx* ctx, uint32_t what, uint32_t arg, uint8_t* out, siz
 /* micro-benchmark hook used by bench.py's roofline section: runs `iters` dependent modular multiplications per lane
  * on `lanes` lanes and returns the elapsed milliseconds. */
 int dst_bench_mulmod(dst_ctx* ctx, uint64_t lanes, uint32_t iters, double* ms);
+/* per-kernel timing: when enabled every kernel launch is bracketed by HIP events on the context's stream;
+ * dst_kernel_stats drains them and writes a JSON object {"kernel": {"launches": k, "ms": total, "bytes": algorithmic}, ...}. */
+int dst_set_profiling(dst_ctx* ctx, int enabled);
+int dst_kernel_stats(dst_ctx* ctx, char* json_out, size_t cap, int reset);
 
 #ifdef __cplusplus
 }
