@@ -619,6 +619,11 @@ int dst_read_buffer(dst_ctx* c, uint32_t what, uint32_t arg, uint8_t* out, size_
     return DST_OK;
 }
 
+int dst_field_op(dst_ctx* c, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t count) {
+    if (!c || !a || !b || !out) return DST_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return k_field_op(c, op, a, b, out, count);
+}
 int dst_set_profiling(dst_ctx* c, int enabled) { if (!c) return DST_ERR_ARG; c->profile = enabled != 0; return DST_OK; }
 int dst_kernel_stats(dst_ctx* c, char* json_out, size_t cap, int reset) {
     if (!c || !json_out) return DST_ERR_ARG;

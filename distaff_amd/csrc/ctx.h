@@ -163,3 +163,4 @@ int k_pow(dst_ctx* c, const uint8_t seed[32], uint32_t grinding, uint64_t* nonce
 void k_gather(dst_ctx* c, const void* src, size_t item_bytes, const uint64_t* idx_dev, size_t count, void* dst);
 void k_gather_rows(dst_ctx* c, const uint64_t* positions_dev, size_t count, fe* out);
 int k_bench_mulmod(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms);
+int k_field_op(dst_ctx* c, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t count);

@@ -114,7 +114,7 @@ FE_HD fe fe_reduce8(const uint32_t* t) {
     return ge ? fe_make(z0, z1, z2, z3) : fe_make(y0, y1, y2, y3);
 }
 
-FE_HD fe fe_mul(const fe& a, const fe& b) {
+FE_HD fe fe_mul_portable(const fe& a, const fe& b) {
     uint32_t t[8];
     uint64_t c;
     // row 0
@@ -132,6 +132,99 @@ FE_HD fe fe_mul(const fe& a, const fe& b) {
         t[i + 4] = (uint32_t)(c >> 32);
     }
     return fe_reduce8(t);
+}
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// ---- gfx950 formulation --------------------------------------------------------------------------------------------------
+// 16 v_mad_u64_u32 for the 256-bit product: partial products with i + j even / odd accumulate in separate 64-bit windows
+// (E0..E3 at limbs 0,2,4,6 and O0..O2 at limbs 1,3,5), the carry-out of each accumulating mad is counted with one
+// v_addc_co_u32, and the windows are merged with two carry chains.  The reduction multiplies the four high limbs by
+// K = 45*2^8 with independent mads (no carry chain between them) and folds with add/sub-with-carry chains.
+__device__ __forceinline__ uint32_t fe_addc(uint32_t a, uint32_t b, uint32_t cin, uint32_t* cout) { return __builtin_addc(a, b, cin, cout); }
+__device__ __forceinline__ uint32_t fe_subb(uint32_t a, uint32_t b, uint32_t bin, uint32_t* bout) { return __builtin_subc(a, b, bin, bout); }
+__device__ __forceinline__ void fe_mac_c(uint64_t& acc, uint32_t& cnt, uint32_t a, uint32_t b) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(cnt) : "v"(a), "v"(b) : "vcc");
+}
+__device__ __forceinline__ fe fe_mul_gfx950(const fe& a, const fe& b) {
+#define FE_LO(x) ((uint32_t)(x))
+#define FE_HI(x) ((uint32_t)((x) >> 32))
+    uint64_t E0 = (uint64_t)a.v[0] * b.v[0];
+    uint64_t E1 = (uint64_t)a.v[0] * b.v[2]; uint32_t ce1 = 0; fe_mac_c(E1, ce1, a.v[1], b.v[1]); fe_mac_c(E1, ce1, a.v[2], b.v[0]);
+    uint64_t E2 = (uint64_t)a.v[1] * b.v[3]; uint32_t ce2 = 0; fe_mac_c(E2, ce2, a.v[2], b.v[2]); fe_mac_c(E2, ce2, a.v[3], b.v[1]);
+    uint64_t E3 = (uint64_t)a.v[3] * b.v[3];
+    uint64_t O0 = (uint64_t)a.v[0] * b.v[1]; uint32_t co0 = 0; fe_mac_c(O0, co0, a.v[1], b.v[0]);
+    uint64_t O1 = (uint64_t)a.v[0] * b.v[3]; uint32_t co1 = 0; fe_mac_c(O1, co1, a.v[1], b.v[2]); fe_mac_c(O1, co1, a.v[2], b.v[1]); fe_mac_c(O1, co1, a.v[3], b.v[0]);
+    uint64_t O2 = (uint64_t)a.v[2] * b.v[3]; uint32_t co2 = 0; fe_mac_c(O2, co2, a.v[3], b.v[2]);
+    uint32_t t0, t1, t2, t3, t4, t5, t6, t7, c, bw;
+    t0 = FE_LO(E0);
+    t1 = fe_addc(FE_HI(E0), FE_LO(O0), 0, &c);
+    t2 = fe_addc(FE_LO(E1), FE_HI(O0), c, &c);
+    t3 = fe_addc(FE_HI(E1), FE_LO(O1), c, &c);
+    t4 = fe_addc(FE_LO(E2), FE_HI(O1), c, &c);
+    t5 = fe_addc(FE_HI(E2), FE_LO(O2), c, &c);
+    t6 = fe_addc(FE_LO(E3), FE_HI(O2), c, &c);
+    t7 = FE_HI(E3) + c;
+    t3 = fe_addc(t3, co0, 0, &c);
+    t4 = fe_addc(t4, ce1, c, &c);
+    t5 = fe_addc(t5, co1, c, &c);
+    t6 = fe_addc(t6, ce2, c, &c);
+    t7 = t7 + co2 + c;
+    // fold 1: v = lo + ((hi * K) << 32) - hi
+    uint64_t P0 = (uint64_t)t4 * FE_K, P1 = (uint64_t)t5 * FE_K, P2 = (uint64_t)t6 * FE_K, P3 = (uint64_t)t7 * FE_K;
+    uint32_t u1, u2, u3, u4, u5;
+    u1 = fe_addc(t1, FE_LO(P0), 0, &c);
+    u2 = fe_addc(t2, FE_LO(P1), c, &c);
+    u3 = fe_addc(t3, FE_LO(P2), c, &c);
+    u4 = fe_addc(FE_LO(P3), 0, c, &c);
+    u5 = c;
+    u2 = fe_addc(u2, FE_HI(P0), 0, &c);
+    u3 = fe_addc(u3, FE_HI(P1), c, &c);
+    u4 = fe_addc(u4, FE_HI(P2), c, &c);
+    u5 = u5 + FE_HI(P3) + c;
+    uint32_t v0, v1, v2, v3, v4, v5;
+    v0 = fe_subb(t0, t4, 0, &bw);
+    v1 = fe_subb(u1, t5, bw, &bw);
+    v2 = fe_subb(u2, t6, bw, &bw);
+    v3 = fe_subb(u3, t7, bw, &bw);
+    v4 = fe_subb(u4, 0, bw, &bw);
+    v5 = u5 - bw;
+    // fold 2: y = v_lo + (((v5:v4) * K) << 32) - (v5:v4)
+    uint64_t w = (uint64_t)v4 * FE_K;
+    uint32_t w0 = FE_LO(w), w1 = FE_HI(w) + v5 * FE_K;
+    uint32_t y0, y1, y2, y3, y4;
+    y1 = fe_addc(v1, w0, 0, &c);
+    y2 = fe_addc(v2, w1, c, &c);
+    y3 = fe_addc(v3, 0, c, &c);
+    y4 = c;
+    y0 = fe_subb(v0, v4, 0, &bw);
+    y1 = fe_subb(y1, v5, bw, &bw);
+    y2 = fe_subb(y2, 0, bw, &bw);
+    y3 = fe_subb(y3, 0, bw, &bw);
+    y4 = y4 - bw;
+    // fold 3: add y4 * C128 (y4 is 0 or 1)
+    uint32_t mask = 0u - y4;
+    y0 = fe_addc(y0, mask, 0, &c);
+    y1 = fe_addc(y1, mask & FE_C1, c, &c);
+    y2 = fe_addc(y2, 0, c, &c);
+    y3 = y3 + c;
+    // canonical form
+    uint32_t z0, z1, z2, z3;
+    z0 = fe_addc(y0, FE_C0, 0, &c);
+    z1 = fe_addc(y1, FE_C1, c, &c);
+    z2 = fe_addc(y2, 0, c, &c);
+    z3 = fe_addc(y3, 0, c, &c);
+#undef FE_LO
+#undef FE_HI
+    return c ? fe_make(z0, z1, z2, z3) : fe_make(y0, y1, y2, y3);
+}
+#endif
+
+FE_HD fe fe_mul(const fe& a, const fe& b) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FE_PORTABLE_MUL)
+    return fe_mul_gfx950(a, b);
+#else
+    return fe_mul_portable(a, b);
+#endif
 }
 
 FE_HD fe fe_sqr(const fe& a) { return fe_mul(a, a); }

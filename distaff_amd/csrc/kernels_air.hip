@@ -16,6 +16,9 @@
 #include "rescue_constants.h"
 
 #define AIR_THREADS 128
+#ifndef AIR_WAVES_PER_SIMD
+#define AIR_WAVES_PER_SIMD 2      // caps the kernel at 256 registers per lane
+#endif
 
 struct AirArgs {
     const fe* lde;               // [W][Bc][n]
@@ -73,7 +76,7 @@ struct Acc {
 
 // CL, LL, SL are compile-time capacities (>= the run-time slice lengths a.cl, a.ll, a.sl)
 template <int CL, int LL, int SL>
-__global__ void __launch_bounds__(AIR_THREADS) air_kernel(AirArgs a) {
+__global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(AirArgs a) {
     const int cl = (int)a.cl, ll = (int)a.ll, sl = (int)a.sl;
     const size_t k = (size_t)blockIdx.x * AIR_THREADS + threadIdx.x;
     if (k >= a.n) return;

@@ -13,7 +13,7 @@
 // Loads/stores are T*16-byte segments (T = 4: 64 B); the working set of one workgroup is 2^log * T * 16 B of LDS.
 #include "ctx.h"
 
-#define NTT_THREADS 256
+#define NTT_THREADS 1024
 
 struct NttArgs {
     const fe* src; fe* dst;
@@ -22,7 +22,7 @@ struct NttArgs {
     const fe* stage_tw;        // w_len^t, t < len/2 (forward or inverse)
     const fe* tw_lo; const fe* tw_hi;           // two-level table of the domain generator (forward or inverse, maybe pre-scaled)
     const fe* prescale;        // w_{B*n1}^t or nullptr
-    uint32_t log_n1, log_n2, tile, lo_bits, log_N, log_b;
+    uint32_t log_n1, log_n2, tile /* log2 of the tile width */, lo_bits, log_N, log_b;
     uint32_t j0;               // global index of the first local coset (0 when `coset_twiddle` is off)
     uint32_t coset_twiddle;    // 1: four-step twiddle includes the coset offset j (LDE), 0: plain transform
     uint32_t has_scale;        // 1: multiply the result by `scale` (1/n of inverse transforms)
@@ -39,19 +39,21 @@ __device__ __forceinline__ fe dom_pow(const fe* lo, const fe* hi, uint32_t lo_bi
 }
 
 // in-LDS radix-2 DIF over the first index of L[len][T]; output position r holds frequency bitrev(r)
-__device__ __forceinline__ void lds_ntt_dif(fe* L, const fe* __restrict__ W, uint32_t log_len, uint32_t T) {
+__device__ __forceinline__ void lds_ntt_dif(fe* L, const fe* __restrict__ W, uint32_t log_len, uint32_t log_t) {
     const uint32_t half = 1u << (log_len - 1);
+    const uint32_t T = 1u << log_t;
     for (uint32_t s = 1; s <= log_len; s++) {
         const uint32_t ld = log_len - s;             // log2 of butterfly distance
         const uint32_t d = 1u << ld;
         for (uint32_t w = threadIdx.x; w < half * T; w += NTT_THREADS) {
-            uint32_t t = w % T, q = w / T;
+            uint32_t t = w & (T - 1), q = w >> log_t;
             uint32_t pos = q & (d - 1), blk = q >> ld;
             uint32_t i0 = (blk << (ld + 1)) + pos, i1 = i0 + d;
-            fe a = L[i0 * T + t], b = L[i1 * T + t];
-            L[i0 * T + t] = fe_add(a, b);
+            fe* p0 = L + ((i0 << log_t) + t); fe* p1 = L + ((i1 << log_t) + t);
+            fe a = *p0, b = *p1;
+            *p0 = fe_add(a, b);
             fe diff = fe_sub(a, b);
-            L[i1 * T + t] = (s == log_len) ? diff : fe_mul(diff, W[pos << (s - 1)]);
+            *p1 = (s == log_len) ? diff : fe_mul(diff, W[pos << (s - 1)]);
         }
         __syncthreads();
     }
@@ -62,52 +64,52 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
 // grid: (n2 / T, cosets, columns)
 __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_a(NttArgs a) {
     fe* L = reinterpret_cast<fe*>(ntt_smem);
-    const uint32_t T = a.tile, n1 = 1u << a.log_n1, n2 = 1u << a.log_n2;
+    const uint32_t log_t = a.tile, T = 1u << log_t, n1 = 1u << a.log_n1, n2 = 1u << a.log_n2;
     const uint32_t m2_0 = blockIdx.x * T;
     const uint32_t jl = blockIdx.y, jg = a.j0 + jl;
     const fe* src = a.src + (size_t)blockIdx.z * a.src_col_stride + (size_t)jl * a.src_coset_stride;
     fe* dst = a.dst + (size_t)blockIdx.z * a.dst_col_stride + (size_t)jl * a.dst_coset_stride;
     const uint32_t pmask = (1u << (a.log_b + a.log_n1)) - 1u;
     for (uint32_t idx = threadIdx.x; idx < n1 * T; idx += NTT_THREADS) {
-        uint32_t t = idx % T, m1 = idx / T;
-        fe v = src[(size_t)m1 * n2 + m2_0 + t];
+        uint32_t t = idx & (T - 1), m1 = idx >> log_t;
+        fe v = src[((size_t)m1 << a.log_n2) + m2_0 + t];
         if (a.prescale != nullptr && jg != 0) v = fe_mul(v, a.prescale[(jg * m1) & pmask]);
         L[idx] = v;
     }
     __syncthreads();
-    lds_ntt_dif(L, a.stage_tw, a.log_n1, T);
+    lds_ntt_dif(L, a.stage_tw, a.log_n1, log_t);
     const uint64_t nmask = (1ull << a.log_N) - 1ull;
     for (uint32_t idx = threadIdx.x; idx < n1 * T; idx += NTT_THREADS) {
-        uint32_t t = idx % T, r = idx / T;
+        uint32_t t = idx & (T - 1), r = idx >> log_t;
         uint32_t k1 = __brev(r) >> (32 - a.log_n1);
         uint32_t m2 = m2_0 + t;
         uint64_t e = ((uint64_t)m2 * (((uint64_t)k1 << a.log_b) + (a.coset_twiddle ? jg : 0u))) & nmask;
         fe v = L[idx];
         if (e != 0) v = fe_mul(v, dom_pow(a.tw_lo, a.tw_hi, a.lo_bits, e));
-        dst[(size_t)k1 * n2 + m2] = v;
+        dst[((size_t)k1 << a.log_n2) + m2] = v;
     }
 }
 
 // grid: (n1 / T, cosets, columns)
 __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_b(NttArgs a) {
     fe* L = reinterpret_cast<fe*>(ntt_smem);
-    const uint32_t T = a.tile, n1 = 1u << a.log_n1, n2 = 1u << a.log_n2;
+    const uint32_t log_t = a.tile, T = 1u << log_t, n1 = 1u << a.log_n1, n2 = 1u << a.log_n2;
     const uint32_t k1_0 = blockIdx.x * T;
     const uint32_t jl = blockIdx.y;
     const fe* src = a.src + (size_t)blockIdx.z * a.src_col_stride + (size_t)jl * a.src_coset_stride;
     fe* dst = a.dst + (size_t)blockIdx.z * a.dst_col_stride + (size_t)jl * a.dst_coset_stride;
     for (uint32_t idx = threadIdx.x; idx < n2 * T; idx += NTT_THREADS) {
-        uint32_t m2 = idx % n2, t = idx / n2;                       // contiguous reads along m2
-        L[m2 * T + t] = src[(size_t)(k1_0 + t) * n2 + m2];
+        uint32_t m2 = idx & (n2 - 1), t = idx >> a.log_n2;           // contiguous reads along m2
+        L[(m2 << log_t) + t] = src[((size_t)(k1_0 + t) << a.log_n2) + m2];
     }
     __syncthreads();
-    lds_ntt_dif(L, a.stage_tw, a.log_n2, T);
+    lds_ntt_dif(L, a.stage_tw, a.log_n2, log_t);
     for (uint32_t idx = threadIdx.x; idx < n2 * T; idx += NTT_THREADS) {
-        uint32_t t = idx % T, r = idx / T;
+        uint32_t t = idx & (T - 1), r = idx >> log_t;
         uint32_t k2 = a.log_n2 ? (__brev(r) >> (32 - a.log_n2)) : 0u;
         fe v = L[idx];
         if (a.has_scale) v = fe_mul(v, a.scale);
-        dst[(size_t)k2 * n1 + k1_0 + t] = v;
+        dst[((size_t)k2 << a.log_n1) + k1_0 + t] = v;
     }
 }
 
@@ -125,14 +127,14 @@ static void launch_two_pass(dst_ctx* c, const fe* src, size_t src_col_stride, si
     // pass A: src -> tmp
     a.src = src; a.src_col_stride = src_col_stride; a.src_coset_stride = src_coset_stride;
     a.dst = c->tmp; a.dst_coset_stride = c->n; a.dst_col_stride = c->n * cosets;
-    a.stage_tw = inverse ? c->w1i : c->w1f; a.tile = p.tile_a;
+    a.stage_tw = inverse ? c->w1i : c->w1f; a.tile = (uint32_t)__builtin_ctz(p.tile_a);
     size_t lds_a = ((size_t)1 << p.log_n1) * p.tile_a * sizeof(fe);
     dim3 ga((unsigned)((1u << p.log_n2) / p.tile_a), (unsigned)cosets, (unsigned)cols);
     { KScope ks_(c, "ntt_pass_a", 16.0 * c->n * cols * (lde ? (1 + cosets) : 2 * cosets)); hipLaunchKernelGGL(ntt_pass_a, ga, dim3(NTT_THREADS), lds_a, c->stream, a); }
     // pass B: tmp -> dst
     a.src = c->tmp; a.src_coset_stride = c->n; a.src_col_stride = c->n * cosets;
     a.dst = dst; a.dst_col_stride = dst_col_stride; a.dst_coset_stride = dst_coset_stride;
-    a.stage_tw = inverse ? c->w2i : c->w2f; a.tile = p.tile_b;
+    a.stage_tw = inverse ? c->w2i : c->w2f; a.tile = (uint32_t)__builtin_ctz(p.tile_b);
     size_t lds_b = ((size_t)1 << p.log_n2) * p.tile_b * sizeof(fe);
     dim3 gb((unsigned)((1u << p.log_n1) / p.tile_b), (unsigned)cosets, (unsigned)cols);
     { KScope ks_(c, "ntt_pass_b", 32.0 * c->n * cols * cosets); hipLaunchKernelGGL(ntt_pass_b, gb, dim3(NTT_THREADS), lds_b, c->stream, a); }

@@ -332,29 +332,61 @@ void k_gather_rows(dst_ctx* c, const uint64_t* positions_dev, size_t count, fe* 
 }
 
 // ---- mulmod micro-benchmark (bench.py's ALU ceiling) --------------------------------------------------------------------------------------
+template <int VARIANT>
 __global__ void __launch_bounds__(PT) mulmod_bench_kernel(fe* out, uint32_t iters) {
+    auto MUL = [](const fe& x, const fe& y) { return VARIANT == 0 ? fe_mul(x, y) : fe_mul_portable(x, y); };
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     fe a = fe_make(g * 2654435761u + 12345u, g ^ 0x9E3779B9u, g + 77u, 0x12345678u);
     fe b = fe_make(g + 1u, 0xABCDEF01u, g * 3u + 5u, 0x0FEDCBA9u);
     fe c2 = fe_make(0x11111111u + g, 0x22222222u, 0x33333333u, 0x04444444u);
     fe d = fe_make(0x55555555u, 0x66666666u + g, 0x77777777u, 0x08888888u);
     for (uint32_t i = 0; i < iters; i++) {      // four independent dependency chains per lane
-        a = fe_mul(a, b); b = fe_mul(b, c2); c2 = fe_mul(c2, d); d = fe_mul(d, a);
+        a = MUL(a, b); b = MUL(b, c2); c2 = MUL(c2, d); d = MUL(d, a);
     }
     out[g] = fe_add(fe_add(a, b), fe_add(c2, d));
 }
 int k_bench_mulmod(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms) {
+    const bool portable = (iters & 0x80000000u) != 0;     // test hook: top bit selects the portable C formulation
+    iters &= 0x7FFFFFFFu;
     if (lanes * sizeof(fe) > c->scratch_elems * sizeof(fe)) lanes = c->scratch_elems;
     lanes = lanes / PT * PT;
     hipEvent_t e0, e1;
     HIP_TRY(c, hipEventCreate(&e0)); HIP_TRY(c, hipEventCreate(&e1));
-    { KScope ks_(c, "mulmod_bench_kernel", 0.0); hipLaunchKernelGGL(mulmod_bench_kernel, dim3((unsigned)(lanes / PT)), dim3(PT), 0, c->stream, c->scratch, 4u); }   // warm-up
+    { KScope ks_(c, "mulmod_bench_kernel", 0.0); hipLaunchKernelGGL(mulmod_bench_kernel<0>, dim3((unsigned)(lanes / PT)), dim3(PT), 0, c->stream, c->scratch, 4u); }   // warm-up
     HIP_TRY(c, hipEventRecord(e0, c->stream));
-    { KScope ks_(c, "mulmod_bench_kernel", 0.0); hipLaunchKernelGGL(mulmod_bench_kernel, dim3((unsigned)(lanes / PT)), dim3(PT), 0, c->stream, c->scratch, iters); }
+    if (portable) { KScope ks_(c, "mulmod_bench_kernel", 0.0); hipLaunchKernelGGL(mulmod_bench_kernel<1>, dim3((unsigned)(lanes / PT)), dim3(PT), 0, c->stream, c->scratch, iters); }
+    else { KScope ks_(c, "mulmod_bench_kernel", 0.0); hipLaunchKernelGGL(mulmod_bench_kernel<0>, dim3((unsigned)(lanes / PT)), dim3(PT), 0, c->stream, c->scratch, iters); }
     HIP_TRY(c, hipEventRecord(e1, c->stream));
     HIP_TRY(c, hipEventSynchronize(e1));
     float f = 0; HIP_TRY(c, hipEventElapsedTime(&f, e0, e1));
     *ms = f;
     hipEventDestroy(e0); hipEventDestroy(e1);
+    return DST_OK;
+}
+
+// ---- element-wise field operations on caller data (test hook behind dst_field_op) ---------------------------------------------------------
+__global__ void field_op_kernel(int op, const fe* a, const fe* b, fe* out, size_t count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    fe x = a[i], y = b[i], r;
+    switch (op) {
+        case 0: r = fe_add(x, y); break;
+        case 1: r = fe_sub(x, y); break;
+        case 2: r = fe_mul(x, y); break;
+        case 3: r = fe_mul_portable(x, y); break;
+        case 4: r = fe_inv(x); break;
+        case 5: r = fe_pow(x, y); break;
+        default: r = fe_zero();
+    }
+    out[i] = r;
+}
+int k_field_op(dst_ctx* c, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t count) {
+    if (3 * count > c->scratch_elems - 2048) { c->err = "dst_field_op: too many elements"; return DST_ERR_ARG; }
+    fe* da = c->scratch; fe* db = da + count; fe* dout = db + count;
+    HIP_TRY(c, hipMemcpyAsync(da, a, count * 16, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(db, b, count * 16, hipMemcpyHostToDevice, c->stream));
+    { KScope ks_(c, "field_op_kernel", 48.0 * count); hipLaunchKernelGGL(field_op_kernel, dim3((unsigned)((count + PT - 1) / PT)), dim3(PT), 0, c->stream, op, (const fe*)da, (const fe*)db, dout, count); }
+    HIP_TRY(c, hipMemcpyAsync(out, dout, count * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DST_OK;
 }

@@ -21,7 +21,7 @@ BUF = {"polys": 0, "lde": 1, "trace_leaves": 2, "trace_nodes": 3, "ceval_i": 4, 
 EXPORTS = ["dst_ctx_create", "dst_ctx_destroy", "dst_last_error", "dst_phase_ms", "dst_trace_upload", "dst_trace_upload_contiguous",
            "dst_commit_trace", "dst_eval_constraints", "dst_compose", "dst_fri_commit_layer", "dst_fri_fold", "dst_pow_grind",
            "dst_build_proof", "dst_prove", "dst_prng_vector", "dst_query_positions", "dst_blake3", "dst_fibonacci_trace",
-           "dst_read_buffer", "dst_bench_mulmod", "dst_set_profiling", "dst_kernel_stats"]
+           "dst_read_buffer", "dst_bench_mulmod", "dst_set_profiling", "dst_kernel_stats", "dst_field_op"]
 
 
 class DistaffError(RuntimeError):
@@ -230,7 +230,14 @@ class Context:
         self._check(self.lib.dst_kernel_stats(self._h, buf, ctypes.c_size_t(1 << 16), int(reset)))
         return json.loads(buf.value.decode())
 
-    def bench_mulmod(self, lanes=1 << 20, iters=256):
+    def field_op(self, op, a, b):
+        ops = {"add": 0, "sub": 1, "mul": 2, "mul_portable": 3, "inv": 4, "pow": 5}
+        a = np.ascontiguousarray(a, dtype=np.uint64); b = np.ascontiguousarray(b, dtype=np.uint64)
+        out = np.zeros_like(a)
+        self._check(self.lib.dst_field_op(self._h, ops[op], _ptr(a), _ptr(b), _ptr(out), ctypes.c_size_t(a.shape[0])))
+        return out
+
+    def bench_mulmod(self, lanes=1 << 20, iters=256, portable=False):
         ms = ctypes.c_double(0)
-        self._check(self.lib.dst_bench_mulmod(self._h, ctypes.c_uint64(lanes), ctypes.c_uint32(iters), ctypes.byref(ms)))
+        self._check(self.lib.dst_bench_mulmod(self._h, ctypes.c_uint64(lanes), ctypes.c_uint32(iters | (0x80000000 if portable else 0)), ctypes.byref(ms)))
         return ms.value

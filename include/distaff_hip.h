@@ -114,6 +114,8 @@ int dst_read_buffer(dst_ctx* ctx, uint32_t what, uint32_t arg, uint8_t* out, siz
 /* micro-benchmark hook used by bench.py's roofline section: runs `iters` dependent modular multiplications per lane
  * on `lanes` lanes and returns the elapsed milliseconds. */
 int dst_bench_mulmod(dst_ctx* ctx, uint64_t lanes, uint32_t iters, double* ms);
+/* element-wise device field arithmetic on caller data (tests): op 0 add, 1 sub, 2 mul, 3 mul (portable formulation), 4 inv(a), 5 a^b */
+int dst_field_op(dst_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t count);
 /* per-kernel timing: when enabled every kernel launch is bracketed by HIP events on the context's stream;
  * dst_kernel_stats drains them and writes a JSON object {"kernel": {"launches": k, "ms": total, "bytes": algorithmic}, ...}. */
 int dst_set_profiling(dst_ctx* ctx, int enabled);

@@ -166,3 +166,24 @@ def test_wide_rows_two_chunk_leaves(oracle):
     assert ctx.commit_trace() == op.get_bytes("roots")[:32]
     assert ctx.read("trace_leaves").tobytes() == op.get_bytes("trace_leaves")
     ctx.close()
+
+
+def test_device_field_arithmetic(oracle):
+    """fe.h on the device (incl. the gfx950-specific multiplication) against Python big integers, edge cases included."""
+    import random
+    import distaff_amd as D
+    P = oracle.P
+    rnd = random.Random(11)
+    edge = [0, 1, 2, P - 1, P - 2, (P + 1) // 2, 2**64, 2**64 - 1, 2**127, 2**96, P - 2**40, 45 * 2**40 - 1, 45 * 2**40, 2**128 - 2**88, 2**32 - 1, 2**96 - 1]
+    edge = [e % P for e in edge]
+    a = [x for x in edge for _ in edge] + [rnd.randrange(P) for _ in range(60000)] + [P - 1 - rnd.randrange(2**20) for _ in range(4000)]
+    b = [y for _ in edge for y in edge] + [rnd.randrange(P) for _ in range(60000)] + [P - 1 - rnd.randrange(2**70) for _ in range(4000)]
+    A, B = D.ints_to_arr(a), D.ints_to_arr(b)
+    ctx = D.Context(6, 17, 0, 0, log_blowup=4)
+    assert D.arr_to_ints(ctx.field_op("mul", A, B)) == [x * y % P for x, y in zip(a, b)]
+    assert D.arr_to_ints(ctx.field_op("mul_portable", A, B)) == [x * y % P for x, y in zip(a, b)]
+    assert D.arr_to_ints(ctx.field_op("add", A, B)) == [(x + y) % P for x, y in zip(a, b)]
+    assert D.arr_to_ints(ctx.field_op("sub", A, B)) == [(x - y) % P for x, y in zip(a, b)]
+    assert D.arr_to_ints(ctx.field_op("inv", A[:300], B[:300])) == [pow(x, P - 2, P) for x in a[:300]]
+    assert D.arr_to_ints(ctx.field_op("pow", A[:300], B[:300])) == [pow(x, y, P) if x else 0 for x, y in zip(a[:300], b[:300])]
+    ctx.close()
