@@ -70,7 +70,7 @@ static std::vector<fe> build_periodic_table() {
 
 static void free_all(dst_ctx* c) {
     void* ptrs[] = {c->tw_lo, c->tw_hi, c->itw_lo, c->itw_hi, c->w1f, c->w2f, c->w1i, c->w2i, c->prescale, c->periodic, c->trace, c->polys, c->lde, c->tmp,
-                    c->trace_leaves, c->trace_nodes, c->ceval, c->cwork, c->cpoly, c->cevals, c->cnodes, c->comp_poly, c->comp, c->scratch, c->d_u64, c->d_stage};
+                    c->trace_leaves, c->trace_nodes, c->air_consts, c->ceval, c->cwork, c->cpoly, c->cevals, c->cnodes, c->comp_poly, c->comp, c->scratch, c->d_u64, c->d_stage};
     for (void* p : ptrs) if (p) hipFree(p);
     for (int d = 0; d < DST_MAX_FRI_LAYERS; d++) {
         if (d > 0 && c->fri_e[d]) hipFree(c->fri_e[d]);
@@ -141,7 +141,7 @@ static int ctx_init(dst_ctx* c) {
     if ((r = dev_alloc(c, &c->trace_leaves, Nl))) return r;
     if ((r = dev_alloc(c, &c->trace_nodes, Nl))) return r;
     if ((r = dev_alloc(c, &c->ceval, 3 * 8 * n))) return r;
-    if ((r = dev_alloc(c, &c->cwork, 4 * 8 * n))) return r;
+    if ((r = dev_alloc(c, &c->cwork, 8 * 8 * n))) return r;
     if ((r = dev_alloc(c, &c->cpoly, 8 * n))) return r;
     if ((r = dev_alloc(c, &c->cevals, Nl))) return r;
     if ((r = dev_alloc(c, &c->cnodes, Nl / 2))) return r;

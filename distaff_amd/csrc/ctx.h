@@ -68,6 +68,7 @@ struct dst_ctx {
     fe *w1f = nullptr, *w2f = nullptr, *w1i = nullptr, *w2i = nullptr;   // stage twiddles w_{n1}^t, w_{n2}^t and inverses
     fe *prescale = nullptr;                      // w_{B*n1}^t, t < B*n1
     fe *periodic = nullptr;                      // [128][23] extended Rescue round constants + cycle masks
+    void *air_consts = nullptr;                  // AirConsts (Rescue MDS matrices) in device memory
     fe n_inv{}, eight_inv{}, four_inv{}, iota{}, g_trace{}, x_last{};   // 1/n, 1/8, 1/4, w_N^(N/4), w_n, w_n^(n-1)
 
     // data (device)

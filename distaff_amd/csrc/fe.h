@@ -31,7 +31,19 @@ FE_HD fe fe_from_u64(uint64_t x) { return fe_make((uint32_t)x, (uint32_t)(x >> 3
 FE_HD bool fe_is_zero(const fe& a) { return (a.v[0] | a.v[1] | a.v[2] | a.v[3]) == 0; }
 FE_HD bool fe_eq(const fe& a, const fe& b) { return ((a.v[0] ^ b.v[0]) | (a.v[1] ^ b.v[1]) | (a.v[2] ^ b.v[2]) | (a.v[3] ^ b.v[3])) == 0; }
 
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ uint32_t fe_addc(uint32_t a, uint32_t b, uint32_t cin, uint32_t* cout) { return __builtin_addc(a, b, cin, cout); }
+__device__ __forceinline__ uint32_t fe_subb(uint32_t a, uint32_t b, uint32_t bin, uint32_t* bout) { return __builtin_subc(a, b, bin, bout); }
+#endif
+
 FE_HD fe fe_add(const fe& a, const fe& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t c, cs;
+    uint32_t s0 = fe_addc(a.v[0], b.v[0], 0, &c), s1 = fe_addc(a.v[1], b.v[1], c, &c), s2 = fe_addc(a.v[2], b.v[2], c, &c), s3 = fe_addc(a.v[3], b.v[3], c, &cs);
+    uint32_t z0 = fe_addc(s0, FE_C0, 0, &c), z1 = fe_addc(s1, FE_C1, c, &c), z2 = fe_addc(s2, 0, c, &c), z3 = fe_addc(s3, 0, c, &c);
+    bool ov = (cs | c) != 0;
+    return fe_make(ov ? z0 : s0, ov ? z1 : s1, ov ? z2 : s2, ov ? z3 : s3);
+#else
     // s = a + b; t = s + C128; a + b >= p  <=>  a + b + C128 >= 2^128
     uint64_t c = (uint64_t)a.v[0] + b.v[0];               uint32_t s0 = (uint32_t)c;
     c = (uint64_t)a.v[1] + b.v[1] + (c >> 32);            uint32_t s1 = (uint32_t)c;
@@ -44,9 +56,17 @@ FE_HD fe fe_add(const fe& a, const fe& b) {
     d = (uint64_t)s3 + (d >> 32);                         uint32_t t3 = (uint32_t)d;
     bool over = (cs | (uint32_t)(d >> 32)) != 0;
     return over ? fe_make(t0, t1, t2, t3) : fe_make(s0, s1, s2, s3);
+#endif
 }
 
 FE_HD fe fe_sub(const fe& a, const fe& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t bw;
+    uint32_t d0 = fe_subb(a.v[0], b.v[0], 0, &bw), d1 = fe_subb(a.v[1], b.v[1], bw, &bw), d2 = fe_subb(a.v[2], b.v[2], bw, &bw), d3 = fe_subb(a.v[3], b.v[3], bw, &bw);
+    uint32_t m = 0u - bw;                              // all ones when a < b: add p == subtract C128 (mod 2^128)
+    uint32_t e0 = fe_subb(d0, m, 0, &bw), e1 = fe_subb(d1, m & FE_C1, bw, &bw), e2 = fe_subb(d2, 0, bw, &bw), e3 = fe_subb(d3, 0, bw, &bw);
+    return fe_make(e0, e1, e2, e3);
+#else
     // d = a - b; on borrow add p, i.e. subtract C128 modulo 2^128
     int64_t c = (int64_t)(uint64_t)a.v[0] - b.v[0];                 uint32_t d0 = (uint32_t)c;
     c = (int64_t)(uint64_t)a.v[1] - b.v[1] + (c >> 32);             uint32_t d1 = (uint32_t)c;
@@ -58,6 +78,7 @@ FE_HD fe fe_sub(const fe& a, const fe& b) {
     e = (int64_t)(uint64_t)d2 + (e >> 32);                          uint32_t e2 = (uint32_t)e;
     e = (int64_t)(uint64_t)d3 + (e >> 32);                          uint32_t e3 = (uint32_t)e;
     return borrow ? fe_make(e0, e1, e2, e3) : fe_make(d0, d1, d2, d3);
+#endif
 }
 
 FE_HD fe fe_neg(const fe& a) { return fe_sub(fe_zero(), a); }
@@ -140,8 +161,6 @@ FE_HD fe fe_mul_portable(const fe& a, const fe& b) {
 // (E0..E3 at limbs 0,2,4,6 and O0..O2 at limbs 1,3,5), the carry-out of each accumulating mad is counted with one
 // v_addc_co_u32, and the windows are merged with two carry chains.  The reduction multiplies the four high limbs by
 // K = 45*2^8 with independent mads (no carry chain between them) and folds with add/sub-with-carry chains.
-__device__ __forceinline__ uint32_t fe_addc(uint32_t a, uint32_t b, uint32_t cin, uint32_t* cout) { return __builtin_addc(a, b, cin, cout); }
-__device__ __forceinline__ uint32_t fe_subb(uint32_t a, uint32_t b, uint32_t bin, uint32_t* bout) { return __builtin_subc(a, b, bin, bout); }
 __device__ __forceinline__ void fe_mac_c(uint64_t& acc, uint32_t& cnt, uint32_t a, uint32_t b) {
     asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(cnt) : "v"(a), "v"(b) : "vcc");
 }

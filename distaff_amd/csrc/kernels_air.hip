@@ -1,474 +1,20 @@
-// AIR constraint evaluation over the degree-8 sub-domain of the LDE domain, one lane per evaluation point.
-//
-// Replaces the loop at /root/reference/src/stark/prover.rs:53-64: for every i in (0..N).step_by(B/8) it fills `current` =
-// row i and `next` = row (i+B) mod N (trace_state.rs:251-277), derives the op flags (trace_state.rs:281-350), evaluates
-// the boundary combinations (constraints/evaluator.rs:181-326) and the 20 + ctx + loop decoder constraints
-// (constraints/decoder/{mod,op_bits,sponge,flow_ops}.rs) and 2 + stack_depth stack constraints (constraints/stack/*.rs),
-// and folds them into one value per point with the random coefficients in degree-group order
-// (evaluator.rs:335-358,385-406).  Instead of materialising the per-constraint vector the kernel accumulates
-// sum cc[2i]*D and, per degree group, sum cc[2i+1]*D on the fly; x^p factors are table look-ups w_N^(i*p mod N)
-// instead of field::exp.  The reference's quirks are reproduced on purpose: ld flag 2 uses
-// cf bit 1, SWAP aggregates both constraints into slot 0, PUSH/ASSERT flag adjustments.
-//
-// Data access: with the coset-major LDE a point is (coset jl, index k); rows i and i+B are (jl,k) and (jl,k+1 mod n),
-// so a wavefront reads 64 consecutive elements of each register -- unit stride, no halo.
-#include "ctx.h"
+// Launcher of the AIR constraint kernel (air_kernel.h) and its fully generic instance.
+#include "air_kernel.h"
 #include "rescue_constants.h"
 
-#define AIR_THREADS 128
-#ifndef AIR_WAVES_PER_SIMD
-#define AIR_WAVES_PER_SIMD 2      // caps the kernel at 256 registers per lane
-#endif
+void air_launch_generic(dst_ctx* c, const AirArgs& a, uint32_t Q) { launch_air<16, 8, 0, 32, 31, true, true>(c, a, Q); }
 
-struct AirArgs {
-    const fe* lde;               // [W][Bc][n]
-    fe* out;                     // [3][Q][n]  (i, f, t), Q = local constraint cosets
-    const fe* coef;              // 344 raw draws: [0,94) first-step boundary, [94,188) last-step boundary
-    const fe* tc;                // [2][NC] transition coefficients by constraint index: plain then degree-adjusted
-    const fe* periodic;          // [128][23]: 8 sponge ark, 12 hasher ark, 3 masks
-    const fe* tw_lo; const fe* tw_hi; uint32_t lo_bits;
-    unsigned long long* bad_step;
-    size_t n, col_stride;        // col_stride = Bc * n
-    uint32_t log_n, log_N, log_b, W, ctx_depth, loop_depth, stack_depth;
-    uint32_t cl, ll, sl;         // lengths of the ctx / loop / user stack slices: max(depth, 1), max(depth, 1), max(depth, 8) (trace_state.rs:58-60)
-    uint32_t coset_step;         // B / 8: local lde coset of evaluation coset q is q * coset_step (within the local range)
-    uint32_t q0;                 // global index of the first local evaluation coset
-    uint32_t num_inputs, num_outputs;
-    fe inputs[8], outputs[8], program_hash[2], op_count;
-};
-
-__constant__ fe c_sponge_mds[16], c_sponge_inv_mds[16], c_hasher_mds[36], c_hasher_inv_mds[36];
-
-__device__ __forceinline__ fe dpow(const AirArgs& a, uint64_t e) {
-    uint32_t l = (uint32_t)e & ((1u << a.lo_bits) - 1u), h = (uint32_t)(e >> a.lo_bits);
-    fe v = a.tw_lo[l];
-    return h ? fe_mul(v, a.tw_hi[h]) : v;
-}
-
-__device__ __forceinline__ fe bnot(const fe& v) { return fe_sub(fe_one(), v); }
-__device__ __forceinline__ fe is_bin(const fe& v) { return fe_sub(fe_sqr(v), v); }
-
-template <int Wd>
-__device__ __forceinline__ void matmul(fe* s, const fe* m) {
-    fe r[Wd];
-#pragma unroll
-    for (int i = 0; i < Wd; i++) {
-        fe acc = fe_mul(m[i * Wd], s[0]);
-#pragma unroll
-        for (int j = 1; j < Wd; j++) acc = fe_add(acc, fe_mul(m[i * Wd + j], s[j]));
-        r[i] = acc;
-    }
-#pragma unroll
-    for (int i = 0; i < Wd; i++) s[i] = r[i];
-}
-
-// degree-group slots: 2->0 3->1 4->2 6->3 7->4 8->5
-struct Acc {
-    fe res, adj[6];
-    bool nonzero;
-    const fe* tc; uint32_t nc;
-    __device__ __forceinline__ void emit(uint32_t cidx, int slot, const fe& d) {
-        nonzero |= !fe_is_zero(d);
-        res = fe_add(res, fe_mul(d, tc[cidx]));
-        adj[slot] = fe_add(adj[slot], fe_mul(d, tc[nc + cidx]));
-    }
-};
-
-// CL, LL, SL are compile-time capacities (>= the run-time slice lengths a.cl, a.ll, a.sl)
-template <int CL, int LL, int SL>
-__global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(AirArgs a) {
-    const int cl = (int)a.cl, ll = (int)a.ll, sl = (int)a.sl;
-    const size_t k = (size_t)blockIdx.x * AIR_THREADS + threadIdx.x;
-    if (k >= a.n) return;
-    const uint32_t ql = blockIdx.y;                       // local evaluation coset
-    const uint32_t qg = a.q0 + ql;
-    const uint32_t jl = ql * a.coset_step;                // local lde coset
-    const size_t kn = (k + 1 == a.n) ? 0 : k + 1;
-    const fe* cur_p = a.lde + (size_t)jl * a.n + k;
-    const fe* nxt_p = a.lde + (size_t)jl * a.n + kn;
-    const size_t cs = a.col_stride;
-#define CUR(c) cur_p[(size_t)(c) * cs]
-#define NXT(c) nxt_p[(size_t)(c) * cs]
-
-    const uint64_t nmask = ((uint64_t)1 << a.log_N) - 1;
-    const uint64_t gi = ((uint64_t)k << a.log_b) + (uint64_t)qg * a.coset_step;     // index into the LDE domain, x = w_N^gi
-    const uint32_t step = (uint32_t)(((uint64_t)k << 3) + qg);                      // index into the 8n evaluation domain
-    const uint64_t n64 = a.n;
-
-    // ---- rows -------------------------------------------------------------------------------------------------------
-    const fe c_opc = CUR(0), n_opc = NXT(0);
-    fe c_sp[4], n_sp[4], cf[3], ld[5], hd[2], n_cf[3];
-#pragma unroll
-    for (int i = 0; i < 4; i++) { c_sp[i] = CUR(1 + i); n_sp[i] = NXT(1 + i); }
-#pragma unroll
-    for (int i = 0; i < 3; i++) { cf[i] = CUR(5 + i); n_cf[i] = NXT(5 + i); }
-#pragma unroll
-    for (int i = 0; i < 5; i++) ld[i] = CUR(8 + i);
-#pragma unroll
-    for (int i = 0; i < 2; i++) hd[i] = CUR(13 + i);
-    fe c_ctx[CL], n_ctx[CL], c_lp[LL], n_lp[LL], o[SL], nw[SL];
-    {
-        uint32_t col = 15;
-#pragma unroll
-        for (int i = 0; i < CL; i++) { bool on = (uint32_t)i < a.ctx_depth; c_ctx[i] = on ? CUR(col + i) : fe_zero(); n_ctx[i] = on ? NXT(col + i) : fe_zero(); }
-        col += a.ctx_depth;
-#pragma unroll
-        for (int i = 0; i < LL; i++) { bool on = (uint32_t)i < a.loop_depth; c_lp[i] = on ? CUR(col + i) : fe_zero(); n_lp[i] = on ? NXT(col + i) : fe_zero(); }
-        col += a.loop_depth;
-#pragma unroll
-        for (int i = 0; i < SL; i++) { bool on = (uint32_t)i < a.stack_depth; o[i] = on ? CUR(col + i) : fe_zero(); nw[i] = on ? NXT(col + i) : fe_zero(); }
-    }
-
-    // ---- boundary constraints (evaluator.rs:181-326) -----------------------------------------------------------------
-    {
-        const fe xp = dpow(a, (gi * (6 * n64 + 2)) & nmask);            // b_degree_adj = 7n + 1 - (n - 1)
-        const fe one = fe_one();
-#pragma unroll 1
-        for (int pass = 0; pass < 2; pass++) {
-            const fe* cc = a.coef + pass * 94;
-            fe res = fe_zero(), adj = fe_zero();
-            auto term = [&](const fe& v, uint32_t idx) { res = fe_add(res, fe_mul(v, cc[idx])); adj = fe_add(adj, fe_mul(v, cc[idx + 1])); };
-            term(pass ? fe_sub(c_opc, a.op_count) : c_opc, 0);
-            if (pass == 0) { for (int i = 0; i < 4; i++) term(c_sp[i], 2 + 2 * i); }
-            else { for (int i = 0; i < 2; i++) term(fe_sub(c_sp[i], a.program_hash[i]), 2 + 2 * i); }
-            for (int i = 0; i < 3; i++) term(pass ? fe_sub(cf[i], one) : cf[i], 10 + 2 * i);
-            for (int i = 0; i < 5; i++) term(pass ? fe_sub(ld[i], one) : ld[i], 16 + 2 * i);
-            for (int i = 0; i < 2; i++) term(pass ? fe_sub(hd[i], one) : hd[i], 26 + 2 * i);
-            for (int i = 0; i < CL; i++) if (i < cl) term(c_ctx[i], 30 + 2 * i);
-            for (int i = 0; i < LL; i++) if (i < ll) term(c_lp[i], 62 + 2 * i);
-            const uint32_t nio = pass ? a.num_outputs : a.num_inputs;
-#pragma unroll
-            for (int i = 0; i < 8; i++) if ((uint32_t)i < nio) term(fe_sub(o[i], pass ? a.outputs[i] : a.inputs[i]), 78 + 2 * i);
-            res = fe_add(res, fe_mul(adj, xp));
-            a.out[((size_t)pass * gridDim.y + ql) * a.n + k] = res;
-        }
-    }
-
-    // ---- op flags (trace_state.rs:281-350) -----------------------------------------------------------------------------
-    fe cff[8], ldf[32], hdf[4], begin_flag, noop_flag, n_void;
-    {
-        fe n0 = bnot(cf[0]), n1 = bnot(cf[1]), n2 = bnot(cf[2]);
-        fe t0 = fe_mul(n0, n1), t1 = fe_mul(cf[0], n1), t2 = fe_mul(n0, cf[1]), t3 = fe_mul(cf[0], cf[1]);
-        cff[0] = fe_mul(t0, n2); cff[1] = fe_mul(t1, n2); cff[2] = fe_mul(t2, n2); cff[3] = fe_mul(t3, n2);
-        cff[4] = fe_mul(t0, cf[2]); cff[5] = fe_mul(t1, cf[2]); cff[6] = fe_mul(t2, cf[2]); cff[7] = fe_mul(t3, cf[2]);
-        n_void = fe_mul(fe_mul(n_cf[0], n_cf[1]), n_cf[2]);             // next.cf_op_flags()[VOID]
-        fe l0 = bnot(ld[0]), l1 = bnot(ld[1]);
-        ldf[0] = fe_mul(l0, l1); ldf[1] = fe_mul(ld[0], l1);
-        ldf[2] = fe_mul(l0, cf[1]);                                    // sic: cf_op_bits[1] (trace_state.rs:301)
-        ldf[3] = fe_mul(ld[0], ld[1]);
-        fe l2 = bnot(ld[2]);
-#pragma unroll
-        for (int i = 0; i < 4; i++) { ldf[4 + i] = fe_mul(ldf[i], ld[2]); ldf[i] = fe_mul(ldf[i], l2); }
-        fe l3 = bnot(ld[3]);
-#pragma unroll
-        for (int i = 0; i < 8; i++) { ldf[8 + i] = fe_mul(ldf[i], ld[3]); ldf[i] = fe_mul(ldf[i], l3); }
-        fe l4 = bnot(ld[4]);
-#pragma unroll
-        for (int i = 0; i < 16; i++) { ldf[16 + i] = fe_mul(ldf[i], ld[4]); ldf[i] = fe_mul(ldf[i], l4); }
-        fe h0 = bnot(hd[0]), h1 = bnot(hd[1]);
-        hdf[0] = fe_mul(h0, h1); hdf[1] = fe_mul(hd[0], h1); hdf[2] = fe_mul(h0, hd[1]); hdf[3] = fe_mul(hd[0], hd[1]);
-        begin_flag = fe_mul(ldf[0], hdf[0]);
-        noop_flag = fe_mul(ldf[31], hdf[3]);
-        hdf[0] = fe_mul(hdf[0], ld[0]);                                // PUSH (trace_state.rs:343)
-        ldf[0] = fe_mul(ldf[0], hd[0]);                                // ASSERT (trace_state.rs:346)
-    }
-
-    const fe* per = a.periodic + (size_t)(step & 127u) * 23;
-    Acc acc;
-    acc.res = fe_zero(); acc.nonzero = false; acc.tc = a.tc; acc.nc = 20 + cl + ll + 2 + a.stack_depth;
-#pragma unroll
-    for (int i = 0; i < 6; i++) acc.adj[i] = fe_zero();
-
-    // ---- decoder: op bits (decoder/op_bits.rs:10-79) -------------------------------------------------------------------
-    {
-        fe cf_sum = fe_add(fe_add(cf[0], cf[1]), cf[2]);
-        fe ld_prod = fe_mul(fe_mul(fe_mul(ld[0], ld[1]), fe_mul(ld[2], ld[3])), ld[4]);
-        fe hd_prod = fe_mul(hd[0], hd[1]);
-#pragma unroll
-        for (int i = 0; i < 3; i++) acc.emit(i, 0, is_bin(cf[i]));
-#pragma unroll
-        for (int i = 0; i < 5; i++) acc.emit(3 + i, 0, is_bin(ld[i]));
-#pragma unroll
-        for (int i = 0; i < 2; i++) acc.emit(8 + i, 0, is_bin(hd[i]));
-        const fe is_hacc = cff[0];
-        fe hacc_tr = fe_mul(fe_add(c_opc, fe_one()), is_hacc);
-        fe rest_tr = fe_mul(c_opc, bnot(is_hacc));
-        acc.emit(10, 1, fe_sub(fe_add(hacc_tr, rest_tr), n_opc));
-        acc.emit(11, 5, fe_mul(c_opc, fe_mul(bnot(ld_prod), bnot(hd_prod))));
-        acc.emit(12, 5, fe_mul(cf_sum, bnot(fe_mul(ld_prod, hd_prod))));
-        acc.emit(13, 3, fe_mul(cff[7], bnot(n_void)));
-        fe prefix = fe_add(fe_add(cff[1], cff[4]), fe_add(cff[5], cff[6]));          // BEGIN, LOOP, WRAP, BREAK
-        fe v = fe_mul(prefix, per[21]);
-        v = fe_add(v, fe_mul(fe_add(cff[2], cff[3]), per[20]));                      // TEND, FEND
-        v = fe_add(v, fe_mul(hdf[0], per[22]));                                      // PUSH
-        acc.emit(14, 2, v);
-    }
-
-    // ---- decoder: sponge, loop image, context and loop stacks (decoder/sponge.rs, decoder/flow_ops.rs) -----------------------
-    {
-        fe sp[4] = {fe_zero(), fe_zero(), fe_zero(), fe_zero()};
-        // HACC (sponge.rs:10-43)
-        {
-            fe os[4], ns[4];
-#pragma unroll
-            for (int i = 0; i < 4; i++) os[i] = fe_cube(fe_add(c_sp[i], per[i]));
-            matmul<4>(os, c_sponge_mds);
-            fe op_code = ld[0];
-            op_code = fe_add(op_code, fe_double(ld[1]));
-            op_code = fe_add(op_code, fe_mul_small(ld[2], 4));
-            op_code = fe_add(op_code, fe_mul_small(ld[3], 8));
-            op_code = fe_add(op_code, fe_mul_small(ld[4], 16));
-            op_code = fe_add(op_code, fe_mul_small(hd[0], 32));
-            op_code = fe_add(op_code, fe_mul_small(hd[1], 64));
-            os[0] = fe_add(os[0], op_code);
-            os[1] = fe_add(os[1], fe_mul(nw[0], hdf[0]));               // op_value = next.user_stack[0] * push_flag
-#pragma unroll
-            for (int i = 0; i < 4; i++) ns[i] = n_sp[i];
-            matmul<4>(ns, c_sponge_inv_mds);
-#pragma unroll
-            for (int i = 0; i < 4; i++) ns[i] = fe_sub(fe_cube(ns[i]), per[4 + i]);
-#pragma unroll
-            for (int i = 0; i < 4; i++) sp[i] = fe_mul(cff[0], fe_sub(os[i], ns[i]));
-        }
-        const fe f_begin = cff[1], f_tend = cff[2], f_fend = cff[3], f_loop = cff[4], f_wrap = cff[5], f_break = cff[6], f_void = cff[7];
-        // sponge cleared by BEGIN, LOOP, WRAP; copied by BREAK, VOID; TEND / FEND merge hashes
-        {
-            fe clr = fe_add(fe_add(f_begin, f_loop), f_wrap);
-            fe cpy = fe_add(f_break, f_void);
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                sp[i] = fe_add(sp[i], fe_mul(clr, n_sp[i]));
-                sp[i] = fe_add(sp[i], fe_mul(cpy, fe_sub(c_sp[i], n_sp[i])));
-            }
-            fe tf = fe_add(f_tend, f_fend);
-            sp[0] = fe_add(sp[0], fe_mul(tf, fe_sub(c_ctx[0], n_sp[0])));
-            sp[1] = fe_add(sp[1], fe_mul(f_tend, fe_sub(c_sp[0], n_sp[1])));
-            sp[2] = fe_add(sp[2], fe_mul(f_fend, fe_sub(c_sp[0], n_sp[2])));
-            sp[3] = fe_add(sp[3], fe_mul(tf, n_sp[3]));
-        }
-        acc.emit(15, 3, sp[0]); acc.emit(16, 4, sp[1]); acc.emit(17, 3, sp[2]); acc.emit(18, 3, sp[3]);
-        // loop image (WRAP, BREAK)
-        acc.emit(19, 2, fe_mul(fe_add(f_wrap, f_break), fe_sub(c_sp[0], c_lp[0])));
-        // context stack: BEGIN/LOOP push sponge[0]; TEND/FEND pop; WRAP/BREAK/VOID copy
-        {
-            fe push = fe_add(f_begin, f_loop), pop = fe_add(f_tend, f_fend), cpy = fe_add(fe_add(f_wrap, f_break), f_void);
-#pragma unroll
-            for (int i = 0; i < CL; i++) {
-                if (i >= cl) break;
-                fe v = fe_mul(push, fe_sub(i == 0 ? c_sp[0] : c_ctx[i - 1 < 0 ? 0 : i - 1], n_ctx[i]));
-                v = fe_add(v, fe_mul(pop, i + 1 < cl ? fe_sub(c_ctx[i + 1 < CL ? i + 1 : 0], n_ctx[i]) : n_ctx[i]));
-                v = fe_add(v, fe_mul(cpy, fe_sub(c_ctx[i], n_ctx[i])));
-                acc.emit(20 + i, 2, v);
-            }
-        }
-        // loop stack: BEGIN/TEND/FEND/WRAP/VOID copy; LOOP shifts right (slot 0 unconstrained); BREAK pops
-        {
-            fe cpy = fe_add(fe_add(fe_add(f_begin, f_tend), fe_add(f_fend, f_wrap)), f_void);
-#pragma unroll
-            for (int i = 0; i < LL; i++) {
-                if (i >= ll) break;
-                fe v = fe_mul(cpy, fe_sub(c_lp[i], n_lp[i]));
-                if (i >= 1) v = fe_add(v, fe_mul(f_loop, fe_sub(c_lp[i - 1 < 0 ? 0 : i - 1], n_lp[i])));
-                v = fe_add(v, fe_mul(f_break, i + 1 < ll ? fe_sub(c_lp[i + 1 < LL ? i + 1 : 0], n_lp[i]) : n_lp[i]));
-                acc.emit(20 + cl + i, 2, v);
-            }
-        }
-    }
-
-    // ---- stack constraints (constraints/stack/mod.rs:117-195) ---------------------------------------------------------------
-    {
-        fe ev[SL], aux0 = fe_zero(), aux1 = fe_zero();
-#pragma unroll
-        for (int i = 0; i < SL; i++) ev[i] = fe_zero();
-        auto agg = [&](int i, const fe& f, const fe& v) { ev[i] = fe_add(ev[i], fe_mul(f, v)); };
-        auto copy_from = [&](int from, const fe& f) {
-#pragma unroll
-            for (int i = 0; i < SL; i++) if (i >= from && i < sl) agg(i, f, fe_sub(o[i], nw[i]));
-        };
-        auto rshift = [&](int num, const fe& f) {
-#pragma unroll
-            for (int i = 0; i < SL; i++) if (i >= num && i < sl) agg(i, f, fe_sub(o[i - num < 0 ? 0 : i - num], nw[i]));
-        };
-        auto lshift = [&](int from, int num, const fe& f) {
-#pragma unroll
-            for (int i = 0; i < SL; i++) {
-                if (i >= from - num && i < sl - num) agg(i, f, fe_sub(o[i + num < SL ? i + num : 0], nw[i]));
-                else if (i >= sl - num && i < sl) agg(i, f, nw[i]);
-            }
-        };
-        fe f;
-        // flags that only shift / copy are merged before the multiplications
-        // right shift by 1: READ (0x10), DUP (0x12), PUSH (hd 0)
-        f = ldf[0x12]; agg(0, f, fe_sub(nw[0], o[0]));
-        rshift(1, fe_add(fe_add(ldf[0x10], ldf[0x12]), hdf[0]));
-        // right shift by 2: READ2 (0x11), DUP2 (0x13), PAD2 (0x15)
-        f = ldf[0x13]; agg(0, f, fe_sub(nw[0], o[0])); agg(1, f, fe_sub(nw[1], o[1]));
-        f = ldf[0x15]; agg(0, f, nw[0]); agg(1, f, nw[1]);
-        rshift(2, fe_add(fe_add(ldf[0x11], ldf[0x13]), ldf[0x15]));
-        // DUP4 (0x14)
-        f = ldf[0x14];
-#pragma unroll
-        for (int i = 0; i < 4; i++) agg(i, f, fe_sub(nw[i], o[i]));
-        rshift(4, f);
-        // left shift (1,1): ASSERT (0x00), DROP (0x03)
-        lshift(1, 1, fe_add(ldf[0x00], ldf[0x03]));
-        aux0 = fe_add(aux0, fe_mul(ldf[0x00], fe_sub(fe_one(), o[0])));
-        // ASSERTEQ (0x01): left shift (2,2)
-        lshift(2, 2, ldf[0x01]);
-        aux0 = fe_add(aux0, fe_mul(ldf[0x01], fe_sub(o[0], o[1])));
-        // DROP4 (0x04)
-        lshift(4, 4, ldf[0x04]);
-        // SWAP (0x18): both constraints land in slot 0 (manipulation.rs:63-64)
-        f = ldf[0x18]; agg(0, f, fe_sub(nw[0], o[1])); agg(0, f, fe_sub(nw[1], o[0])); copy_from(2, f);
-        // SWAP2 (0x19)
-        f = ldf[0x19]; agg(0, f, fe_sub(nw[0], o[2])); agg(1, f, fe_sub(nw[1], o[3])); agg(2, f, fe_sub(nw[2], o[0])); agg(3, f, fe_sub(nw[3], o[1])); copy_from(4, f);
-        // SWAP4 (0x1A)
-        f = ldf[0x1A];
-#pragma unroll
-        for (int i = 0; i < 4; i++) { agg(i, f, fe_sub(nw[i], o[4 + i])); agg(4 + i, f, fe_sub(nw[4 + i], o[i])); }
-        copy_from(8, f);
-        // ROLL4 (0x1B), ROLL8 (0x1C)
-        f = ldf[0x1B]; agg(0, f, fe_sub(nw[0], o[3]));
-#pragma unroll
-        for (int i = 1; i < 4; i++) agg(i, f, fe_sub(nw[i], o[i - 1]));
-        copy_from(4, f);
-        f = ldf[0x1C]; agg(0, f, fe_sub(nw[0], o[7]));
-#pragma unroll
-        for (int i = 1; i < 8; i++) agg(i, f, fe_sub(nw[i], o[i - 1]));
-        copy_from(8, f);
-        // ADD (0x08), MUL (0x09), AND (0x0A), OR (0x0B): left shift (2,1)
-        {
-            fe xy = fe_mul(o[0], o[1]);
-            agg(0, ldf[0x08], fe_sub(nw[0], fe_add(o[0], o[1])));
-            agg(0, fe_add(ldf[0x09], ldf[0x0A]), fe_sub(nw[0], xy));
-            agg(0, ldf[0x0B], fe_sub(nw[0], bnot(fe_mul(bnot(o[0]), bnot(o[1])))));
-            lshift(2, 1, fe_add(fe_add(ldf[0x08], ldf[0x09]), fe_add(ldf[0x0A], ldf[0x0B])));
-            fe b0 = is_bin(o[0]), b1 = is_bin(o[1]);
-            fe andor = fe_add(ldf[0x0A], ldf[0x0B]);
-            aux0 = fe_add(aux0, fe_mul(fe_add(andor, ldf[0x0E]), b0));            // NOT also checks operand 0
-            aux1 = fe_add(aux1, fe_mul(andor, b1));
-        }
-        // INV (0x0C), NEG (0x0D), NOT (0x0E): copy from 1
-        agg(0, ldf[0x0C], fe_sub(fe_one(), fe_mul(nw[0], o[0])));
-        agg(0, ldf[0x0D], fe_add(nw[0], o[0]));
-        agg(0, ldf[0x0E], fe_sub(nw[0], bnot(o[0])));
-        copy_from(1, fe_add(fe_add(ldf[0x0C], ldf[0x0D]), ldf[0x0E]));
-        // EQ (0x02)
-        {
-            f = ldf[0x02];
-            fe diff = fe_sub(o[1], o[2]);
-            agg(0, f, fe_sub(nw[0], bnot(fe_mul(diff, o[0]))));
-            lshift(3, 2, f);
-            aux0 = fe_add(aux0, fe_mul(f, fe_mul(nw[0], diff)));
-        }
-        // BINACC (0x1D)
-        {
-            f = ldf[0x1D];
-            agg(0, f, is_bin(nw[0])); agg(1, f, nw[1]);
-            agg(2, f, fe_sub(nw[2], fe_double(o[2])));
-            agg(3, f, fe_sub(nw[3], fe_add(o[3], fe_mul(nw[0], o[2]))));
-            copy_from(4, f);
-        }
-        // CHOOSE (0x05), CHOOSE2 (0x06), CSWAP2 (0x07)
-        {
-            f = ldf[0x05];
-            fe c = o[2], nc = bnot(c);
-            agg(0, f, fe_sub(nw[0], fe_add(fe_mul(c, o[0]), fe_mul(nc, o[1]))));
-            lshift(3, 2, f);
-            aux0 = fe_add(aux0, fe_mul(f, is_bin(c)));
-            c = o[4]; nc = bnot(c);
-            fe binc = is_bin(c);
-            f = ldf[0x06];
-            agg(0, f, fe_sub(nw[0], fe_add(fe_mul(c, o[0]), fe_mul(nc, o[2]))));
-            agg(1, f, fe_sub(nw[1], fe_add(fe_mul(c, o[1]), fe_mul(nc, o[3]))));
-            lshift(6, 4, f);
-            aux0 = fe_add(aux0, fe_mul(f, binc));
-            f = ldf[0x07];
-            agg(0, f, fe_sub(nw[0], fe_add(fe_mul(c, o[2]), fe_mul(nc, o[0]))));
-            agg(1, f, fe_sub(nw[1], fe_add(fe_mul(c, o[3]), fe_mul(nc, o[1]))));
-            agg(2, f, fe_sub(nw[2], fe_add(fe_mul(c, o[0]), fe_mul(nc, o[2]))));
-            agg(3, f, fe_sub(nw[3], fe_add(fe_mul(c, o[1]), fe_mul(nc, o[3]))));
-            lshift(6, 2, f);
-            aux0 = fe_add(aux0, fe_mul(f, binc));
-        }
-        // CMP (hd 1) (comparison.rs:64-105)
-        {
-            f = hdf[1];
-            fe x_bit = nw[1], y_bit = nw[2], not_set = nw[3];
-            agg(0, f, is_bin(x_bit)); agg(1, f, is_bin(y_bit));
-            fe bit_gt = fe_mul(x_bit, bnot(y_bit)), bit_lt = fe_mul(y_bit, bnot(x_bit));
-            agg(2, f, fe_sub(nw[4], fe_add(o[4], fe_mul(bit_gt, not_set))));
-            agg(3, f, fe_sub(nw[5], fe_add(o[5], fe_mul(bit_lt, not_set))));
-            agg(4, f, fe_sub(nw[6], fe_add(o[6], fe_mul(y_bit, o[0]))));
-            agg(5, f, fe_sub(nw[7], fe_add(o[7], fe_mul(x_bit, o[0]))));
-            agg(6, f, fe_sub(not_set, fe_mul(bnot(o[5]), bnot(o[4]))));
-            agg(7, f, fe_sub(fe_double(nw[0]), o[0]));
-            copy_from(8, f);
-        }
-        // RESCR (hd 2) (hash.rs:9-35)
-        {
-            f = hdf[2];
-            fe os[6], ns[6];
-#pragma unroll
-            for (int i = 0; i < 6; i++) os[i] = fe_cube(fe_add(o[i], per[8 + i]));
-            matmul<6>(os, c_hasher_mds);
-#pragma unroll
-            for (int i = 0; i < 6; i++) ns[i] = nw[i];
-            matmul<6>(ns, c_hasher_inv_mds);
-#pragma unroll
-            for (int i = 0; i < 6; i++) ns[i] = fe_sub(fe_cube(ns[i]), per[14 + i]);
-#pragma unroll
-            for (int i = 0; i < 6; i++) agg(i, f, fe_sub(ns[i], os[i]));
-            copy_from(6, f);
-        }
-        // BEGIN and NOOP leave the stack untouched
-        copy_from(0, fe_add(begin_flag, noop_flag));
-
-        const uint32_t sbase = 20 + cl + ll;
-        acc.emit(sbase, 4, aux0); acc.emit(sbase + 1, 4, aux1);
-#pragma unroll
-        for (int i = 0; i < SL; i++) if ((uint32_t)i < a.stack_depth) acc.emit(sbase + 2 + i, 4, ev[i]);
-    }
-
-    // ---- combination (evaluator.rs:139-162, 335-358) ---------------------------------------------------------------------------
-    fe t;
-    const bool on_trace = (qg == 0);
-    if (on_trace && k + 1 != a.n) {
-        if (acc.nonzero) atomicMin(a.bad_step, (unsigned long long)k);
-        t = fe_zero();
-    } else {
-        // x^p with p = 8n - 1 - (n - 1) * degree for degrees 2, 3, 4, 6, 7, 8
-        const uint32_t degs[6] = {2, 3, 4, 6, 7, 8};
-        t = acc.res;
-#pragma unroll
-        for (int g = 0; g < 6; g++) {
-            uint64_t p = 8 * n64 - 1 - (n64 - 1) * degs[g];
-            t = fe_add(t, fe_mul(acc.adj[g], dpow(a, (gi * p) & nmask)));
-        }
-    }
-    a.out[((size_t)2 * gridDim.y + ql) * a.n + k] = t;
-#undef CUR
-#undef NXT
-}
-
-template <int CL, int LL, int SL>
-static void launch_air(dst_ctx* c, const AirArgs& a, uint32_t Q) {
-    dim3 g((unsigned)((c->n + AIR_THREADS - 1) / AIR_THREADS), Q);
-    { KScope ks_(c, "air_kernel", 16.0 * c->n * Q * (c->W + 3)); hipLaunchKernelGGL((air_kernel<CL, LL, SL>), g, dim3(AIR_THREADS), 0, c->stream, a); }
-}
-
-static bool g_consts_loaded[64] = {false};
 
 int k_eval_constraints(dst_ctx* c, const fe* coeffs_dev, const fe* tc_dev, int64_t* bad_step) {
-    if (c->device >= 0 && c->device < 64 && !g_consts_loaded[c->device]) {
-        HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(c_sponge_mds), SPONGE_MDS, sizeof(fe) * 16));
-        HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(c_sponge_inv_mds), SPONGE_INV_MDS, sizeof(fe) * 16));
-        HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(c_hasher_mds), HASHER_MDS, sizeof(fe) * 36));
-        HIP_TRY(c, hipMemcpyToSymbol(HIP_SYMBOL(c_hasher_inv_mds), HASHER_INV_MDS, sizeof(fe) * 36));
-        g_consts_loaded[c->device] = true;
+    if (!c->air_consts) {
+        AirConsts h;
+        memcpy(h.sponge_mds, SPONGE_MDS, sizeof(h.sponge_mds)); memcpy(h.sponge_inv_mds, SPONGE_INV_MDS, sizeof(h.sponge_inv_mds));
+        memcpy(h.hasher_mds, HASHER_MDS, sizeof(h.hasher_mds)); memcpy(h.hasher_inv_mds, HASHER_INV_MDS, sizeof(h.hasher_inv_mds));
+        HIP_TRY(c, hipMalloc(&c->air_consts, sizeof(AirConsts)));
+        HIP_TRY(c, hipMemcpy(c->air_consts, &h, sizeof(AirConsts), hipMemcpyHostToDevice));
     }
     AirArgs a{};
-    a.lde = c->lde; a.out = c->ceval; a.coef = coeffs_dev; a.tc = tc_dev; a.periodic = c->periodic;
+    a.lde = c->lde; a.out = c->ceval; a.coef = coeffs_dev; a.tc = tc_dev; a.periodic = c->periodic; a.consts = (const AirConsts*)c->air_consts; a.partial = c->cwork;
     a.tw_lo = c->tw_lo; a.tw_hi = c->tw_hi; a.lo_bits = c->tw_lo_bits;
     a.bad_step = (unsigned long long*)c->d_u64;
     a.n = c->n; a.col_stride = c->Bc * c->n;
@@ -485,8 +31,9 @@ int k_eval_constraints(dst_ctx* c, const fe* coeffs_dev, const fe* tc_dev, int64
     HIP_TRY(c, hipMemcpyAsync(c->d_u64, &init, 8, hipMemcpyHostToDevice, c->stream));
     const uint32_t cd = c->prm.ctx_depth, lp = c->prm.loop_depth, sd = (uint32_t)c->stack_depth;
     a.cl = cd > 1 ? cd : 1; a.ll = lp > 1 ? lp : 1; a.sl = sd > 8 ? sd : 8;
-    if (a.cl <= 2 && a.ll <= 1 && a.sl <= 8) launch_air<2, 1, 8>(c, a, Q);
-    else launch_air<16, 8, 32>(c, a, Q);
+    if (a.cl <= 2 && a.ll <= 1 && sd == 4) air_launch_sd4(c, a, Q);
+    else if (a.cl <= 2 && a.ll <= 1 && sd <= 8) air_launch_small(c, a, Q);
+    else air_launch_generic(c, a, Q);
     unsigned long long res = 0;
     HIP_TRY(c, hipMemcpyAsync(&res, c->d_u64, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
