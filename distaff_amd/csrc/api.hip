@@ -72,6 +72,10 @@ static void free_all(dst_ctx* c) {
     void* ptrs[] = {c->tw_lo, c->tw_hi, c->itw_lo, c->itw_hi, c->w1f, c->w2f, c->w1i, c->w2i, c->prescale, c->periodic, c->trace, c->polys, c->lde, c->tmp,
                     c->trace_leaves, c->trace_nodes, c->air_consts, c->ceval, c->cwork, c->cpoly, c->cevals, c->cnodes, c->comp_poly, c->comp, c->scratch, c->d_u64, c->d_stage};
     for (void* p : ptrs) if (p) hipFree(p);
+    if (c->gather_buf) hipFree(c->gather_buf);
+    if (c->trace_upper) hipFree(c->trace_upper);
+    if (c->c_upper) hipFree(c->c_upper);
+    for (int d = 0; d < DST_MAX_FRI_LAYERS; d++) if (c->fri_upper[d]) hipFree(c->fri_upper[d]);
     for (int d = 0; d < DST_MAX_FRI_LAYERS; d++) {
         if (d > 0 && c->fri_e[d]) hipFree(c->fri_e[d]);
         if (c->fri_leaves[d]) hipFree(c->fri_leaves[d]);
@@ -232,7 +236,7 @@ int dst_commit_trace(dst_ctx* c, uint8_t trace_root[32]) {
 // ---- steps 3-5 ------------------------------------------------------------------------------------------------------------------
 // constraint degrees in constraint-index order (decoder/mod.rs:31-47, stack/mod.rs:40-41) and the coefficient each
 // constraint receives when they are visited in degree-group order (evaluator.rs:335-358,385-406; coefficients.rs:140-185)
-static void transition_coefficients(const dst_ctx* c, const fe* draws344, std::vector<fe>& tc) {
+void dst_internal_transition_coefficients(const dst_ctx* c, const fe* draws344, std::vector<fe>& tc) {
     const size_t cl = c->prm.ctx_depth > 1 ? c->prm.ctx_depth : 1, ll = c->prm.loop_depth > 1 ? c->prm.loop_depth : 1;
     const size_t sl = c->stack_depth > 8 ? c->stack_depth : 8;
     std::vector<int> deg = {2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 8, 8, 6, 4, 6, 7, 6, 6, 4};
@@ -260,7 +264,7 @@ int dst_eval_constraints(dst_ctx* c, const dst_public* pub, const uint8_t* coeff
     c->pub = *pub;
     double t0 = wall_ms();
     std::vector<fe> draws = copy_fe(coeffs, 344), tc;
-    transition_coefficients(c, draws.data(), tc);
+    dst_internal_transition_coefficients(c, draws.data(), tc);
     fe* d_coef = c->scratch + c->scratch_elems - 1024;           // tail of the scratch area
     fe* d_tc = d_coef + 344;
     HIP_TRY(c, hipMemcpyAsync(d_coef, draws.data(), 344 * 16, hipMemcpyHostToDevice, c->stream));

@@ -88,6 +88,9 @@ struct dst_ctx {
     digest *fri_leaves[DST_MAX_FRI_LAYERS] = {nullptr};
     digest *fri_nodes[DST_MAX_FRI_LAYERS] = {nullptr};
     size_t fri_size[DST_MAX_FRI_LAYERS] = {0};       // N_d
+    // coset-sharded mode (world > 1): replicated upper parts of the trees and the gather landing buffer
+    digest *trace_upper = nullptr, *c_upper = nullptr, *fri_upper[DST_MAX_FRI_LAYERS] = {nullptr};
+    uint8_t *gather_buf = nullptr; size_t gather_bytes = 0;
     uint64_t *d_u64 = nullptr;                        // small device scalars (pow result, AIR failure flag)
     uint8_t *d_stage = nullptr;                       // staging buffer for gathers
     size_t stage_bytes = 0;
@@ -164,4 +167,12 @@ int k_pow(dst_ctx* c, const uint8_t seed[32], uint32_t grinding, uint64_t* nonce
 void k_gather(dst_ctx* c, const void* src, size_t item_bytes, const uint64_t* idx_dev, size_t count, void* dst);
 void k_gather_rows(dst_ctx* c, const uint64_t* positions_dev, size_t count, fe* out);
 int k_bench_mulmod(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms);
+// coset-sharded (multi-GPU) helpers
+void k_merkle_local_levels(dst_ctx* c, digest* nodes, size_t count, size_t stop_count);
+void k_merkle_levels_to(dst_ctx* c, const digest* leaves, digest* nodes, size_t num_leaves, size_t stop_count);
+void k_upper_tree(dst_ctx* c, const digest* gathered, digest* upper, size_t nb, uint32_t G);
+void k_constraint_level1(dst_ctx* c);
+void k_fri_leaves_cm(dst_ctx* c, const fe* e, digest* leaves, size_t nd);
+void k_fri_fold_cm(dst_ctx* c, const fe* e, fe* out, size_t nd, int layer, fe special_x);
+void k_copy(dst_ctx* c, void* dst, const void* src, size_t bytes);
 int k_field_op(dst_ctx* c, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t count);

@@ -220,3 +220,63 @@ void k_fri_leaves(dst_ctx* c, int layer) {
     { KScope ks_(c, "fri_leaves_kernel", 96.0 * R); hipLaunchKernelGGL(fri_leaves_kernel, dim3((unsigned)((R + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream,
                        (const fe*)c->fri_e[layer], c->fri_leaves[layer], R); }
 }
+
+// ---- coset-sharded trees (world > 1): a rank owns leaves B*k + j for its cosets j and keeps them as local index k*Bc + jl, so the
+//      lowest log2(Bc) levels of every tree are rank-local.  `k_merkle_levels_to` builds the local heap down to `stop_count`
+//      nodes (one per k); after the all-gather `k_upper_tree` interleaves the ranks' boundary nodes (node G*k + g = gathered[g][k])
+//      and finishes the replicated upper part of the tree. ---------------------------------------------------------------------
+void k_merkle_local_levels(dst_ctx* c, digest* nodes, size_t count, size_t stop_count) {      // nodes[count..2count) valid on entry
+    while (count > stop_count) {
+        size_t cnt = count >> 1;
+        { KScope ks_(c, "merkle_level_kernel", 96.0 * cnt); hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((cnt + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream,
+                           (const digest*)(nodes + count), nodes + cnt, cnt); }
+        count = cnt;
+    }
+}
+void k_merkle_levels_to(dst_ctx* c, const digest* leaves, digest* nodes, size_t num_leaves, size_t stop_count) {
+    size_t cnt = num_leaves >> 1;
+    { KScope ks_(c, "merkle_level_kernel", 96.0 * cnt); hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((cnt + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream,
+                       leaves, nodes + cnt, cnt); }
+    k_merkle_local_levels(c, nodes, cnt, stop_count);
+}
+__global__ void interleave_boundary_kernel(const digest* __restrict__ gathered, digest* __restrict__ out, size_t nb, uint32_t G) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nb * G) return;
+    size_t k = t / G, g = t % G;
+    out[t] = gathered[g * nb + k];
+}
+void k_upper_tree(dst_ctx* c, const digest* gathered, digest* upper, size_t nb, uint32_t G) {
+    size_t count = nb * G;
+    { KScope ks_(c, "interleave_boundary_kernel", 64.0 * count); hipLaunchKernelGGL(interleave_boundary_kernel, dim3((unsigned)((count + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream, gathered, upper + count, nb, G); }
+    merkle_upper_levels(c, upper, count);
+}
+// first node level of the constraint tree only (local), see k_constraint_tree
+void k_constraint_level1(dst_ctx* c) {
+    uint32_t qn = (uint32_t)(c->Bc / 4);
+    uint32_t qt = qn < 32 ? qn : 32u, log_qt = 0;
+    while ((1u << log_qt) < qt) log_qt++;
+    uint32_t KT = HASH_THREADS >> log_qt;
+    size_t level1 = c->Bc * c->n / 4;
+    dim3 g((unsigned)(c->n / KT), (unsigned)(qn >> log_qt));
+    { KScope ks_(c, "constraint_level1_kernel", 96.0 * level1); hipLaunchKernelGGL(constraint_level1_kernel, g, dim3(HASH_THREADS), 0, c->stream, (const fe*)c->cevals, c->cnodes + level1, c->n, (uint32_t)c->Bc, log_qt); }
+}
+// FRI leaves of a coset-major layer e[Bc][nd]: leaf (k, jl), k < nd/4, local index k*Bc + jl
+__global__ void __launch_bounds__(HASH_THREADS) fri_leaves_cm_kernel(const fe* __restrict__ e, digest* __restrict__ leaves, size_t nd, uint32_t Bc) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t q = nd / 4;
+    if (t >= q * Bc) return;
+    size_t jl = t / q, k = t % q;
+    const fe* base = e + jl * nd + k;
+    uint32_t m[16], h[8];
+#pragma unroll
+    for (uint32_t s = 0; s < 4; s++) {
+        fe v = base[(size_t)s * q];
+        m[4 * s] = v.v[0]; m[4 * s + 1] = v.v[1]; m[4 * s + 2] = v.v[2]; m[4 * s + 3] = v.v[3];
+    }
+    b3_hash64(m, h);
+    store_digest(leaves + k * Bc + jl, h);
+}
+void k_fri_leaves_cm(dst_ctx* c, const fe* e, digest* leaves, size_t nd) {
+    size_t total = nd / 4 * c->Bc;
+    { KScope ks_(c, "fri_leaves_cm_kernel", 96.0 * total); hipLaunchKernelGGL(fri_leaves_cm_kernel, dim3((unsigned)((total + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream, e, leaves, nd, (uint32_t)c->Bc); }
+}

@@ -390,3 +390,34 @@ int k_field_op(dst_ctx* c, int op, const uint8_t* a, const uint8_t* b, uint8_t* 
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return DST_OK;
 }
+
+// ---- coset-major FRI fold (sharded mode): e[Bc][nd] -> out[Bc][nd/4]; row r = B*k + j0 + jl of the layer with stride 4^layer ------------
+__global__ void __launch_bounds__(PT) fri_fold_cm_kernel(const fe* __restrict__ e, fe* __restrict__ out, size_t nd, uint32_t Bc, uint32_t log_b, uint32_t j0,
+                                                        uint32_t log_stride, FoldArgs a) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t q = nd / 4;
+    if (t >= q * Bc) return;
+    size_t jl = t / q, k = t % q;
+    const fe* base = e + jl * nd + k;
+    uint64_t r = ((uint64_t)k << log_b) + j0 + jl;
+    out[jl * q + k] = fold_row(a, base[0], base[q], base[2 * q], base[3 * q], r << log_stride);
+}
+void k_fri_fold_cm(dst_ctx* c, const fe* e, fe* out, size_t nd, int layer, fe special_x) {
+    FoldArgs a;
+    a.itw_lo = c->itw_lo; a.itw_hi = c->itw_hi; a.lo_bits = c->tw_lo_bits; a.log_N = c->log_N;
+    a.alpha = special_x; a.iota = c->iota; a.quarter = c->four_inv;
+    size_t total = nd / 4 * c->Bc;
+    { KScope ks_(c, "fri_fold_cm_kernel", 80.0 * total); hipLaunchKernelGGL(fri_fold_cm_kernel, dim3((unsigned)((total + PT - 1) / PT)), dim3(PT), 0, c->stream, e, out, nd, (uint32_t)c->Bc, c->log_b,
+                       (uint32_t)c->j0, (uint32_t)(2 * layer), a); }
+}
+// plain 16-byte-vector copy, used to move shards between this library's buffers and device memory owned by another runtime
+// instance in the same process (e.g. a torch tensor): the GPU sees one address space, the other runtime's API does not know our pointers
+__global__ void copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, size_t vecs) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < vecs; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i];
+}
+void k_copy(dst_ctx* c, void* dst, const void* src, size_t bytes) {
+    size_t vecs = bytes / 16;
+    if (!vecs) return;
+    size_t blocks = (vecs + PT - 1) / PT; if (blocks > 8192) blocks = 8192;
+    { KScope ks_(c, "copy_kernel", 2.0 * bytes); hipLaunchKernelGGL(copy_kernel, dim3((unsigned)blocks), dim3(PT), 0, c->stream, (uint4*)dst, (const uint4*)src, vecs); }
+}

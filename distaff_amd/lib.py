@@ -21,7 +21,9 @@ BUF = {"polys": 0, "lde": 1, "trace_leaves": 2, "trace_nodes": 3, "ceval_i": 4, 
 EXPORTS = ["dst_ctx_create", "dst_ctx_destroy", "dst_last_error", "dst_phase_ms", "dst_trace_upload", "dst_trace_upload_contiguous",
            "dst_commit_trace", "dst_eval_constraints", "dst_compose", "dst_fri_commit_layer", "dst_fri_fold", "dst_pow_grind",
            "dst_build_proof", "dst_prove", "dst_prng_vector", "dst_query_positions", "dst_blake3", "dst_fibonacci_trace",
-           "dst_read_buffer", "dst_bench_mulmod", "dst_set_profiling", "dst_kernel_stats", "dst_field_op"]
+           "dst_read_buffer", "dst_bench_mulmod", "dst_set_profiling", "dst_kernel_stats", "dst_field_op",
+           "dst_shard_commit_trace", "dst_shard_eval_constraints", "dst_shard_combine", "dst_shard_fri_layer", "dst_shard_fri_fold",
+           "dst_shard_export_size", "dst_shard_export", "dst_shard_import", "dst_shard_read", "dst_shard_info"]
 
 
 class DistaffError(RuntimeError):
@@ -44,12 +46,34 @@ class Public(ctypes.Structure):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm ships its own libamdhip64.so (soname libamdhip64.so.7) next to libtorch_hip.so;
+    libdistaff_hip.so needs `libamdhip64.so.7`.  If the ROCm copy under /opt/rocm is loaded first, torch later brings its own copy
+    in as a SECOND runtime, which then finds no devices; loaded the other way round, the dynamic linker resolves our NEEDED entry to
+    torch's copy by soname and both share one runtime (and device pointers can be exchanged directly, which the sharded prover
+    relies on).  So when torch is installed, its copy is loaded first, without importing torch.  Without torch nothing happens and
+    the library binds to /opt/rocm as usual (that is the case for a Rust host binding the C-ABI)."""
+    if os.environ.get("DISTAFF_HIP_RUNTIME", "torch") != "torch":
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+        if spec is None or not spec.submodule_search_locations:
+            return
+        cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+    except OSError:
+        pass
+
+
 def load():
     """Loads the shared library (raises if it has not been built: run ``python -c 'import __graft_entry__ as g; g.build()'``)."""
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError("libdistaff_hip.so is missing (%s): the HIP extension must be built, there is no CPU fallback" % LIB_PATH)
+        _share_hip_runtime_with_torch()
         _lib = ctypes.CDLL(LIB_PATH)
         _lib.dst_last_error.restype = ctypes.c_char_p
         _lib.dst_last_error.argtypes = [ctypes.c_void_p]
@@ -220,6 +244,56 @@ class Context:
 
     def read_elements(self, what, arg=0):
         return self.read(what, arg).view(np.uint64).reshape(-1, 2)
+
+    # ---- coset-sharded phases (world > 1): see distaff_amd/sharded.py ------------------------------------------------
+    def shard_commit_trace(self):
+        self._check(self.lib.dst_shard_commit_trace(self._h))
+
+    def shard_eval_constraints(self, inputs, outputs, coeffs):
+        c = np.ascontiguousarray(coeffs, dtype=np.uint64)
+        bad = ctypes.c_int64(-1)
+        pub = make_public(inputs, outputs)
+        r = self.lib.dst_shard_eval_constraints(self._h, ctypes.byref(pub), _ptr(c), ctypes.byref(bad))
+        if r == DST_ERR_AIR:
+            return bad.value
+        self._check(r)
+        return -1
+
+    def shard_combine(self):
+        self._check(self.lib.dst_shard_combine(self._h))
+
+    def shard_fri_layer(self):
+        more = ctypes.c_int(0)
+        self._check(self.lib.dst_shard_fri_layer(self._h, ctypes.byref(more)))
+        return bool(more.value)
+
+    def fri_fold_shard(self, special_x):
+        self._check(self.lib.dst_shard_fri_fold(self._h, int_to_bytes(special_x)))
+
+    def shard_export_size(self, what, arg=0):
+        n = ctypes.c_size_t(0)
+        self._check(self.lib.dst_shard_export_size(self._h, ctypes.c_uint32(what), ctypes.c_uint32(arg), ctypes.byref(n)))
+        return n.value
+
+    def shard_export(self, what, arg, dst_ptr, is_device):
+        self._check(self.lib.dst_shard_export(self._h, ctypes.c_uint32(what), ctypes.c_uint32(arg), ctypes.c_void_p(dst_ptr), int(is_device)))
+
+    def shard_import(self, what, arg, src_ptr, is_device):
+        root = ctypes.create_string_buffer(32)
+        self._check(self.lib.dst_shard_import(self._h, ctypes.c_uint32(what), ctypes.c_uint32(arg), ctypes.c_void_p(src_ptr), int(is_device), root))
+        return root.raw
+
+    def shard_read(self, buffer, arg, indices):
+        idx = np.asarray(indices, dtype=np.uint64)
+        item = self.W * 16 if buffer == 10 else (16 if buffer in (3, 6) else 32)
+        out = np.zeros(len(indices) * item, dtype=np.uint8)
+        self._check(self.lib.dst_shard_read(self._h, ctypes.c_uint32(buffer), ctypes.c_uint32(arg), _ptr(idx), ctypes.c_uint32(len(indices)), _ptr(out)))
+        return out.tobytes()
+
+    def shard_info(self):
+        op = ctypes.c_uint64(0); layers = ctypes.c_uint32(0); sd = ctypes.c_uint32(0)
+        self._check(self.lib.dst_shard_info(self._h, ctypes.byref(op), ctypes.byref(layers), ctypes.byref(sd)))
+        return op.value, layers.value, sd.value
 
     def set_profiling(self, enabled=True):
         self._check(self.lib.dst_set_profiling(self._h, int(enabled)))

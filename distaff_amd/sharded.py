@@ -1,0 +1,381 @@
+"""Coset-sharded STARK proving on several GPUs: one process (or, for tests, one thread) per GPU, SPMD.
+
+Rank g of G owns the cosets [g*B/G, (g+1)*B/G) of every low-degree extension.  Between the phases of
+``stark::prove`` (/root/reference/src/stark/prover.rs:17-168) the ranks exchange
+  * the boundary nodes of each Merkle tree (the level at which a node's leaves stop being rank-local) -- all-gather,
+  * the combined constraint evaluations before the cross-coset inverse transform -- all-gather,
+  * the handful of leaves / nodes / rows that the query openings need -- small object gathers,
+and every rank derives the same Fiat-Shamir challenges from the same roots.  There is no all-reduce.
+
+The pure index logic (batch-opening plan, ownership of tree nodes, wire format) lives here and is tested on the CPU;
+collectives go through a ``Comm`` object: ``TorchComm`` (torch.distributed: RCCL on GPUs, gloo on CPUs) or ``LocalComm``
+(threads in one process, used to exercise the sharded kernels on a single GPU).
+"""
+import struct
+import threading
+
+import numpy as np
+
+from . import lib as L
+
+SH_TRACE_TREE, SH_CONSTRAINT_TREE, SH_FRI_TREE, SH_CEVAL, SH_FRI_LAST = 0, 1, 2, 3, 4
+RD_TRACE_LEAF, RD_TRACE_NODE, RD_TRACE_UPPER, RD_CEVAL, RD_C_NODE, RD_C_UPPER, RD_FRI_E, RD_FRI_LEAF, RD_FRI_NODE, RD_FRI_UPPER, RD_LDE_ROW = range(11)
+
+
+# ---- pure host logic ---------------------------------------------------------------------------------------------------------
+def plan_batch(indexes, num_leaves):
+    """Which leaves / nodes MerkleTree::prove_batch (src/crypto/merkle.rs:64-124) puts into a batch proof.
+    Returns (values: leaf index per requested position, nodes: per normalised pair a list of (is_leaf, heap_or_leaf_index), depth)."""
+    index_map = {idx: i for i, idx in enumerate(indexes)}
+    assert len(index_map) == len(indexes), "repeating indexes detected"
+    norm = sorted({i - (i & 1) for i in indexes})
+    nodes, nxt = [], []
+    for index in norm:
+        has1, has2 = index in index_map, (index + 1) in index_map
+        if has1 and has2:
+            nodes.append([])
+        elif has1:
+            nodes.append([(True, index + 1)])
+        else:
+            nodes.append([(True, index)])
+        nxt.append((index + num_leaves) >> 1)
+    depth = num_leaves.bit_length() - 1
+    for _ in range(1, depth):
+        cur, nxt = nxt, []
+        i = 0
+        while i < len(cur):
+            sib = cur[i] ^ 1
+            if i + 1 < len(cur) and cur[i + 1] == sib:
+                i += 1
+            else:
+                nodes[i].append((False, sib))
+            nxt.append(sib >> 1)
+            i += 1
+    return list(indexes), nodes, depth
+
+
+def augmented_positions(positions, column_length):          # src/stark/fri/utils.rs:4
+    row_length = column_length // 4
+    out = []
+    for p in positions:
+        ap = p % row_length
+        if ap not in out:
+            out.append(ap)
+    return out
+
+
+def constraint_positions(positions):                         # src/stark/utils/mod.rs:46
+    out = []
+    for p in positions:
+        if p // 2 not in out:
+            out.append(p // 2)
+    return out
+
+
+class TreeGeometry:
+    """A Merkle tree over L = Bt*K natural-order leaves (leaf = Bt*k + j') whose leaf columns j' are split evenly over G ranks.
+    Rank g keeps leaf (k, j') at local index k*Bct + (j' - g*Bct) and the nodes of the lowest log2(Bct) levels in a local heap;
+    levels with 2^l >= Bct are replicated ("upper" heap, same indices as the global heap)."""
+
+    def __init__(self, num_leaves, Bt, G):
+        self.L, self.Bt, self.G = num_leaves, Bt, G
+        self.Bct = Bt // G
+        self.K = num_leaves // Bt
+
+    def leaf(self, i):
+        k, j = divmod(i, self.Bt)
+        g = j // self.Bct
+        return g, k * self.Bct + (j - g * self.Bct)
+
+    def node(self, heap_index):
+        """(rank or None when replicated, local-or-upper heap index)"""
+        level_count = 1 << (heap_index.bit_length() - 1)      # number of nodes on this level
+        t = heap_index - level_count
+        span = self.L // level_count                          # leaves covered by the node
+        if span >= self.Bct:
+            return None, heap_index
+        g, local_leaf = self.leaf(t * span)
+        local_count = self.K * self.Bct // span
+        return g, local_count + local_leaf // span
+
+
+class Writer:
+    """bincode's default encoding as used for StarkProof (src/main.rs:44)."""
+
+    def __init__(self):
+        self.parts = []
+
+    def u8(self, v): self.parts.append(struct.pack("<B", v))
+    def u32(self, v): self.parts.append(struct.pack("<I", v))
+    def u64(self, v): self.parts.append(struct.pack("<Q", v))
+    def raw(self, b): self.parts.append(bytes(b))
+    def bytes(self): return b"".join(self.parts)
+
+
+# ---- communicators -----------------------------------------------------------------------------------------------------------------
+class LocalComm:
+    """All 'ranks' are threads of one process (single-GPU exercise of the sharded path, CPU tests of the logic)."""
+
+    class _Shared:
+        def __init__(self, world):
+            self.world = world
+            self.barrier = threading.Barrier(world)
+            self.slots = [None] * world
+
+    def __init__(self, shared, rank):
+        self.shared, self.rank, self.world = shared, rank, shared.world
+        self.device_path = False
+
+    @classmethod
+    def create(cls, world):
+        shared = cls._Shared(world)
+        return [cls(shared, r) for r in range(world)]
+
+    def all_gather_object(self, obj):
+        s = self.shared
+        s.slots[self.rank] = obj
+        s.barrier.wait()
+        out = list(s.slots)
+        s.barrier.wait()
+        return out
+
+    def all_gather(self, arr):
+        return np.concatenate([np.asarray(a).reshape(-1) for a in self.all_gather_object(np.asarray(arr).copy())])
+
+    def barrier(self):
+        self.shared.barrier.wait()
+
+
+class TorchComm:
+    """torch.distributed communicator.  With the nccl (= RCCL) backend the payload travels GPU-to-GPU over xGMI; shards move
+    between libdistaff_hip.so and the torch tensors either directly on the device (``device_path``) or staged through the host."""
+
+    def __init__(self, dist, device=None, device_path=False):
+        import torch
+        self.torch, self.dist = torch, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.device = device                      # torch.device for collectives (None: CPU / gloo)
+        self.device_path = bool(device_path and device is not None)
+
+    def all_gather_object(self, obj):
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def all_gather(self, arr):
+        t = self.torch.from_numpy(np.ascontiguousarray(arr).view(np.uint8).reshape(-1))
+        if self.device is not None:
+            t = t.to(self.device)
+        out = self.torch.empty(t.numel() * self.world, dtype=self.torch.uint8, device=t.device)
+        self.dist.all_gather_into_tensor(out, t)
+        return out.cpu().numpy()
+
+    def all_gather_device(self, send):
+        """send: uint8 torch tensor on self.device -> gathered tensor (rank-major)"""
+        out = self.torch.empty(send.numel() * self.world, dtype=self.torch.uint8, device=send.device)
+        self.dist.all_gather_into_tensor(out, send)
+        self.torch.cuda.synchronize(send.device)
+        return out
+
+    def barrier(self):
+        self.dist.barrier()
+
+
+# ---- the SPMD prover ---------------------------------------------------------------------------------------------------------------------
+class ShardedProver:
+    def __init__(self, ctx, comm):
+        self.ctx, self.comm = ctx, comm
+        self.G, self.rank = comm.world, comm.rank
+        assert ctx.params.world == self.G and ctx.params.rank == self.rank
+        self.B, self.n, self.N, self.W = ctx.B, ctx.n, ctx.N, ctx.W
+        self.Bc = self.B // self.G
+
+    # -- exchanges
+    def _exchange(self, what, arg=0):
+        ctx, comm = self.ctx, self.comm
+        size = ctx.shard_export_size(what, arg)
+        if getattr(comm, "device_path", False):
+            torch = comm.torch
+            send = torch.empty(size, dtype=torch.uint8, device=comm.device)
+            torch.cuda.synchronize(comm.device)
+            ctx.shard_export(what, arg, send.data_ptr(), True)
+            gathered = comm.all_gather_device(send)
+            root = ctx.shard_import(what, arg, gathered.data_ptr(), True)
+            del send, gathered
+            return root
+        buf = np.empty(size, dtype=np.uint8)
+        ctx.shard_export(what, arg, buf.ctypes.data, False)
+        gathered = np.ascontiguousarray(comm.all_gather(buf))
+        return ctx.shard_import(what, arg, gathered.ctypes.data, False)
+
+    # -- openings
+    def _fetch(self, requests):
+        """requests: list of (owner_rank or None, buffer, arg, local_index); returns the items in order (replicated items from
+        this rank, owned items from their owner)."""
+        mine = [(i, r) for i, r in enumerate(requests) if r[0] == self.rank or (r[0] is None and self.rank == 0)]
+        groups = {}
+        for i, (_, buf, arg, idx) in mine:
+            groups.setdefault((buf, arg), []).append((i, idx))
+        got = {}
+        for (buf, arg), items in groups.items():
+            data = self.ctx.shard_read(buf, arg, [idx for _, idx in items])
+            item = len(data) // len(items)
+            for n_, (i, _) in enumerate(items):
+                got[i] = data[n_ * item:(n_ + 1) * item]
+        merged = {}
+        for part in self.comm.all_gather_object(got):
+            merged.update(part)
+        return [merged[i] for i in range(len(requests))]
+
+    def _tree_requests(self, geom, refs, leaf_buf, node_buf, upper_buf, arg=0):
+        reqs = []
+        for is_leaf, idx in refs:
+            if is_leaf:
+                g, li = geom.leaf(idx)
+                reqs.append((g, leaf_buf, arg, li))
+            else:
+                g, hi = geom.node(idx)
+                reqs.append((g, node_buf if g is not None else upper_buf, arg, hi))
+        return reqs
+
+    def _element_request(self, position, nd):
+        """element at natural position B*k + j of a coset-major [Bc][nd] array"""
+        k, j = divmod(position, self.B)
+        g = j // self.Bc
+        return g, (j - g * self.Bc) * nd + k
+
+    def prove(self, inputs, outputs):
+        """stark::prove across the ranks; every rank returns the same serialised StarkProof."""
+        ctx, comm, G = self.ctx, self.comm, self.G
+        B, n, N, W = self.B, self.n, self.N, self.W
+        p = ctx.params
+        # steps 1-2
+        ctx.shard_commit_trace()
+        trace_root = self._exchange(SH_TRACE_TREE)
+        # steps 3-5
+        coeffs = L.prng_vector(trace_root, 344)
+        bad = ctx.shard_eval_constraints(inputs, outputs, coeffs)
+        bads = [b for b in comm.all_gather_object(bad) if b >= 0]
+        if bads:
+            raise L.DistaffError(L.DST_ERR_AIR, "transition constraints were not satisfied at step %d" % min(bads))
+        self._exchange(SH_CEVAL)
+        ctx.shard_combine()
+        constraint_root = self._exchange(SH_CONSTRAINT_TREE)
+        # step 6
+        draws = L.prng_vector(constraint_root, 516)
+        z1, z2 = ctx.compose(draws)
+        # step 7
+        fri_roots, d = [], 0
+        while True:
+            more = ctx.shard_fri_layer()
+            root = self._exchange(SH_FRI_TREE, d)
+            fri_roots.append(root)
+            if not more:
+                break
+            ctx.fri_fold_shard(L.arr_to_ints(L.prng_vector(root, 1))[0])
+            d += 1
+        layers = len(fri_roots)
+        # step 8
+        seed0 = L.blake3(b"".join(fri_roots))
+        seed1, nonce = ctx.pow_grind(seed0, p.grinding_factor)
+        positions = L.query_positions(seed1, N, B, p.num_queries)
+        # step 9
+        op_count, _, stack_depth = ctx.shard_info()
+        w = Writer()
+        w.raw(trace_root)
+        w.u8(N.bit_length() - 1); w.u8(p.ctx_depth); w.u8(p.loop_depth); w.u8(stack_depth); w.u32(op_count)
+        tgeom = TreeGeometry(N, B, G)
+        _, tnodes, _ = plan_batch(positions, N)
+        flat = [r for lst in tnodes for r in lst]
+        items = self._fetch(self._tree_requests(tgeom, flat, RD_TRACE_LEAF, RD_TRACE_NODE, RD_TRACE_UPPER))
+        self._write_nodes(w, tnodes, items)
+        rows = self._fetch([((pos % B) // self.Bc, RD_LDE_ROW, 0, pos) for pos in positions])
+        w.u64(len(positions))
+        for r in rows:
+            w.u64(W); w.raw(r)
+        w.raw(constraint_root)
+        cpos = constraint_positions(positions)
+        cvals, cnodes, cdepth = plan_batch(cpos, N // 2)
+        cgeom = TreeGeometry(N // 2, B // 2, G)
+
+        def pair_requests(u):
+            return [(g, RD_CEVAL, 0, li) for g, li in (self._element_request(2 * u, n), self._element_request(2 * u + 1, n))]
+        vals = self._fetch([r for u in cvals for r in pair_requests(u)])
+        w.u64(len(cvals)); w.raw(b"".join(vals))
+        flat = [r for lst in cnodes for r in lst]
+        reqs, spans = [], []
+        for is_leaf, idx in flat:
+            if is_leaf:
+                reqs += pair_requests(idx); spans.append(2)
+            else:
+                g, hi = cgeom.node(idx)
+                reqs.append((g, RD_C_NODE if g is not None else RD_C_UPPER, 0, hi)); spans.append(1)
+        got = self._fetch(reqs)
+        items, o = [], 0
+        for s in spans:
+            items.append(b"".join(got[o:o + s])); o += s
+        self._write_nodes(w, cnodes, items)
+        w.u8(cdepth)
+        w.u64(W); w.raw(z1.tobytes())
+        w.u64(W); w.raw(z2.tobytes())
+        # FRI proof
+        w.u64(layers - 1)
+        pos = list(positions)
+        size = N
+        for dd in range(layers - 1):
+            R, nd = size // 4, size // B
+            pos = augmented_positions(pos, size)
+            fvals, fnodes, fdepth = plan_batch(pos, R)
+            w.raw(fri_roots[dd])
+            vals = self._fetch([(g, RD_FRI_E, dd, li) for r in pos for s in range(4) for g, li in (self._element_request(r + s * R, nd),)])
+            w.u64(len(pos)); w.raw(b"".join(vals))
+            fgeom = TreeGeometry(R, B, G)
+            flat = [r for lst in fnodes for r in lst]
+            items = self._fetch(self._tree_requests(fgeom, flat, RD_FRI_LEAF, RD_FRI_NODE, RD_FRI_UPPER, dd))
+            self._write_nodes(w, fnodes, items)
+            w.u8(fdepth)
+            size //= 4
+        w.raw(fri_roots[-1])
+        nl = size // B                                         # remainder: natural order from the ranks' coset-major pieces
+        last = np.empty(ctx.shard_export_size(SH_FRI_LAST, 0), dtype=np.uint8)
+        ctx.shard_export(SH_FRI_LAST, 0, last.ctypes.data, False)
+        pieces = np.asarray(comm.all_gather(last)).view(np.uint64).reshape(G * self.Bc, nl, 2)     # [B][nl]
+        w.u64(size); w.raw(np.ascontiguousarray(pieces.transpose(1, 0, 2)).tobytes())
+        w.u64(nonce)
+        w.u8(p.log_blowup); w.u8(p.num_queries); w.u8(p.grinding_factor); w.u8(0)
+        return w.bytes()
+
+    @staticmethod
+    def _write_nodes(w, node_lists, items):
+        w.u64(len(node_lists))
+        o = 0
+        for lst in node_lists:
+            w.u64(len(lst))
+            for _ in lst:
+                w.raw(items[o]); o += 1
+
+
+def prove_local(columns, log_n, width, ctx_depth, loop_depth, inputs, outputs, world, device=0, **options):
+    """Runs the sharded prover with `world` ranks as threads on ONE device (tests / single-GPU validation of the sharded path)."""
+    comms = LocalComm.create(world)
+    results, errors = [None] * world, [None] * world
+
+    def run(rank):
+        try:
+            ctx = L.Context(log_n, width, ctx_depth, loop_depth, device=device, rank=rank, world=world, **options)
+            ctx.upload(columns)
+            results[rank] = ShardedProver(ctx, comms[rank]).prove(inputs, outputs)
+            ctx.close()
+        except BaseException as e:      # noqa: BLE001 -- surfaced below; break the barrier so the other ranks do not hang
+            errors[rank] = e
+            comms[rank].shared.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    first = next((e for e in errors if e is not None and not isinstance(e, threading.BrokenBarrierError)), None) or next((e for e in errors if e is not None), None)
+    if first is not None:
+        raise first
+    return results

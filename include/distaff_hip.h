@@ -108,6 +108,26 @@ void dst_blake3(const uint8_t* in, size_t len, uint8_t out[32]);                
  * (W = 20, ctx_depth 1, loop_depth 0).  cols = [20][n] elements; outputs the program hash and the result. -------------- */
 int dst_fibonacci_trace(uint32_t log_n, uint8_t* cols, uint8_t program_hash[32], uint8_t result[16]);
 
+/* ---- coset-sharded proving on several GPUs (one context per GPU, params.rank / params.world) ----------
+ * The phases mirror the single-GPU ones; collectives are issued by the host between them.  `what`: 0 trace-tree boundary
+ * nodes, 1 constraint-tree boundary nodes, 2 FRI-tree boundary nodes of layer `arg`, 3 combined constraint evaluations,
+ * 4 last FRI layer (remainder).  dst_shard_import takes the all-gathered items of all ranks (rank-major); for trees it
+ * finishes the replicated upper levels and returns the root.  *_is_device: the pointer is device memory (possibly owned
+ * by another HIP runtime instance in the process, e.g. a torch tensor) instead of host memory. */
+int dst_shard_commit_trace(dst_ctx* ctx);
+int dst_shard_eval_constraints(dst_ctx* ctx, const dst_public* pub, const uint8_t* coeffs /* 344*16 */, int64_t* bad_step);
+int dst_shard_combine(dst_ctx* ctx);
+int dst_shard_fri_layer(dst_ctx* ctx, int* more);
+int dst_shard_fri_fold(dst_ctx* ctx, const uint8_t special_x[16]);
+int dst_shard_export_size(dst_ctx* ctx, uint32_t what, uint32_t arg, size_t* bytes);
+int dst_shard_export(dst_ctx* ctx, uint32_t what, uint32_t arg, void* dst, int dst_is_device);
+int dst_shard_import(dst_ctx* ctx, uint32_t what, uint32_t arg, const void* src, int src_is_device, uint8_t root_out[32]);
+/* openings: `count` items by LOCAL index from buffer 0 trace leaves, 1 trace local nodes, 2 trace upper nodes, 3 constraint
+ * evaluations (elements), 4 constraint local nodes, 5 constraint upper nodes, 6 FRI layer `arg` evaluations (elements), 7 FRI leaves,
+ * 8 FRI local nodes, 9 FRI upper nodes, 10 LDE rows (idx = natural positions owned by this rank, W elements each). */
+int dst_shard_read(dst_ctx* ctx, uint32_t buffer, uint32_t arg, const uint64_t* idx, uint32_t count, uint8_t* out);
+int dst_shard_info(dst_ctx* ctx, uint64_t* op_count, uint32_t* num_fri_layers, uint32_t* stack_depth);
+
 /* ---- inspection (tests and profiling): copies an internal device buffer to the host.  `what` ids are listed in
  * distaff_amd/csrc/ctx.h (DST_BUF_*).  Two-call protocol: out = NULL returns the size through *len. ------------------- */
 int dst_read_buffer(dst_ctx* ctx, uint32_t what, uint32_t arg, uint8_t* out, size_t cap, size_t* len);

@@ -187,3 +187,56 @@ def test_device_field_arithmetic(oracle):
     assert D.arr_to_ints(ctx.field_op("inv", A[:300], B[:300])) == [pow(x, P - 2, P) for x in a[:300]]
     assert D.arr_to_ints(ctx.field_op("pow", A[:300], B[:300])) == [pow(x, y, P) if x else 0 for x, y in zip(a[:300], b[:300])]
     ctx.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_prover_equals_single_gpu(oracle, world):
+    """Coset-sharded proving (distaff_amd/sharded.py) with `world` ranks as threads on one GPU: every rank returns the oracle's proof."""
+    import distaff_amd as D
+    from distaff_amd import sharded
+    O = oracle
+    for log_n, log_b, nq in ((8, 5, 50), (10, 5, 50), (8, 4, 100)):
+        if world > (1 << log_b) // 8:
+            continue
+        t = O.fibonacci_trace(1 << log_n)
+        op = O.Prover.from_trace(t, 1, ext=1 << log_b, num_queries=nq, grinding=10)
+        expected = op.prove()
+        proofs = sharded.prove_local(t.columns, log_n, t.width, t.ctx_depth, t.loop_depth, t.public_inputs, op.outputs, world,
+                                     log_blowup=log_b, num_queries=nq, grinding=10)
+        assert all(p == expected for p in proofs), (world, log_n, log_b)
+
+
+def test_sharded_prover_reports_invalid_trace(oracle):
+    import distaff_amd as D
+    from distaff_amd import sharded
+    t = oracle.fibonacci_trace(256)
+    cols = t.columns.copy()
+    cols[17, 100, 0] += 1
+    with pytest.raises(D.DistaffError):
+        sharded.prove_local(cols, 8, t.width, t.ctx_depth, t.loop_depth, [1, 0], [1], 2, grinding=8)
+
+
+def test_sharded_prover_over_torch_distributed_world1(oracle):
+    """The torch.distributed (RCCL) transport of the sharded prover on one GPU, both shard-transfer modes: staged through the host and
+    directly between libdistaff_hip.so's buffers and torch tensors on the device."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    import distaff_amd as D
+    from distaff_amd import sharded
+    O = oracle
+    t = O.fibonacci_trace(256)
+    op = O.Prover.from_trace(t, 1, grinding=8)
+    expected = op.prove()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        for device_path in (False, True):
+            comm = sharded.TorchComm(dist, torch.device("cuda", 0), device_path=device_path)
+            ctx = D.Context(8, t.width, t.ctx_depth, t.loop_depth, grinding=8)
+            ctx.upload(t.columns)
+            proof = sharded.ShardedProver(ctx, comm).prove(t.public_inputs, op.outputs)
+            assert proof == expected, device_path
+            ctx.close()
+    finally:
+        dist.destroy_process_group()
