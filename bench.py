@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=int(os.environ.get("BENCH_LOG_N", "20")))
     ap.add_argument("--cpu-log-n", type=int, default=int(os.environ.get("BENCH_CPU_LOG_N", "15")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-sharded", action="store_true", help="run the sharded (multi-GPU) code path even with one rank")
     args = ap.parse_args()
 
     import torch
@@ -58,9 +59,12 @@ def main():
         raise SystemExit("bench.py needs a GPU: the HIP prover has no CPU fallback")
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_sharded:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if "MASTER_ADDR" in os.environ:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if dist is not None:
@@ -75,7 +79,7 @@ def main():
     ctx = D.Context(log_n, W_FIB, 1, 0, device=local_rank, rank=rank, world=world)   # default ProofOptions: blowup 32, 50 queries, grinding 20
     ctx.upload(cols)                                                # inputs resident in HBM before the timed region
 
-    if world == 1:
+    if world == 1 and not args.force_sharded:
         def prove():
             return ctx.prove([1, 0], [result])
         transport = "none"
@@ -88,9 +92,7 @@ def main():
             # self-check of the direct hand-off between the library's buffers and torch tensors; fall back to host staging
             ok = True
             try:
-                probe = torch.zeros(1 << 16, dtype=torch.uint8, device=comm.device)
-                ctx.lib.dst_shard_commit_trace(ctx._h)
-                size = min(ctx.shard_export_size(0), probe.numel())
+                ctx.shard_commit_trace()
                 host = np.empty(ctx.shard_export_size(0), dtype=np.uint8)
                 ctx.shard_export(0, 0, host.ctypes.data, False)
                 big = torch.zeros(ctx.shard_export_size(0), dtype=torch.uint8, device=comm.device)
@@ -116,10 +118,14 @@ def main():
     barrier()
     t0 = time.perf_counter()
     phase_sum = [0.0] * 9
+    stage_sum = {}
     for _ in range(args.steps):
         proof = prove()
         for i, v in enumerate(ctx.phase_ms()):
             phase_sum[i] += v
+        if transport != "none":
+            for k, v in prover.stage_ms.items():
+                stage_sum[k] = stage_sum.get(k, 0.0) + v
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -140,19 +146,34 @@ def main():
     # dominant kernel by device time, measured with HIP events on the launch stream inside the timed region
     dom = max(stats.items(), key=lambda kv: kv[1]["ms"]) if stats else (None, None)
     roofline = None
+
+    def pmc_traffic(kernel):
+        """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command (profiles/README.md):
+        FETCH_SIZE doubled (gfx950 correction for wide coalesced reads) + WRITE_SIZE, both converted from KiB."""
+        import csv
+        import glob
+        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_per_kernel.csv")))
+        if not files:
+            return None, None
+        with open(files[-1], newline="") as fh:
+            for row in csv.DictReader(fh):
+                if row["kernel"].replace("void ", "").replace(" ", "").startswith(kernel.replace(" ", "")) and row["fetch_bytes_per_launch_x2"] and row["write_bytes_per_launch_raw"]:
+                    return int(row["fetch_bytes_per_launch_x2"]) + int(row["write_bytes_per_launch_raw"]), os.path.basename(files[-1])
+        return None, None
     if dom[0]:
         name, st = dom
         per_launch_ms = st["ms"] / st["launches"]
         per_launch_bytes = st["bytes"] / st["launches"]
         achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name)[0] if log_n == 20 and world == 1 else None,
+                    "traffic_source": pmc_traffic(name)[1] if log_n == 20 and world == 1 else None,
                     "launches_per_step": st["launches"] / args.steps, "avg_launch_ms": round(per_launch_ms, 4),
                     "algorithmic_bytes_per_launch": per_launch_bytes,
                     "note": "the path is 128-bit modular integer arithmetic on the VALU: see alu_roofline and DESIGN.md"}
     # ALU ceiling: dependent-chain modular multiplications per second measured on this device with the same fe_mul
-    mm_ms = ctx.bench_mulmod(1 << 22, 256)
-    mulmod_peak = (1 << 22) * 256 * 4 / (mm_ms * 1e-3)
+    mm_ms = ctx.bench_mulmod(1 << 21, 512)
+    mulmod_peak = (1 << 21) * 512 * 4 / (mm_ms * 1e-3)
     out = {
         "metric": "trace_cells_per_sec", "value": value, "unit": "trace-cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
@@ -166,6 +187,7 @@ def main():
         "phase_ms": {k: round(v / args.steps, 3) for k, v in zip(
             ["lde", "trace_merkle", "constraint_eval", "combine", "constraint_lde_merkle", "deep_composition", "fri", "pow_queries", "openings"], phase_sum)},
         "proof_bytes": len(proof),
+        "shard_stage_ms_rank0": {k: round(v / args.steps, 3) for k, v in stage_sum.items()} or None,
         "roofline": roofline,
         "alu_roofline": {"unit": "mulmod/s", "peak_measured": mulmod_peak, "kernel": "mulmod_bench_kernel (4 dependent chains per lane)"},
         "kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"] / args.steps, 3), "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}

@@ -86,7 +86,7 @@ static void free_all(dst_ctx* c) {
 
 static int ctx_init(dst_ctx* c) {
     const dst_params& p = c->prm;
-    if (p.log_trace_length < 6 || p.log_trace_length > 26) { c->err = "log_trace_length must be in [6, 26]"; return DST_ERR_ARG; }
+    if (p.log_trace_length < 6 || p.log_trace_length > 24) { c->err = "log_trace_length must be in [6, 24]"; return DST_ERR_ARG; }
     if (p.log_blowup < 4 || p.log_blowup > 8) { c->err = "extension factor must be in [16, 256]"; return DST_ERR_ARG; }
     if (p.ctx_depth > 16 || p.loop_depth > 8) { c->err = "context / loop depth out of range"; return DST_ERR_ARG; }
     if (p.width >= 128 || p.width <= 15 + p.ctx_depth + p.loop_depth) { c->err = "register count out of range"; return DST_ERR_ARG; }
@@ -112,6 +112,20 @@ static int ctx_init(dst_ctx* c) {
     };
     pl.tile_a = tile_for(pl.log_n1, pl.log_n2);
     pl.tile_b = tile_for(pl.log_n2, pl.log_n1);
+    // kernel choice per pass (measured): the LDS radix-2 kernels win while a tile holds >= 2 columns in 64 KiB of LDS; the
+    // register-radix kernels take over for 4096-point tiles.  DISTAFF_NTT=reg|lds forces one family (tests run both).
+    {
+        const bool reg_ok = pl.log_n2 >= 6 && pl.log_n1 <= 12;
+        const char* force = getenv("DISTAFF_NTT");
+        pl.reg_a = reg_ok && false; pl.reg_b = reg_ok && pl.log_n2 >= 12;
+        if (force && !strcmp(force, "reg") && reg_ok) pl.reg_a = pl.reg_b = true;
+        if (force && !strcmp(force, "lds")) pl.reg_a = pl.reg_b = false;
+    }
+    {
+        fe w16 = h_root_of_unity(4), w16i = h_inv(w16);
+        std::vector<fe> f = h_powers(w16, 8), b = h_powers(w16i, 8);
+        for (int j = 0; j < 8; j++) { c->c16f[j] = f[j]; c->c16i[j] = b[j]; }
+    }
 
     // twiddle tables
     fe wN = h_root_of_unity(c->log_N), wN_inv = h_inv(wN);

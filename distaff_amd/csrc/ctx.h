@@ -46,6 +46,7 @@ enum {
 struct NttPlan {
     uint32_t log_n = 0, log_n1 = 0, log_n2 = 0;      // n = n1 * n2, n1 >= n2
     uint32_t tile_a = 1, tile_b = 1;                 // columns per workgroup tile in pass A / pass B
+    bool reg_a = false, reg_b = false;               // per pass: register-radix kernel (tile lengths 2^6 .. 2^12) instead of the LDS radix-2 one
 };
 
 struct dst_ctx {
@@ -69,6 +70,7 @@ struct dst_ctx {
     fe *prescale = nullptr;                      // w_{B*n1}^t, t < B*n1
     fe *periodic = nullptr;                      // [128][23] extended Rescue round constants + cycle masks
     void *air_consts = nullptr;                  // AirConsts (Rescue MDS matrices) in device memory
+    fe c16f[8], c16i[8];                         // w_16^j and w_16^-j, j < 8 (passed to the NTT kernels by value)
     fe n_inv{}, eight_inv{}, four_inv{}, iota{}, g_trace{}, x_last{};   // 1/n, 1/8, 1/4, w_N^(N/4), w_n, w_n^(n-1)
 
     // data (device)

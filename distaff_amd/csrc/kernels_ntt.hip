@@ -12,6 +12,7 @@
 // are B coset transforms of size n (coset j holds the reference's indices B*k + j), stored coset-major.
 // Loads/stores are T*16-byte segments (T = 4: 64 B); the working set of one workgroup is 2^log * T * 16 B of LDS.
 #include "ctx.h"
+#include <type_traits>
 
 #define NTT_THREADS 1024
 
@@ -113,9 +114,224 @@ __global__ void __launch_bounds__(NTT_THREADS) ntt_pass_b(NttArgs a) {
     }
 }
 
-static void launch_two_pass(dst_ctx* c, const fe* src, size_t src_col_stride, size_t src_coset_stride,
-                            fe* dst, size_t dst_col_stride, size_t dst_coset_stride,
-                            size_t cosets, size_t cols, bool inverse, bool lde) {
+// ---- register-radix transform (tile lengths 2^6 .. 2^12) -----------------------------------------------------------------------
+// The same two passes, but every lane keeps 16 points in registers and runs 3-4 butterfly stages on them before the tile is
+// exchanged through LDS, so a 1024-point tile needs two LDS exchanges and two barriers instead of ten.  Mixed-radix
+// Cooley-Tukey over the digits (r1, r2[, r3]) of the tile length L = 2^(r1+r2+r3): with the time index written
+// m = (m1, m2, m3) (m1 most significant) and the frequency k = k1 + R1*k2 + R1*R2*k3,
+//   round i: for fixed other digits, the R_i-point DFT over m_i (radix-2 DIF in registers, roots w_16^j from the kernel
+//            arguments, i.e. scalar registers), then the twiddle w_{L_i}^(k_i * mlow) from the stage table (L_i = remaining
+//            length, mlow = the digits below i); the slot (.., m_i, ..) of the tile now holds (.., k_i, ..).
+// Round 1 reads straight from HBM and the last round writes straight to HBM; lanes run over the T tile columns first, so
+// every HBM access is a T*16-byte segment as before.  LDS slot = digits * T + t with an XOR swizzle that moves the 8-lane
+// groups of the last round (stride R_q*T slots) onto distinct banks.
+template <int LOGL> struct NttDigits;
+template <> struct NttDigits<6>  { static constexpr int r1 = 3, r2 = 3, r3 = 0, log_t = 2; };
+template <> struct NttDigits<7>  { static constexpr int r1 = 4, r2 = 3, r3 = 0, log_t = 2; };
+template <> struct NttDigits<8>  { static constexpr int r1 = 4, r2 = 4, r3 = 0, log_t = 2; };
+template <> struct NttDigits<9>  { static constexpr int r1 = 3, r2 = 3, r3 = 3, log_t = 2; };
+template <> struct NttDigits<10> { static constexpr int r1 = 4, r2 = 3, r3 = 3, log_t = 2; };
+template <> struct NttDigits<11> { static constexpr int r1 = 4, r2 = 4, r3 = 3, log_t = 2; };
+template <> struct NttDigits<12> { static constexpr int r1 = 4, r2 = 4, r3 = 4, log_t = 1; };
+
+struct NttRegArgs {
+    const fe* src; fe* dst;
+    size_t src_col_stride, src_coset_stride, dst_col_stride, dst_coset_stride;
+    size_t in_stride_m, in_stride_t;    // element strides of the time index and of the tile column on input
+    size_t out_stride_k;                // element stride of the frequency index on output (tile columns are contiguous)
+    const fe* stage_tw;                 // w_L^t, t < L/2
+    const fe* tw_lo; const fe* tw_hi;   // two-level table of w_N (pass A four-step twiddle) or nullptr
+    const fe* prescale;                 // w_{B*L}^t or nullptr
+    uint32_t lo_bits, log_N, log_b, j0, coset_twiddle, has_scale;
+    fe scale;
+    fe c16[8];                          // w_16^j (forward or inverse), j < 8
+};
+
+constexpr __host__ __device__ int ntt_brev(int v, int bits) { int r = 0; for (int i = 0; i < bits; i++) r |= ((v >> i) & 1) << (bits - 1 - i); return r; }
+
+// One out-of-line copy of the 128-bit modular multiplication for the register-radix kernels: with every call site inlined a
+// 1024-point kernel is ~190 KB of straight-line code, several times the 64 KB instruction cache a CU pair shares, and the waves
+// stall on instruction fetch; as a call the kernel is a few thousand instructions.
+__device__ __attribute__((noinline)) fe fe_mul_call(fe a, fe b) { return fe_mul(a, b); }
+
+// compile-time loop: the bodies hold fully inlined 128-bit multiplications, far beyond the size the loop unroller accepts, so the
+// unrolling is structural and every register-array index is a constant
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+// radix-2 DIF over x[0 .. 2^r): x[rho] <- X[brev_r(rho)]
+template <int r>
+__device__ __forceinline__ void dft_regs(fe* x, const fe* c16) {
+    constexpr int R = 1 << r;
+    static_for<0, r>([&](auto s_) {
+        constexpr int s = decltype(s_)::value, half = R >> (s + 1);
+        static_for<0, R / 2>([&](auto i_) {
+            constexpr int i = decltype(i_)::value, b = (i / half) * 2 * half, j = i % half;
+            fe u = x[b + j], v = x[b + j + half];
+            x[b + j] = fe_add(u, v);
+            fe d = fe_sub(u, v);
+            if constexpr (j == 0) x[b + j + half] = d;
+            else x[b + j + half] = fe_mul_call(d, c16[(j << s) << (4 - r)]);
+        });
+    });
+}
+
+template <int LOGL>
+__device__ __forceinline__ fe stage_twiddle(const fe* __restrict__ tw, uint32_t e) {
+    constexpr uint32_t H = 1u << (LOGL - 1);
+    fe v = tw[e & (H - 1)];
+    return (e & H) ? fe_neg(v) : v;
+}
+
+template <int LOGL>
+__global__ void __launch_bounds__((1 << (LOGL + NttDigits<LOGL>::log_t)) / 16, (LOGL + NttDigits<LOGL>::log_t >= 13) ? 1 : 2) ntt_reg_kernel(NttRegArgs a) {
+    using D = NttDigits<LOGL>;
+    constexpr int r1 = D::r1, r2 = D::r2, r3 = D::r3, LT = D::log_t, T = 1 << LT;
+    constexpr int rq = r3 ? r3 : r2;                               // last digit
+    constexpr int L = 1 << LOGL, E = 16, NT = L * T / E;
+    constexpr int SWZ_SHIFT = LT + rq, SWZ_MASK = 8 / T - 1;
+    __shared__ fe tile[L * T];
+    auto phys = [](uint32_t s) -> uint32_t { return s ^ (((s >> SWZ_SHIFT) & SWZ_MASK) << LT); };
+    const uint32_t tid = threadIdx.x;
+    const uint32_t jl = blockIdx.y, jg = a.j0 + jl;
+    const fe* src = a.src + (size_t)blockIdx.z * a.src_col_stride + (size_t)jl * a.src_coset_stride + (size_t)blockIdx.x * T * a.in_stride_t;
+    fe* dst = a.dst + (size_t)blockIdx.z * a.dst_col_stride + (size_t)jl * a.dst_coset_stride + (size_t)blockIdx.x * T;
+    fe x[E];
+
+    // ---- round 1: HBM -> registers -> LDS
+    {
+        constexpr int R = 1 << r1, LO = L >> r1, SETS = E / R;
+        static_for<0, E>([&](auto i_) {
+            constexpr int i = decltype(i_)::value, u = i / R, d = i % R;
+            const uint32_t w = tid + NT * u, t = w & (T - 1), p = w >> LT;
+            x[i] = src[(size_t)(d * LO + p) * a.in_stride_m + (size_t)t * a.in_stride_t];
+        });
+        if (a.prescale != nullptr && jg != 0) {
+            const uint32_t pmask = (1u << (a.log_b + LOGL)) - 1u;
+            static_for<0, E>([&](auto i_) {
+                constexpr int i = decltype(i_)::value, u = i / R, d = i % R;
+                const uint32_t p = (tid + NT * u) >> LT;
+                x[i] = fe_mul_call(x[i], a.prescale[(jg * (uint32_t)(d * LO + p)) & pmask]);
+            });
+        }
+        static_for<0, SETS>([&](auto u_) {
+            constexpr int u = decltype(u_)::value;
+            const uint32_t w = tid + NT * u, t = w & (T - 1), p = w >> LT;
+            dft_regs<r1>(x + u * R, a.c16);
+            static_for<0, R>([&](auto rho_) {
+                constexpr int rho = decltype(rho_)::value, k = ntt_brev(rho, r1);
+                fe v = x[u * R + rho];
+                if constexpr (k != 0) v = fe_mul_call(v, stage_twiddle<LOGL>(a.stage_tw, (uint32_t)k * p));
+                tile[phys((((uint32_t)k * LO + p) << LT) + t)] = v;
+            });
+        });
+    }
+    __syncthreads();
+    // ---- round 2 of 3: LDS -> registers -> LDS (slots are owned by one lane, so only the rounds are separated by barriers)
+    if constexpr (r3 != 0) {
+        constexpr int R = 1 << r2, LO = L >> (r1 + r2), SETS = E / R;
+        static_for<0, SETS>([&](auto u_) {
+            constexpr int u = decltype(u_)::value;
+            const uint32_t w = tid + NT * u, t = w & (T - 1), rest = w >> LT, low = rest & (LO - 1), high = rest / LO;
+            const uint32_t base = (high * (R * LO) + low);
+            static_for<0, R>([&](auto d_) {
+                constexpr int d = decltype(d_)::value;
+                x[u * R + d] = tile[phys(((base + d * LO) << LT) + t)];
+            });
+            dft_regs<r2>(x + u * R, a.c16);
+            static_for<0, R>([&](auto rho_) {
+                constexpr int rho = decltype(rho_)::value, k = ntt_brev(rho, r2);
+                fe v = x[u * R + rho];
+                if constexpr (k != 0) v = fe_mul_call(v, stage_twiddle<LOGL>(a.stage_tw, ((uint32_t)k * low) << r1));
+                tile[phys(((base + k * LO) << LT) + t)] = v;
+            });
+        });
+        __syncthreads();
+    }
+    // ---- last round: LDS -> registers -> HBM
+    {
+        constexpr int R = 1 << rq, SETS = E / R;
+        const uint64_t nmask = (1ull << a.log_N) - 1ull;
+        static_for<0, SETS>([&](auto u_) {
+            constexpr int u = decltype(u_)::value;
+            const uint32_t w = tid + NT * u, t = w & (T - 1), high = w >> LT;
+            static_for<0, R>([&](auto d_) {
+                constexpr int d = decltype(d_)::value;
+                x[u * R + d] = tile[phys(((high * R + d) << LT) + t)];
+            });
+            dft_regs<rq>(x + u * R, a.c16);
+            // frequency of the digits above: k1 + R1 * k2 (three rounds: high = k1 * R2 + k2) or k1 (two rounds)
+            const uint32_t klow = r3 ? ((high >> r2) + ((high & ((1u << r2) - 1u)) << r1)) : high;
+            const uint32_t m2 = blockIdx.x * T + t;
+            static_for<0, R>([&](auto rho_) {
+                constexpr int rho = decltype(rho_)::value;
+                const uint32_t k = klow + ((uint32_t)ntt_brev(rho, rq) << (LOGL - rq));
+                fe v = x[u * R + rho];
+                if (a.tw_lo != nullptr) {
+                    uint64_t e = ((uint64_t)m2 * (((uint64_t)k << a.log_b) + (a.coset_twiddle ? jg : 0u))) & nmask;
+                    if (e != 0) {
+                        const uint32_t el = (uint32_t)e & ((1u << a.lo_bits) - 1u), eh = (uint32_t)(e >> a.lo_bits);
+                        v = fe_mul_call(v, a.tw_lo[el]);
+                        if (eh != 0) v = fe_mul_call(v, a.tw_hi[eh]);
+                    }
+                }
+                if (a.has_scale) v = fe_mul_call(v, a.scale);
+                dst[(size_t)k * a.out_stride_k + t] = v;
+            });
+        });
+    }
+}
+
+template <int LOGL>
+static void launch_ntt_reg(dst_ctx* c, const NttRegArgs& a, size_t tiles, size_t cosets, size_t cols, const char* name, double bytes) {
+    constexpr int NT = (1 << (LOGL + NttDigits<LOGL>::log_t)) / 16;
+    dim3 g((unsigned)(tiles >> NttDigits<LOGL>::log_t), (unsigned)cosets, (unsigned)cols);
+    KScope ks_(c, name, bytes);
+    hipLaunchKernelGGL(ntt_reg_kernel<LOGL>, g, dim3(NT), 0, c->stream, a);
+}
+static void dispatch_ntt_reg(dst_ctx* c, uint32_t log_len, const NttRegArgs& a, size_t tiles, size_t cosets, size_t cols, const char* name, double bytes) {
+    switch (log_len) {
+        case 6: launch_ntt_reg<6>(c, a, tiles, cosets, cols, name, bytes); break;
+        case 7: launch_ntt_reg<7>(c, a, tiles, cosets, cols, name, bytes); break;
+        case 8: launch_ntt_reg<8>(c, a, tiles, cosets, cols, name, bytes); break;
+        case 9: launch_ntt_reg<9>(c, a, tiles, cosets, cols, name, bytes); break;
+        case 10: launch_ntt_reg<10>(c, a, tiles, cosets, cols, name, bytes); break;
+        case 11: launch_ntt_reg<11>(c, a, tiles, cosets, cols, name, bytes); break;
+        default: launch_ntt_reg<12>(c, a, tiles, cosets, cols, name, bytes); break;
+    }
+}
+
+static void launch_pass_reg(dst_ctx* c, bool pass_b, const fe* src, size_t src_col_stride, size_t src_coset_stride,
+                            fe* dst, size_t dst_col_stride, size_t dst_coset_stride, size_t cosets, size_t cols, bool inverse, bool lde) {
+    const NttPlan& p = c->plan;
+    const size_t n1 = (size_t)1 << p.log_n1, n2 = (size_t)1 << p.log_n2;
+    NttRegArgs a{};
+    a.log_N = c->log_N; a.log_b = c->log_b; a.lo_bits = c->tw_lo_bits;
+    a.j0 = lde ? (uint32_t)c->j0 : 0u; a.coset_twiddle = lde ? 1u : 0u;
+    for (int j = 0; j < 8; j++) a.c16[j] = inverse ? c->c16i[j] : c->c16f[j];
+    a.src = src; a.src_col_stride = src_col_stride; a.src_coset_stride = src_coset_stride;
+    a.dst = dst; a.dst_col_stride = dst_col_stride; a.dst_coset_stride = dst_coset_stride;
+    a.scale = c->n_inv;
+    if (!pass_b) {      // n1-point transforms over the stride-n2 dimension
+        a.in_stride_m = n2; a.in_stride_t = 1; a.out_stride_k = n2;
+        a.stage_tw = inverse ? c->w1i : c->w1f;
+        a.tw_lo = inverse ? c->itw_lo : c->tw_lo; a.tw_hi = inverse ? c->itw_hi : c->tw_hi;
+        a.prescale = lde ? c->prescale : nullptr;
+        a.has_scale = 0;
+        dispatch_ntt_reg(c, p.log_n1, a, n2, cosets, cols, "ntt_pass_a", 16.0 * c->n * cols * (lde ? (1 + cosets) : 2 * cosets));
+    } else {            // n2-point transforms over the contiguous dimension, natural-order output
+        a.in_stride_m = 1; a.in_stride_t = n2; a.out_stride_k = n1;
+        a.stage_tw = inverse ? c->w2i : c->w2f;
+        a.tw_lo = nullptr; a.tw_hi = nullptr; a.prescale = nullptr;
+        a.has_scale = inverse ? 1u : 0u;
+        dispatch_ntt_reg(c, p.log_n2, a, n1, cosets, cols, "ntt_pass_b", 32.0 * c->n * cols * cosets);
+    }
+}
+
+static void launch_pass_lds(dst_ctx* c, bool pass_b, const fe* src, size_t src_col_stride, size_t src_coset_stride,
+                            fe* dst, size_t dst_col_stride, size_t dst_coset_stride, size_t cosets, size_t cols, bool inverse, bool lde) {
     const NttPlan& p = c->plan;
     NttArgs a{};
     a.log_n1 = p.log_n1; a.log_n2 = p.log_n2; a.log_N = c->log_N; a.log_b = c->log_b; a.lo_bits = c->tw_lo_bits;
@@ -124,20 +340,29 @@ static void launch_two_pass(dst_ctx* c, const fe* src, size_t src_col_stride, si
     a.tw_hi = inverse ? c->itw_hi : c->tw_hi;
     a.prescale = lde ? c->prescale : nullptr;
     a.has_scale = inverse ? 1u : 0u; a.scale = c->n_inv;
-    // pass A: src -> tmp
     a.src = src; a.src_col_stride = src_col_stride; a.src_coset_stride = src_coset_stride;
-    a.dst = c->tmp; a.dst_coset_stride = c->n; a.dst_col_stride = c->n * cosets;
-    a.stage_tw = inverse ? c->w1i : c->w1f; a.tile = (uint32_t)__builtin_ctz(p.tile_a);
-    size_t lds_a = ((size_t)1 << p.log_n1) * p.tile_a * sizeof(fe);
-    dim3 ga((unsigned)((1u << p.log_n2) / p.tile_a), (unsigned)cosets, (unsigned)cols);
-    { KScope ks_(c, "ntt_pass_a", 16.0 * c->n * cols * (lde ? (1 + cosets) : 2 * cosets)); hipLaunchKernelGGL(ntt_pass_a, ga, dim3(NTT_THREADS), lds_a, c->stream, a); }
-    // pass B: tmp -> dst
-    a.src = c->tmp; a.src_coset_stride = c->n; a.src_col_stride = c->n * cosets;
     a.dst = dst; a.dst_col_stride = dst_col_stride; a.dst_coset_stride = dst_coset_stride;
-    a.stage_tw = inverse ? c->w2i : c->w2f; a.tile = (uint32_t)__builtin_ctz(p.tile_b);
-    size_t lds_b = ((size_t)1 << p.log_n2) * p.tile_b * sizeof(fe);
-    dim3 gb((unsigned)((1u << p.log_n1) / p.tile_b), (unsigned)cosets, (unsigned)cols);
-    { KScope ks_(c, "ntt_pass_b", 32.0 * c->n * cols * cosets); hipLaunchKernelGGL(ntt_pass_b, gb, dim3(NTT_THREADS), lds_b, c->stream, a); }
+    if (!pass_b) {
+        a.stage_tw = inverse ? c->w1i : c->w1f; a.tile = (uint32_t)__builtin_ctz(p.tile_a);
+        size_t lds_a = ((size_t)1 << p.log_n1) * p.tile_a * sizeof(fe);
+        dim3 ga((unsigned)((1u << p.log_n2) / p.tile_a), (unsigned)cosets, (unsigned)cols);
+        KScope ks_(c, "ntt_pass_a", 16.0 * c->n * cols * (lde ? (1 + cosets) : 2 * cosets));
+        hipLaunchKernelGGL(ntt_pass_a, ga, dim3(NTT_THREADS), lds_a, c->stream, a);
+    } else {
+        a.stage_tw = inverse ? c->w2i : c->w2f; a.tile = (uint32_t)__builtin_ctz(p.tile_b);
+        size_t lds_b = ((size_t)1 << p.log_n2) * p.tile_b * sizeof(fe);
+        dim3 gb((unsigned)((1u << p.log_n1) / p.tile_b), (unsigned)cosets, (unsigned)cols);
+        KScope ks_(c, "ntt_pass_b", 32.0 * c->n * cols * cosets);
+        hipLaunchKernelGGL(ntt_pass_b, gb, dim3(NTT_THREADS), lds_b, c->stream, a);
+    }
+}
+
+static void launch_two_pass(dst_ctx* c, const fe* src, size_t src_col_stride, size_t src_coset_stride,
+                            fe* dst, size_t dst_col_stride, size_t dst_coset_stride,
+                            size_t cosets, size_t cols, bool inverse, bool lde) {
+    // pass A: src -> tmp, pass B: tmp -> dst
+    (c->plan.reg_a ? launch_pass_reg : launch_pass_lds)(c, false, src, src_col_stride, src_coset_stride, c->tmp, c->n * cosets, c->n, cosets, cols, inverse, lde);
+    (c->plan.reg_b ? launch_pass_reg : launch_pass_lds)(c, true, c->tmp, c->n * cosets, c->n, dst, dst_col_stride, dst_coset_stride, cosets, cols, inverse, lde);
 }
 
 // how many (coset x column) size-n arrays fit in c->tmp

@@ -348,7 +348,7 @@ __global__ void __launch_bounds__(PT) mulmod_bench_kernel(fe* out, uint32_t iter
 int k_bench_mulmod(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms) {
     const bool portable = (iters & 0x80000000u) != 0;     // test hook: top bit selects the portable C formulation
     iters &= 0x7FFFFFFFu;
-    if (lanes * sizeof(fe) > c->scratch_elems * sizeof(fe)) lanes = c->scratch_elems;
+    if (lanes > c->scratch_elems || lanes < PT) { c->err = "dst_bench_mulmod: lanes must be in [256, 2^21]"; return DST_ERR_ARG; }
     lanes = lanes / PT * PT;
     hipEvent_t e0, e1;
     HIP_TRY(c, hipEventCreate(&e0)); HIP_TRY(c, hipEventCreate(&e1));

@@ -13,6 +13,7 @@ collectives go through a ``Comm`` object: ``TorchComm`` (torch.distributed: RCCL
 """
 import struct
 import threading
+import time
 
 import numpy as np
 
@@ -190,6 +191,11 @@ class ShardedProver:
         self.B, self.n, self.N, self.W = ctx.B, ctx.n, ctx.N, ctx.W
         self.Bc = self.B // self.G
 
+    def _mark(self, name):
+        now = time.perf_counter()
+        self.stage_ms[name] = self.stage_ms.get(name, 0.0) + (now - self._t) * 1e3
+        self._t = now
+
     # -- exchanges
     def _exchange(self, what, arg=0):
         ctx, comm = self.ctx, self.comm
@@ -197,7 +203,6 @@ class ShardedProver:
         if getattr(comm, "device_path", False):
             torch = comm.torch
             send = torch.empty(size, dtype=torch.uint8, device=comm.device)
-            torch.cuda.synchronize(comm.device)
             ctx.shard_export(what, arg, send.data_ptr(), True)
             gathered = comm.all_gather_device(send)
             root = ctx.shard_import(what, arg, gathered.data_ptr(), True)
@@ -209,9 +214,9 @@ class ShardedProver:
         return ctx.shard_import(what, arg, gathered.ctypes.data, False)
 
     # -- openings
-    def _fetch(self, requests):
+    def _fetch(self, requests, extra=None):
         """requests: list of (owner_rank or None, buffer, arg, local_index); returns the items in order (replicated items from
-        this rank, owned items from their owner)."""
+        rank 0, owned items from their owner) and the list of every rank's `extra` object.  ONE object all-gather."""
         mine = [(i, r) for i, r in enumerate(requests) if r[0] == self.rank or (r[0] is None and self.rank == 0)]
         groups = {}
         for i, (_, buf, arg, idx) in mine:
@@ -222,10 +227,11 @@ class ShardedProver:
             item = len(data) // len(items)
             for n_, (i, _) in enumerate(items):
                 got[i] = data[n_ * item:(n_ + 1) * item]
-        merged = {}
-        for part in self.comm.all_gather_object(got):
+        merged, extras = {}, []
+        for part, ex in self.comm.all_gather_object((got, extra)):
             merged.update(part)
-        return [merged[i] for i in range(len(requests))]
+            extras.append(ex)
+        return [merged[i] for i in range(len(requests))], extras
 
     def _tree_requests(self, geom, refs, leaf_buf, node_buf, upper_buf, arg=0):
         reqs = []
@@ -249,21 +255,29 @@ class ShardedProver:
         ctx, comm, G = self.ctx, self.comm, self.G
         B, n, N, W = self.B, self.n, self.N, self.W
         p = ctx.params
+        self.stage_ms, self._t = {}, time.perf_counter()
         # steps 1-2
         ctx.shard_commit_trace()
+        self._mark("lde_trace_leaves")
         trace_root = self._exchange(SH_TRACE_TREE)
+        self._mark("trace_tree_exchange")
         # steps 3-5
         coeffs = L.prng_vector(trace_root, 344)
         bad = ctx.shard_eval_constraints(inputs, outputs, coeffs)
-        bads = [b for b in comm.all_gather_object(bad) if b >= 0]
+        self._mark("constraint_eval")
+        bads = [int(b) for b in comm.all_gather(np.array([bad], dtype=np.int64)).view(np.int64) if b >= 0]
         if bads:
             raise L.DistaffError(L.DST_ERR_AIR, "transition constraints were not satisfied at step %d" % min(bads))
         self._exchange(SH_CEVAL)
+        self._mark("ceval_exchange")
         ctx.shard_combine()
+        self._mark("combine_constraint_lde")
         constraint_root = self._exchange(SH_CONSTRAINT_TREE)
+        self._mark("constraint_tree_exchange")
         # step 6
         draws = L.prng_vector(constraint_root, 516)
         z1, z2 = ctx.compose(draws)
+        self._mark("deep_composition")
         # step 7
         fri_roots, d = [], 0
         while True:
@@ -275,74 +289,87 @@ class ShardedProver:
             ctx.fri_fold_shard(L.arr_to_ints(L.prng_vector(root, 1))[0])
             d += 1
         layers = len(fri_roots)
+        self._mark("fri")
         # step 8
         seed0 = L.blake3(b"".join(fri_roots))
         seed1, nonce = ctx.pow_grind(seed0, p.grinding_factor)
         positions = L.query_positions(seed1, N, B, p.num_queries)
-        # step 9
+        self._mark("pow_queries")
+        # step 9: every opening of the proof is requested in ONE batch (the positions are all known by now), then serialised
         op_count, _, stack_depth = ctx.shard_info()
-        w = Writer()
-        w.raw(trace_root)
-        w.u8(N.bit_length() - 1); w.u8(p.ctx_depth); w.u8(p.loop_depth); w.u8(stack_depth); w.u32(op_count)
-        tgeom = TreeGeometry(N, B, G)
-        _, tnodes, _ = plan_batch(positions, N)
-        flat = [r for lst in tnodes for r in lst]
-        items = self._fetch(self._tree_requests(tgeom, flat, RD_TRACE_LEAF, RD_TRACE_NODE, RD_TRACE_UPPER))
-        self._write_nodes(w, tnodes, items)
-        rows = self._fetch([((pos % B) // self.Bc, RD_LDE_ROW, 0, pos) for pos in positions])
-        w.u64(len(positions))
-        for r in rows:
-            w.u64(W); w.raw(r)
-        w.raw(constraint_root)
-        cpos = constraint_positions(positions)
-        cvals, cnodes, cdepth = plan_batch(cpos, N // 2)
-        cgeom = TreeGeometry(N // 2, B // 2, G)
+        reqs = []
+
+        def ask(lst):
+            o = len(reqs)
+            reqs.extend(lst)
+            return o, len(lst)
 
         def pair_requests(u):
             return [(g, RD_CEVAL, 0, li) for g, li in (self._element_request(2 * u, n), self._element_request(2 * u + 1, n))]
-        vals = self._fetch([r for u in cvals for r in pair_requests(u)])
-        w.u64(len(cvals)); w.raw(b"".join(vals))
-        flat = [r for lst in cnodes for r in lst]
-        reqs, spans = [], []
-        for is_leaf, idx in flat:
+
+        tgeom = TreeGeometry(N, B, G)
+        _, tnodes, _ = plan_batch(positions, N)
+        h_tnodes = ask(self._tree_requests(tgeom, [r for lst in tnodes for r in lst], RD_TRACE_LEAF, RD_TRACE_NODE, RD_TRACE_UPPER))
+        h_rows = ask([((pos % B) // self.Bc, RD_LDE_ROW, 0, pos) for pos in positions])
+        cpos = constraint_positions(positions)
+        cvals, cnodes, cdepth = plan_batch(cpos, N // 2)
+        cgeom = TreeGeometry(N // 2, B // 2, G)
+        h_cvals = ask([r for u in cvals for r in pair_requests(u)])
+        creqs, spans = [], []
+        for is_leaf, idx in (r for lst in cnodes for r in lst):
             if is_leaf:
-                reqs += pair_requests(idx); spans.append(2)
+                creqs += pair_requests(idx); spans.append(2)
             else:
                 g, hi = cgeom.node(idx)
-                reqs.append((g, RD_C_NODE if g is not None else RD_C_UPPER, 0, hi)); spans.append(1)
-        got = self._fetch(reqs)
-        items, o = [], 0
-        for s in spans:
-            items.append(b"".join(got[o:o + s])); o += s
+                creqs.append((g, RD_C_NODE if g is not None else RD_C_UPPER, 0, hi)); spans.append(1)
+        h_cnodes = ask(creqs)
+        fri_plan, pos, size = [], list(positions), N
+        for dd in range(layers - 1):
+            R, nd = size // 4, size // B
+            pos = augmented_positions(pos, size)
+            fvals, fnodes, fdepth = plan_batch(pos, R)
+            h_vals = ask([(g, RD_FRI_E, dd, li) for r in pos for s in range(4) for g, li in (self._element_request(r + s * R, nd),)])
+            fgeom = TreeGeometry(R, B, G)
+            h_nodes = ask(self._tree_requests(fgeom, [r for lst in fnodes for r in lst], RD_FRI_LEAF, RD_FRI_NODE, RD_FRI_UPPER, dd))
+            fri_plan.append((len(pos), h_vals, fnodes, h_nodes, fdepth))
+            size //= 4
+        last = np.empty(ctx.shard_export_size(SH_FRI_LAST, 0), dtype=np.uint8)     # this rank's cosets of the remainder
+        ctx.shard_export(SH_FRI_LAST, 0, last.ctypes.data, False)
+        got, lasts = self._fetch(reqs, last.tobytes())
+
+        def take(h):
+            return got[h[0]:h[0] + h[1]]
+
+        w = Writer()
+        w.raw(trace_root)
+        w.u8(N.bit_length() - 1); w.u8(p.ctx_depth); w.u8(p.loop_depth); w.u8(stack_depth); w.u32(op_count)
+        self._write_nodes(w, tnodes, take(h_tnodes))
+        w.u64(len(positions))
+        for r in take(h_rows):
+            w.u64(W); w.raw(r)
+        w.raw(constraint_root)
+        w.u64(len(cvals)); w.raw(b"".join(take(h_cvals)))
+        part, items, o = take(h_cnodes), [], 0
+        for sp in spans:
+            items.append(b"".join(part[o:o + sp])); o += sp
         self._write_nodes(w, cnodes, items)
         w.u8(cdepth)
         w.u64(W); w.raw(z1.tobytes())
         w.u64(W); w.raw(z2.tobytes())
         # FRI proof
         w.u64(layers - 1)
-        pos = list(positions)
-        size = N
-        for dd in range(layers - 1):
-            R, nd = size // 4, size // B
-            pos = augmented_positions(pos, size)
-            fvals, fnodes, fdepth = plan_batch(pos, R)
+        for dd, (count, h_vals, fnodes, h_nodes, fdepth) in enumerate(fri_plan):
             w.raw(fri_roots[dd])
-            vals = self._fetch([(g, RD_FRI_E, dd, li) for r in pos for s in range(4) for g, li in (self._element_request(r + s * R, nd),)])
-            w.u64(len(pos)); w.raw(b"".join(vals))
-            fgeom = TreeGeometry(R, B, G)
-            flat = [r for lst in fnodes for r in lst]
-            items = self._fetch(self._tree_requests(fgeom, flat, RD_FRI_LEAF, RD_FRI_NODE, RD_FRI_UPPER, dd))
-            self._write_nodes(w, fnodes, items)
+            w.u64(count); w.raw(b"".join(take(h_vals)))
+            self._write_nodes(w, fnodes, take(h_nodes))
             w.u8(fdepth)
-            size //= 4
         w.raw(fri_roots[-1])
         nl = size // B                                         # remainder: natural order from the ranks' coset-major pieces
-        last = np.empty(ctx.shard_export_size(SH_FRI_LAST, 0), dtype=np.uint8)
-        ctx.shard_export(SH_FRI_LAST, 0, last.ctypes.data, False)
-        pieces = np.asarray(comm.all_gather(last)).view(np.uint64).reshape(G * self.Bc, nl, 2)     # [B][nl]
+        pieces = np.frombuffer(b"".join(lasts), dtype=np.uint64).reshape(G * self.Bc, nl, 2)       # [B][nl]
         w.u64(size); w.raw(np.ascontiguousarray(pieces.transpose(1, 0, 2)).tobytes())
         w.u64(nonce)
         w.u8(p.log_blowup); w.u8(p.num_queries); w.u8(p.grinding_factor); w.u8(0)
+        self._mark("openings")
         return w.bytes()
 
     @staticmethod

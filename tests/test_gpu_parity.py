@@ -240,3 +240,43 @@ def test_sharded_prover_over_torch_distributed_world1(oracle):
             ctx.close()
     finally:
         dist.destroy_process_group()
+
+
+def _random_columns(W, n, seed):
+    rng = np.random.default_rng(seed)
+    cols = rng.integers(0, 2**63, size=(W, n, 2), dtype=np.uint64)      # high limb < 2^63: always below the modulus
+    return cols
+
+
+@pytest.mark.parametrize("family,log_n,log_blowup", [("reg", 13, 5), ("reg", 14, 5), ("reg", 15, 4), ("reg", 16, 5), ("reg", 17, 4), ("reg", 18, 4),
+                                                      ("reg", 19, 4), ("reg", 20, 4), ("reg", 21, 4), ("reg", 22, 4), ("reg", 23, 4), ("reg", 24, 4),
+                                                      ("lds", 13, 5), ("lds", 16, 5), ("lds", 19, 4), ("lds", 22, 4), ("auto", 24, 4)])
+def test_lde_every_tile_length(oracle, monkeypatch, family, log_n, log_blowup):
+    """Both NTT kernel families (register-radix: every tile length 2^6 .. 2^12 in both passes; LDS radix-2) and the default per-pass
+    choice at the largest size, through size-independent properties that pin the
+    transforms point-wise: the interpolated polynomial evaluated by the oracle (Horner) at trace-domain points gives the trace, and at
+    LDE-domain points gives the device's extension -- including the largest trace length (BASELINE config 5: 2^24, blowup 16)."""
+    import distaff_amd as D
+    O = oracle
+    n, B, W = 1 << log_n, 1 << log_blowup, 16
+    cols = _random_columns(W, n, 1000 + log_n)
+    if family == "auto":
+        monkeypatch.delenv("DISTAFF_NTT", raising=False)
+    else:
+        monkeypatch.setenv("DISTAFF_NTT", family)                       # read by dst_ctx_create
+    ctx = D.Context(log_n, W, 0, 0, log_blowup=log_blowup)
+    ctx.upload(cols)
+    ctx.commit_trace()
+    c = 5
+    poly = ctx.read_elements("polys").reshape(W, n, 2)[c]
+    lde = ctx.read_elements("lde", c)
+    ctx.close()
+    assert lde.shape == (n * B, 2)
+    g_n, g_N = O.root_of_unity(n), O.root_of_unity(n * B)
+    rng = np.random.default_rng(7 + log_n)
+    samples = 6 if log_n <= 20 else 3
+    for k in [0, 1, n - 1] + [int(v) for v in rng.integers(0, n, size=samples)]:
+        assert O.poly_eval(poly, O.exp(g_n, k)) == O.to_ints(cols[c, k:k + 1])[0], ("interpolation", k)
+    for i in [1, B - 1, B, n * B - 1] + [int(v) for v in rng.integers(0, n * B, size=samples)]:
+        assert O.poly_eval(poly, O.exp(g_N, i)) == O.to_ints(lde[i:i + 1])[0], ("extension", i)
+    assert (lde[::B] == cols[c]).all()                                 # coset 0 of the extension is the trace itself

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Runs on the GPU box (through gpurun): rocprofv3 kernel-trace/stats pass + separate PMC passes over the SAME bench command, then
+# summarises them into profiles/<tag>_* (copied back through gpurun_out/).   usage: bash tools/profile_round.sh <tag> [steps]
+TAG=${1:-r1}; STEPS=${2:-3}
+export TMPDIR=/tmp
+R=$PWD
+OUT=$R/gpurun_out/prof_$TAG
+rm -rf $OUT; mkdir -p $OUT
+cd /tmp
+CMD="python $R/bench.py --steps $STEPS --warmup 1 --no-cpu-baseline"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- $CMD > $OUT/stats.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o p -- $CMD > $OUT/fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o p -- $CMD > $OUT/write.log 2>&1
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $OUT/sq1 -o p -- $CMD > $OUT/sq1.log 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_ANY --kernel-trace --output-format csv -d $OUT/sq2 -o p -- $CMD > $OUT/sq2.log 2>&1
+cd $R
+grep -h metric $OUT/stats.log > $OUT/bench_under_rocprof.json
+python tools/summarize_profile.py $OUT $R/gpurun_out/profiles_$TAG $TAG
+ls -la $R/gpurun_out/profiles_$TAG
