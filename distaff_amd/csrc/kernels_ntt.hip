@@ -14,7 +14,7 @@
 #include "ctx.h"
 #include <type_traits>
 
-#define NTT_THREADS 1024
+#define NTT_THREADS 512
 
 struct NttArgs {
     const fe* src; fe* dst;
@@ -27,6 +27,7 @@ struct NttArgs {
     uint32_t j0;               // global index of the first local coset (0 when `coset_twiddle` is off)
     uint32_t coset_twiddle;    // 1: four-step twiddle includes the coset offset j (LDE), 0: plain transform
     uint32_t has_scale;        // 1: multiply the result by `scale` (1/n of inverse transforms)
+    uint32_t tiles_per_block;  // adjacent tiles one workgroup walks through
     fe scale;
 };
 
@@ -39,22 +40,48 @@ __device__ __forceinline__ fe dom_pow(const fe* lo, const fe* hi, uint32_t lo_bi
     return fe_mul(a, hi[h]);
 }
 
-// in-LDS radix-2 DIF over the first index of L[len][T]; output position r holds frequency bitrev(r)
-__device__ __forceinline__ void lds_ntt_dif(fe* L, const fe* __restrict__ W, uint32_t log_len, uint32_t log_t) {
-    const uint32_t half = 1u << (log_len - 1);
+// compile-time loop: the bodies hold fully inlined 128-bit multiplications, far beyond the size the loop unroller accepts, so the
+// unrolling is structural and every register-array index is a constant
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+// in-LDS DIF over the first index of L[len][T]; output position r holds frequency bitrev(r).  W: stage twiddles w_len^t in LDS.
+// Two radix-2 stages are fused into one radix-4 round (one LDS round trip, one barrier and one index computation per two
+// stages; the arithmetic is exactly the two radix-2 stages); an odd stage count ends with a plain radix-2 stage.
+__device__ __forceinline__ void lds_ntt_dif(fe* L, const fe* W, uint32_t log_len, uint32_t log_t) {
     const uint32_t T = 1u << log_t;
-    for (uint32_t s = 1; s <= log_len; s++) {
-        const uint32_t ld = log_len - s;             // log2 of butterfly distance
-        const uint32_t d = 1u << ld;
-        for (uint32_t w = threadIdx.x; w < half * T; w += NTT_THREADS) {
-            uint32_t t = w & (T - 1), q = w >> log_t;
-            uint32_t pos = q & (d - 1), blk = q >> ld;
-            uint32_t i0 = (blk << (ld + 1)) + pos, i1 = i0 + d;
-            fe* p0 = L + ((i0 << log_t) + t); fe* p1 = L + ((i1 << log_t) + t);
-            fe a = *p0, b = *p1;
-            *p0 = fe_add(a, b);
-            fe diff = fe_sub(a, b);
-            *p1 = (s == log_len) ? diff : fe_mul(diff, W[pos << (s - 1)]);
+    uint32_t s = 1;
+    for (; s + 1 <= log_len; s += 2) {
+        const uint32_t ld = log_len - s;             // log2 of the first stage's butterfly distance d
+        const uint32_t d = 1u << ld, hd = d >> 1;
+        const bool last = (s + 1 == log_len);        // second stage has distance 1: its twiddles are 1
+        for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 2) * T; w += NTT_THREADS) {
+            const uint32_t t = w & (T - 1), q = w >> log_t;
+            const uint32_t pos = q & (hd - 1), blk = q >> (ld - 1);
+            const uint32_t i0 = (blk << (ld + 1)) + pos;
+            fe* p0 = L + ((i0 << log_t) + t); fe* p1 = p0 + (hd << log_t); fe* p2 = p0 + (d << log_t); fe* p3 = p2 + (hd << log_t);
+            const fe x0 = *p0, x1 = *p1, x2 = *p2, x3 = *p3;
+            // stage s: (x0, x2) with w_2d^pos, (x1, x3) with w_2d^(pos + d/2)
+            fe a0 = fe_add(x0, x2), a2 = fe_sub(x0, x2);
+            fe a1 = fe_add(x1, x3), a3 = fe_sub(x1, x3);
+            if (pos != 0) a2 = fe_mul(a2, W[pos << (s - 1)]);
+            a3 = fe_mul(a3, W[(pos + hd) << (s - 1)]);
+            // stage s + 1: (a0, a1) and (a2, a3) with w_d^pos
+            fe y0 = fe_add(a0, a1), y1 = fe_sub(a0, a1);
+            fe y2 = fe_add(a2, a3), y3 = fe_sub(a2, a3);
+            if (!last && pos != 0) { const fe tw = W[pos << s]; y1 = fe_mul(y1, tw); y3 = fe_mul(y3, tw); }
+            *p0 = y0; *p1 = y1; *p2 = y2; *p3 = y3;
+        }
+        __syncthreads();
+    }
+    if (s == log_len) {                              // distance-1 stage, no twiddles
+        for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 1) * T; w += NTT_THREADS) {
+            const uint32_t t = w & (T - 1), q = w >> log_t;
+            fe* p0 = L + (((q << 1) << log_t) + t); fe* p1 = p0 + T;
+            const fe a = *p0, b = *p1;
+            *p0 = fe_add(a, b); *p1 = fe_sub(a, b);
         }
         __syncthreads();
     }
@@ -62,55 +89,86 @@ __device__ __forceinline__ void lds_ntt_dif(fe* L, const fe* __restrict__ W, uin
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
 
-// grid: (n2 / T, cosets, columns)
-__global__ void __launch_bounds__(NTT_THREADS) ntt_pass_a(NttArgs a) {
+// Both passes are persistent over `tiles_per_block` adjacent tiles: the tile's elements for the NEXT iteration are fetched from HBM
+// into registers before the butterfly stages of the current one start, so the HBM latency and most of the transfer overlap
+// with the arithmetic (measured: a block that loads, computes and stores in sequence pays HBM time + ALU time, not their maximum).
+// The stage twiddles live in LDS behind the tile, so the stages issue no global loads that would have to wait behind the prefetch.
+#define NTT_EPT 8      // elements per lane: tile elements (<= 4096) / NTT_THREADS
+
+// grid: (n2 / T / tiles_per_block, cosets, columns)
+__global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_a(NttArgs a, const fe* __restrict__ src_base, fe* __restrict__ dst_base) {
     fe* L = reinterpret_cast<fe*>(ntt_smem);
     const uint32_t log_t = a.tile, T = 1u << log_t, n1 = 1u << a.log_n1, n2 = 1u << a.log_n2;
-    const uint32_t m2_0 = blockIdx.x * T;
+    fe* TW = L + n1 * T;
     const uint32_t jl = blockIdx.y, jg = a.j0 + jl;
-    const fe* src = a.src + (size_t)blockIdx.z * a.src_col_stride + (size_t)jl * a.src_coset_stride;
-    fe* dst = a.dst + (size_t)blockIdx.z * a.dst_col_stride + (size_t)jl * a.dst_coset_stride;
+    const fe* __restrict__ src = src_base + (size_t)blockIdx.z * a.src_col_stride + (size_t)jl * a.src_coset_stride;
+    fe* __restrict__ dst = dst_base + (size_t)blockIdx.z * a.dst_col_stride + (size_t)jl * a.dst_coset_stride;
     const uint32_t pmask = (1u << (a.log_b + a.log_n1)) - 1u;
-    for (uint32_t idx = threadIdx.x; idx < n1 * T; idx += NTT_THREADS) {
-        uint32_t t = idx & (T - 1), m1 = idx >> log_t;
-        fe v = src[((size_t)m1 << a.log_n2) + m2_0 + t];
-        if (a.prescale != nullptr && jg != 0) v = fe_mul(v, a.prescale[(jg * m1) & pmask]);
-        L[idx] = v;
-    }
-    __syncthreads();
-    lds_ntt_dif(L, a.stage_tw, a.log_n1, log_t);
     const uint64_t nmask = (1ull << a.log_N) - 1ull;
-    for (uint32_t idx = threadIdx.x; idx < n1 * T; idx += NTT_THREADS) {
-        uint32_t t = idx & (T - 1), r = idx >> log_t;
-        uint32_t k1 = __brev(r) >> (32 - a.log_n1);
-        uint32_t m2 = m2_0 + t;
-        uint64_t e = ((uint64_t)m2 * (((uint64_t)k1 << a.log_b) + (a.coset_twiddle ? jg : 0u))) & nmask;
-        fe v = L[idx];
-        if (e != 0) v = fe_mul(v, dom_pow(a.tw_lo, a.tw_hi, a.lo_bits, e));
-        dst[((size_t)k1 << a.log_n2) + m2] = v;
+    for (uint32_t i = threadIdx.x; i < n1 / 2; i += NTT_THREADS) TW[i] = a.stage_tw[i];
+    const bool scaled = a.prescale != nullptr && jg != 0;
+    fe pre0 = fe_zero(), pre1 = fe_zero(), pre2 = fe_zero(), pre3 = fe_zero(), pre4 = fe_zero(), pre5 = fe_zero(), pre6 = fe_zero(), pre7 = fe_zero();
+    const uint32_t count = n1 * T;
+#define NTT_FETCH_A1(e, var, m2_0) { uint32_t idx = threadIdx.x + (e) * NTT_THREADS; idx = idx < count ? idx : 0u; /* branch-free: a lane past the tile re-reads element 0 */ var = src[((size_t)(idx >> log_t) << a.log_n2) + (m2_0) + (idx & (T - 1))]; }
+#define NTT_FETCH_A(tile) { const uint32_t f0 = (tile) * T; NTT_FETCH_A1(0, pre0, f0) NTT_FETCH_A1(1, pre1, f0) NTT_FETCH_A1(2, pre2, f0) NTT_FETCH_A1(3, pre3, f0) \
+                                                        NTT_FETCH_A1(4, pre4, f0) NTT_FETCH_A1(5, pre5, f0) NTT_FETCH_A1(6, pre6, f0) NTT_FETCH_A1(7, pre7, f0) }
+    const uint32_t tile0 = blockIdx.x * a.tiles_per_block;
+    NTT_FETCH_A(tile0)
+    for (uint32_t it = 0; it < a.tiles_per_block; it++) {
+        const uint32_t m2_0 = (tile0 + it) * T;
+        __syncthreads();                                   // the previous tile has left LDS (and TW is complete)
+        // the coset pre-scale depends on the row m1 of an element only; the table is small and stays in L2
+#define NTT_PUT_A(e, var) { const uint32_t idx = threadIdx.x + (e) * NTT_THREADS; if (idx < count) L[idx] = scaled ? fe_mul(var, a.prescale[(jg * (idx >> log_t)) & pmask]) : var; }
+        NTT_PUT_A(0, pre0) NTT_PUT_A(1, pre1) NTT_PUT_A(2, pre2) NTT_PUT_A(3, pre3) NTT_PUT_A(4, pre4) NTT_PUT_A(5, pre5) NTT_PUT_A(6, pre6) NTT_PUT_A(7, pre7)
+#undef NTT_PUT_A
+        __syncthreads();
+        if (it + 1 < a.tiles_per_block) NTT_FETCH_A(tile0 + it + 1)
+        lds_ntt_dif(L, TW, a.log_n1, log_t);
+        for (uint32_t idx = threadIdx.x; idx < n1 * T; idx += NTT_THREADS) {
+            uint32_t t = idx & (T - 1), r = idx >> log_t;
+            uint32_t k1 = __brev(r) >> (32 - a.log_n1);
+            uint32_t m2 = m2_0 + t;
+            uint64_t e = ((uint64_t)m2 * (((uint64_t)k1 << a.log_b) + (a.coset_twiddle ? jg : 0u))) & nmask;
+            fe v = L[idx];
+            if (e != 0) v = fe_mul(v, dom_pow(a.tw_lo, a.tw_hi, a.lo_bits, e));
+            dst[((size_t)k1 << a.log_n2) + m2] = v;
+        }
     }
 }
 
-// grid: (n1 / T, cosets, columns)
-__global__ void __launch_bounds__(NTT_THREADS) ntt_pass_b(NttArgs a) {
+// grid: (n1 / T / tiles_per_block, cosets, columns)
+__global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_b(NttArgs a, const fe* __restrict__ src_base, fe* __restrict__ dst_base) {
     fe* L = reinterpret_cast<fe*>(ntt_smem);
     const uint32_t log_t = a.tile, T = 1u << log_t, n1 = 1u << a.log_n1, n2 = 1u << a.log_n2;
-    const uint32_t k1_0 = blockIdx.x * T;
+    fe* TW = L + n2 * T;
     const uint32_t jl = blockIdx.y;
-    const fe* src = a.src + (size_t)blockIdx.z * a.src_col_stride + (size_t)jl * a.src_coset_stride;
-    fe* dst = a.dst + (size_t)blockIdx.z * a.dst_col_stride + (size_t)jl * a.dst_coset_stride;
-    for (uint32_t idx = threadIdx.x; idx < n2 * T; idx += NTT_THREADS) {
-        uint32_t m2 = idx & (n2 - 1), t = idx >> a.log_n2;           // contiguous reads along m2
-        L[(m2 << log_t) + t] = src[((size_t)(k1_0 + t) << a.log_n2) + m2];
-    }
-    __syncthreads();
-    lds_ntt_dif(L, a.stage_tw, a.log_n2, log_t);
-    for (uint32_t idx = threadIdx.x; idx < n2 * T; idx += NTT_THREADS) {
-        uint32_t t = idx & (T - 1), r = idx >> log_t;
-        uint32_t k2 = a.log_n2 ? (__brev(r) >> (32 - a.log_n2)) : 0u;
-        fe v = L[idx];
-        if (a.has_scale) v = fe_mul(v, a.scale);
-        dst[((size_t)k2 << a.log_n1) + k1_0 + t] = v;
+    const fe* __restrict__ src = src_base + (size_t)blockIdx.z * a.src_col_stride + (size_t)jl * a.src_coset_stride;
+    fe* __restrict__ dst = dst_base + (size_t)blockIdx.z * a.dst_col_stride + (size_t)jl * a.dst_coset_stride;
+    for (uint32_t i = threadIdx.x; i < n2 / 2; i += NTT_THREADS) TW[i] = a.stage_tw[i];
+    fe pre0 = fe_zero(), pre1 = fe_zero(), pre2 = fe_zero(), pre3 = fe_zero(), pre4 = fe_zero(), pre5 = fe_zero(), pre6 = fe_zero(), pre7 = fe_zero();
+    const uint32_t count = n2 * T;
+    // contiguous along m2
+#define NTT_FETCH_B1(e, var, k1_0) { uint32_t idx = threadIdx.x + (e) * NTT_THREADS; idx = idx < count ? idx : 0u; var = src[((size_t)((k1_0) + (idx >> a.log_n2)) << a.log_n2) + (idx & (n2 - 1))]; }
+#define NTT_FETCH_B(tile) { const uint32_t f0 = (tile) * T; NTT_FETCH_B1(0, pre0, f0) NTT_FETCH_B1(1, pre1, f0) NTT_FETCH_B1(2, pre2, f0) NTT_FETCH_B1(3, pre3, f0) \
+                                                        NTT_FETCH_B1(4, pre4, f0) NTT_FETCH_B1(5, pre5, f0) NTT_FETCH_B1(6, pre6, f0) NTT_FETCH_B1(7, pre7, f0) }
+    const uint32_t tile0 = blockIdx.x * a.tiles_per_block;
+    NTT_FETCH_B(tile0)
+    for (uint32_t it = 0; it < a.tiles_per_block; it++) {
+        const uint32_t k1_0 = (tile0 + it) * T;
+        __syncthreads();
+#define NTT_PUT_B(e, var) { const uint32_t idx = threadIdx.x + (e) * NTT_THREADS; if (idx < count) L[((idx & (n2 - 1)) << log_t) + (idx >> a.log_n2)] = var; }
+        NTT_PUT_B(0, pre0) NTT_PUT_B(1, pre1) NTT_PUT_B(2, pre2) NTT_PUT_B(3, pre3) NTT_PUT_B(4, pre4) NTT_PUT_B(5, pre5) NTT_PUT_B(6, pre6) NTT_PUT_B(7, pre7)
+#undef NTT_PUT_B
+        __syncthreads();
+        if (it + 1 < a.tiles_per_block) NTT_FETCH_B(tile0 + it + 1)
+        lds_ntt_dif(L, TW, a.log_n2, log_t);
+        for (uint32_t idx = threadIdx.x; idx < n2 * T; idx += NTT_THREADS) {
+            uint32_t t = idx & (T - 1), r = idx >> log_t;
+            uint32_t k2 = a.log_n2 ? (__brev(r) >> (32 - a.log_n2)) : 0u;
+            fe v = L[idx];
+            if (a.has_scale) v = fe_mul(v, a.scale);
+            dst[((size_t)k2 << a.log_n1) + k1_0 + t] = v;
+        }
     }
 }
 
@@ -153,13 +211,6 @@ constexpr __host__ __device__ int ntt_brev(int v, int bits) { int r = 0; for (in
 // 1024-point kernel is ~190 KB of straight-line code, several times the 64 KB instruction cache a CU pair shares, and the waves
 // stall on instruction fetch; as a call the kernel is a few thousand instructions.
 __device__ __attribute__((noinline)) fe fe_mul_call(fe a, fe b) { return fe_mul(a, b); }
-
-// compile-time loop: the bodies hold fully inlined 128-bit multiplications, far beyond the size the loop unroller accepts, so the
-// unrolling is structural and every register-array index is a constant
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
-}
 
 // radix-2 DIF over x[0 .. 2^r): x[rho] <- X[brev_r(rho)]
 template <int r>
@@ -330,9 +381,21 @@ static void launch_pass_reg(dst_ctx* c, bool pass_b, const fe* src, size_t src_c
     }
 }
 
+// tiles a workgroup walks through: as many as keep >= 2048 workgroups in the launch (8 per CU), at most 8
+static uint32_t ntt_tiles_per_block(uint32_t tiles, size_t arrays) {
+    uint32_t k = 1;
+    while (k < 8 && tiles % (2 * k) == 0 && (size_t)(tiles / (2 * k)) * arrays >= 2048) k *= 2;
+    return k;
+}
 static void launch_pass_lds(dst_ctx* c, bool pass_b, const fe* src, size_t src_col_stride, size_t src_coset_stride,
                             fe* dst, size_t dst_col_stride, size_t dst_coset_stride, size_t cosets, size_t cols, bool inverse, bool lde) {
     const NttPlan& p = c->plan;
+    static bool lds_limit_raised[64] = {};
+    if (c->device >= 0 && c->device < 64 && !lds_limit_raised[c->device]) {     // tile + stage twiddles can exceed the 64 KiB default
+        (void)hipFuncSetAttribute((const void*)ntt_pass_a, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)ntt_pass_b, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        lds_limit_raised[c->device] = true;
+    }
     NttArgs a{};
     a.log_n1 = p.log_n1; a.log_n2 = p.log_n2; a.log_N = c->log_N; a.log_b = c->log_b; a.lo_bits = c->tw_lo_bits;
     a.j0 = lde ? (uint32_t)c->j0 : 0u; a.coset_twiddle = lde ? 1u : 0u;
@@ -344,16 +407,20 @@ static void launch_pass_lds(dst_ctx* c, bool pass_b, const fe* src, size_t src_c
     a.dst = dst; a.dst_col_stride = dst_col_stride; a.dst_coset_stride = dst_coset_stride;
     if (!pass_b) {
         a.stage_tw = inverse ? c->w1i : c->w1f; a.tile = (uint32_t)__builtin_ctz(p.tile_a);
-        size_t lds_a = ((size_t)1 << p.log_n1) * p.tile_a * sizeof(fe);
-        dim3 ga((unsigned)((1u << p.log_n2) / p.tile_a), (unsigned)cosets, (unsigned)cols);
+        size_t lds_a = (((size_t)1 << p.log_n1) * p.tile_a + ((size_t)1 << p.log_n1) / 2) * sizeof(fe);
+        const uint32_t tiles = (1u << p.log_n2) / p.tile_a;
+        a.tiles_per_block = ntt_tiles_per_block(tiles, cosets * cols);
+        dim3 ga((unsigned)(tiles / a.tiles_per_block), (unsigned)cosets, (unsigned)cols);
         KScope ks_(c, "ntt_pass_a", 16.0 * c->n * cols * (lde ? (1 + cosets) : 2 * cosets));
-        hipLaunchKernelGGL(ntt_pass_a, ga, dim3(NTT_THREADS), lds_a, c->stream, a);
+        hipLaunchKernelGGL(ntt_pass_a, ga, dim3(NTT_THREADS), lds_a, c->stream, a, a.src, a.dst);
     } else {
         a.stage_tw = inverse ? c->w2i : c->w2f; a.tile = (uint32_t)__builtin_ctz(p.tile_b);
-        size_t lds_b = ((size_t)1 << p.log_n2) * p.tile_b * sizeof(fe);
-        dim3 gb((unsigned)((1u << p.log_n1) / p.tile_b), (unsigned)cosets, (unsigned)cols);
+        size_t lds_b = (((size_t)1 << p.log_n2) * p.tile_b + ((size_t)1 << p.log_n2) / 2) * sizeof(fe);
+        const uint32_t tiles = (1u << p.log_n1) / p.tile_b;
+        a.tiles_per_block = ntt_tiles_per_block(tiles, cosets * cols);
+        dim3 gb((unsigned)(tiles / a.tiles_per_block), (unsigned)cosets, (unsigned)cols);
         KScope ks_(c, "ntt_pass_b", 32.0 * c->n * cols * cosets);
-        hipLaunchKernelGGL(ntt_pass_b, gb, dim3(NTT_THREADS), lds_b, c->stream, a);
+        hipLaunchKernelGGL(ntt_pass_b, gb, dim3(NTT_THREADS), lds_b, c->stream, a, a.src, a.dst);
     }
 }
 

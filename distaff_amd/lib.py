@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdistaff_hip.so")
+LIB_PATH = os.environ.get("DISTAFF_HIP_LIB") or os.path.join(_HERE, "libdistaff_hip.so")
 
 DST_OK, DST_ERR_ARG, DST_ERR_HIP, DST_ERR_AIR, DST_ERR_STATE = 0, -1, -2, -3, -4
 
