@@ -164,16 +164,20 @@ FE_HD fe fe_mul_portable(const fe& a, const fe& b) {
 __device__ __forceinline__ void fe_mac_c(uint64_t& acc, uint32_t& cnt, uint32_t a, uint32_t b) {
     asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(cnt) : "v"(a), "v"(b) : "vcc");
 }
+// first accumulation into a window: the carry count starts as the carry-out itself (no zero-initialised register)
+__device__ __forceinline__ void fe_mac_c0(uint64_t& acc, uint32_t& cnt, uint32_t a, uint32_t b) {
+    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, 0, vcc" : "+v"(acc), "=v"(cnt) : "v"(a), "v"(b) : "vcc");
+}
 __device__ __forceinline__ fe fe_mul_gfx950(const fe& a, const fe& b) {
 #define FE_LO(x) ((uint32_t)(x))
 #define FE_HI(x) ((uint32_t)((x) >> 32))
     uint64_t E0 = (uint64_t)a.v[0] * b.v[0];
-    uint64_t E1 = (uint64_t)a.v[0] * b.v[2]; uint32_t ce1 = 0; fe_mac_c(E1, ce1, a.v[1], b.v[1]); fe_mac_c(E1, ce1, a.v[2], b.v[0]);
-    uint64_t E2 = (uint64_t)a.v[1] * b.v[3]; uint32_t ce2 = 0; fe_mac_c(E2, ce2, a.v[2], b.v[2]); fe_mac_c(E2, ce2, a.v[3], b.v[1]);
+    uint64_t E1 = (uint64_t)a.v[0] * b.v[2]; uint32_t ce1; fe_mac_c0(E1, ce1, a.v[1], b.v[1]); fe_mac_c(E1, ce1, a.v[2], b.v[0]);
+    uint64_t E2 = (uint64_t)a.v[1] * b.v[3]; uint32_t ce2; fe_mac_c0(E2, ce2, a.v[2], b.v[2]); fe_mac_c(E2, ce2, a.v[3], b.v[1]);
     uint64_t E3 = (uint64_t)a.v[3] * b.v[3];
-    uint64_t O0 = (uint64_t)a.v[0] * b.v[1]; uint32_t co0 = 0; fe_mac_c(O0, co0, a.v[1], b.v[0]);
-    uint64_t O1 = (uint64_t)a.v[0] * b.v[3]; uint32_t co1 = 0; fe_mac_c(O1, co1, a.v[1], b.v[2]); fe_mac_c(O1, co1, a.v[2], b.v[1]); fe_mac_c(O1, co1, a.v[3], b.v[0]);
-    uint64_t O2 = (uint64_t)a.v[2] * b.v[3]; uint32_t co2 = 0; fe_mac_c(O2, co2, a.v[3], b.v[2]);
+    uint64_t O0 = (uint64_t)a.v[0] * b.v[1]; uint32_t co0; fe_mac_c0(O0, co0, a.v[1], b.v[0]);
+    uint64_t O1 = (uint64_t)a.v[0] * b.v[3]; uint32_t co1; fe_mac_c0(O1, co1, a.v[1], b.v[2]); fe_mac_c(O1, co1, a.v[2], b.v[1]); fe_mac_c(O1, co1, a.v[3], b.v[0]);
+    uint64_t O2 = (uint64_t)a.v[2] * b.v[3]; uint32_t co2; fe_mac_c0(O2, co2, a.v[3], b.v[2]);
     uint32_t t0, t1, t2, t3, t4, t5, t6, t7, c, bw;
     t0 = FE_LO(E0);
     t1 = fe_addc(FE_HI(E0), FE_LO(O0), 0, &c);
@@ -220,18 +224,14 @@ __device__ __forceinline__ fe fe_mul_gfx950(const fe& a, const fe& b) {
     y2 = fe_subb(y2, 0, bw, &bw);
     y3 = fe_subb(y3, 0, bw, &bw);
     y4 = y4 - bw;
-    // fold 3: add y4 * C128 (y4 is 0 or 1)
-    uint32_t mask = 0u - y4;
-    y0 = fe_addc(y0, mask, 0, &c);
-    y1 = fe_addc(y1, mask & FE_C1, c, &c);
-    y2 = fe_addc(y2, 0, c, &c);
-    y3 = y3 + c;
-    // canonical form
+    // fold 3 and canonical form in one step.  The value is Y = y + y4 * 2^128 with y4 in {0, 1} and Y < 2p.  z = y + C128 (mod 2^128)
+    // is Y - p whenever Y >= p, and Y >= p <=> y4 = 1 or the addition carries out (when y4 = 1, y < p - C128, so no carry).
     uint32_t z0, z1, z2, z3;
     z0 = fe_addc(y0, FE_C0, 0, &c);
     z1 = fe_addc(y1, FE_C1, c, &c);
     z2 = fe_addc(y2, 0, c, &c);
     z3 = fe_addc(y3, 0, c, &c);
+    c |= y4;
 #undef FE_LO
 #undef FE_HI
     return c ? fe_make(z0, z1, z2, z3) : fe_make(y0, y1, y2, y3);
