@@ -83,7 +83,7 @@ struct Acc {
 // SD: compile-time user stack depth, or 0 when the depth is only known at run time (then SLCAP bounds the slice length).
 // Only the first `stack_depth` stack constraints are emitted (stack/mod.rs:194), so with SD known the unused slots vanish.
 // SECT selects which constraint sections this launch evaluates (bit 0 boundary, 1 op bits, 2 sponge/context/loop, 3 stack:
-// low-degree ops, 4 stack: high-degree + composite ops).  The combination is linear in the constraints, so a launch that is
+// low-degree ops that move items, 5 stack: low-degree arithmetic / selection ops, 4 stack: PUSH / CMP / BEGIN / NOOP, 6 stack: RESCR).  The combination is linear in the constraints, so a launch that is
 // not FIRST starts from the partial sums (res, adj[6]) left by the previous launch and one that is not LAST stores them;
 // splitting the evaluation this way keeps the live state of each launch within the register budget.
 template <int CL, int LL, int SD, int SLCAP, int SECT, bool FIRST, bool LAST>
@@ -195,11 +195,6 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
 #pragma unroll
     for (int i = 0; i < 6; i++) acc.adj[i] = fe_zero();
     const size_t pstride = (size_t)gridDim.y * a.n, pidx = (size_t)ql * a.n + k;
-    if constexpr (!FIRST) {
-        acc.res = a.partial[pidx];
-#pragma unroll
-        for (int i = 0; i < 6; i++) acc.adj[i] = a.partial[(size_t)(i + 1) * pstride + pidx];
-    }
 
     // ---- decoder: op bits (decoder/op_bits.rs:10-79) -------------------------------------------------------------------
     if constexpr ((SECT & 2) != 0) {
@@ -298,7 +293,7 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
     }
 
     // ---- stack constraints (constraints/stack/mod.rs:117-195) ---------------------------------------------------------------
-    if constexpr ((SECT & 24) != 0) {
+    if constexpr ((SECT & 120) != 0) {
         fe ev[SL], aux0 = fe_zero(), aux1 = fe_zero();
 #pragma unroll
         for (int i = 0; i < SL; i++) ev[i] = fe_zero();
@@ -359,6 +354,8 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
 #pragma unroll
         for (int i = 1; i < 8; i++) agg(i, f, fe_sub(nw[i], o[i - 1]));
         copy_from(8, f);
+        }   // low-degree ops that only move stack items
+        if constexpr ((SECT & 32) != 0) {
         // ADD (0x08), MUL (0x09), AND (0x0A), OR (0x0B): left shift (2,1)
         {
             fe xy = fe_mul(o[0], o[1]);
@@ -414,7 +411,7 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
             lshift(6, 2, f);
             aux0 = fe_add(aux0, fe_mul(f, binc));
         }
-        }   // low-degree ops
+        }   // low-degree arithmetic / selection ops
         if constexpr ((SECT & 16) != 0) {
         rshift(1, hdf[0]);                                             // PUSH (input.rs:6)
         // CMP (hd 1) (comparison.rs:64-105)
@@ -431,6 +428,10 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
             agg(7, f, fe_sub(fe_double(nw[0]), o[0]));
             copy_from(8, f);
         }
+        // BEGIN and NOOP leave the stack untouched
+        copy_from(0, fe_add(begin_flag, noop_flag));
+        }   // PUSH, CMP, BEGIN / NOOP
+        if constexpr ((SECT & 64) != 0) {
         // RESCR (hd 2) (hash.rs:9-35)
         {
             f = hdf[2];
@@ -447,23 +448,30 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
             for (int i = 0; i < 6; i++) agg(i, f, fe_sub(ns[i], os[i]));
             copy_from(6, f);
         }
-        // BEGIN and NOOP leave the stack untouched
-        copy_from(0, fe_add(begin_flag, noop_flag));
-        }   // high-degree and composite ops
+        }   // RESCR
 
         const uint32_t sbase = 20 + cl + ll;
-        if constexpr ((SECT & 8) != 0) { acc.emit(sbase, 4, aux0); acc.emit(sbase + 1, 4, aux1); }     // only low-degree ops touch the aux constraints
+        if constexpr ((SECT & 40) != 0) { acc.emit(sbase, 4, aux0); acc.emit(sbase + 1, 4, aux1); }    // only low-degree ops touch the aux constraints
 #pragma unroll
         for (int i = 0; i < SL; i++) if (i < sd) acc.emit(sbase + 2 + i, 4, ev[i]);
     }
 
     // ---- combination (evaluator.rs:139-162, 335-358) ---------------------------------------------------------------------------
+    if constexpr (SECT == 1) return;           // a boundary-only launch neither reads nor writes the partial sums
     const bool on_trace = (qg == 0);
     if (on_trace && k + 1 != a.n && acc.nonzero) atomicMin(a.bad_step, (unsigned long long)k);      // evaluator.rs:152-158
+    // the partial sums of the previous launches join at the end (they are not live during the evaluation); a launch only moves the
+    // degree-group sums its sections emit into: op bits {2,3,4,6,8}, sponge / context / loop {4,6,7}, stack {7}
+    constexpr uint32_t USED = ((SECT & 2) ? 0x2Fu : 0u) | ((SECT & 4) ? 0x1Cu : 0u) | ((SECT & 120) ? 0x10u : 0u);
+    if constexpr (!FIRST) {
+        acc.res = fe_add(acc.res, a.partial[pidx]);
+#pragma unroll
+        for (int i = 0; i < 6; i++) if (LAST || ((USED >> i) & 1u)) acc.adj[i] = fe_add(acc.adj[i], a.partial[(size_t)(i + 1) * pstride + pidx]);
+    }
     if constexpr (!LAST) {
         a.partial[pidx] = acc.res;
 #pragma unroll
-        for (int i = 0; i < 6; i++) a.partial[(size_t)(i + 1) * pstride + pidx] = acc.adj[i];
+        for (int i = 0; i < 6; i++) if (FIRST || ((USED >> i) & 1u)) a.partial[(size_t)(i + 1) * pstride + pidx] = acc.adj[i];
         return;
     }
     fe t;

@@ -2,7 +2,7 @@
 #include "air_kernel.h"
 #include "rescue_constants.h"
 
-void air_launch_generic(dst_ctx* c, const AirArgs& a, uint32_t Q) { launch_air<16, 8, 0, 32, 31, true, true>(c, a, Q); }
+void air_launch_generic(dst_ctx* c, const AirArgs& a, uint32_t Q) { launch_air<16, 8, 0, 32, 127, true, true>(c, a, Q); }
 
 
 int k_eval_constraints(dst_ctx* c, const fe* coeffs_dev, const fe* tc_dev, int64_t* bad_step) {

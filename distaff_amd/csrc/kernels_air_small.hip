@@ -3,5 +3,5 @@
 #include "air_kernel.h"
 void air_launch_small(dst_ctx* c, const AirArgs& a, uint32_t Q) {
     launch_air<2, 1, 0, 8, 7, true, false>(c, a, Q);      // boundary + op bits + sponge / context / loop
-    launch_air<2, 1, 0, 8, 24, false, true>(c, a, Q);     // stack + combination
+    launch_air<2, 1, 0, 8, 120, false, true>(c, a, Q);     // stack + combination
 }
