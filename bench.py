@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=int(os.environ.get("BENCH_LOG_N", "20")))
-    ap.add_argument("--cpu-log-n", type=int, default=int(os.environ.get("BENCH_CPU_LOG_N", "15")))
+    ap.add_argument("--cpu-log-n", type=int, default=int(os.environ.get("BENCH_CPU_LOG_N", "16")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (multi-GPU) code path even with one rank")
     args = ap.parse_args()
