@@ -6,6 +6,7 @@
 // exports and imports the shards.
 #include "ctx.h"
 #include "host_util.h"
+#include "host_proof.h"
 
 using namespace dsth;
 
@@ -237,6 +238,198 @@ int dst_shard_read(dst_ctx* c, uint32_t buffer, uint32_t arg, const uint64_t* id
     HIP_TRY(c, hipMemcpyAsync(out, d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
+    return DST_OK;
+}
+
+// ---- step 9 across ranks -------------------------------------------------------------------------------------------------------------
+// Every rank derives the same ordered request list from the query positions (which leaf / node / element / row the proof
+// needs, who owns it, where it sits in the owner's buffers) and the same proof template with one slot per request.
+// dst_shard_open gathers the items this rank owns into one blob (one batched device gather, one copy back);
+// dst_shard_assemble fills the template from the blobs of all ranks.  The orchestration all-gathers the blobs in between.
+namespace {
+struct OpenReq { int owner; uint32_t buffer, arg; uint64_t index; uint32_t bytes; };       // owner -1: replicated, served by rank 0
+struct OpenPlan { std::vector<OpenReq> reqs; std::vector<size_t> slot; Writer w; };
+
+struct Geometry {                      // distaff_amd/sharded.py TreeGeometry: leaves Bt*k + j', columns j' split over G ranks
+    uint64_t L, Bt, G, Bct, K;
+    Geometry(uint64_t leaves, uint64_t bt, uint64_t g) : L(leaves), Bt(bt), G(g), Bct(bt / g), K(leaves / bt) {}
+    void leaf(uint64_t i, int& g, uint64_t& local) const { uint64_t k = i / Bt, j = i % Bt; g = (int)(j / Bct); local = k * Bct + (j - (uint64_t)g * Bct); }
+    void node(uint64_t heap, int& g, uint64_t& idx) const {
+        uint64_t level = 1; while (level * 2 <= heap) level *= 2;              // nodes on this level
+        uint64_t t = heap - level, span = L / level;
+        if (span >= Bct) { g = -1; idx = heap; return; }
+        uint64_t local_leaf; leaf(t * span, g, local_leaf);
+        idx = K * Bct / span + local_leaf / span;
+    }
+};
+
+void plan_item(OpenPlan& p, int owner, uint32_t buffer, uint32_t arg, uint64_t index, uint32_t bytes) {
+    p.reqs.push_back({owner, buffer, arg, index, bytes});
+    p.slot.push_back(p.w.b.size());
+    p.w.b.resize(p.w.b.size() + bytes);
+}
+// element at natural position pos of a coset-major [B][nd] array
+void plan_element(const dst_ctx* c, OpenPlan& p, uint32_t buffer, uint32_t arg, uint64_t pos, uint64_t nd) {
+    uint64_t k = pos / c->B, j = pos % c->B, g = j / c->Bc;
+    plan_item(p, (int)g, buffer, arg, (j - g * c->Bc) * nd + k, 16);
+}
+void plan_tree_nodes(const dst_ctx* c, OpenPlan& p, const BatchPlan& bp, const Geometry& geo, uint32_t leaf_buf, uint32_t node_buf, uint32_t upper_buf,
+                     uint32_t arg, bool raw_pair_leaves) {
+    p.w.u64(bp.nodes.size());
+    for (auto& l : bp.nodes) {
+        p.w.u64(l.size());
+        for (auto& r : l) {
+            int g; uint64_t idx;
+            if (r.is_leaf) {
+                if (raw_pair_leaves) { plan_element(c, p, RD_CEVAL, 0, 2 * r.index, c->n); plan_element(c, p, RD_CEVAL, 0, 2 * r.index + 1, c->n); }
+                else { geo.leaf(r.index, g, idx); plan_item(p, g, leaf_buf, arg, idx, 32); }
+            } else {
+                geo.node(r.index, g, idx);
+                plan_item(p, g, g < 0 ? upper_buf : node_buf, arg, idx, 32);
+            }
+        }
+    }
+}
+
+// the serialised StarkProof (proof.rs:11-22) with empty slots; same field order as dst_build_proof (api.hip)
+int build_open_plan(dst_ctx* c, const uint64_t* positions_in, uint32_t num_positions, uint64_t pow_nonce, OpenPlan& p) {
+    const uint64_t G = c->prm.world, B = c->B, N = c->N, n = c->n, W = c->W;
+    std::vector<uint64_t> positions(positions_in, positions_in + num_positions);
+    for (uint64_t q : positions) if (q >= N) { c->err = "query position out of range"; return DST_ERR_ARG; }
+    const int L = c->num_fri_layers;
+    if ((int)c->fri_roots.size() < L) { c->err = "dst_shard_open: FRI commit phase not finished"; return DST_ERR_STATE; }
+    Writer& w = p.w;
+    w.raw(c->trace_root, 32);
+    w.u8((uint8_t)c->log_N); w.u8((uint8_t)c->prm.ctx_depth); w.u8((uint8_t)c->prm.loop_depth); w.u8((uint8_t)c->stack_depth); w.u32((uint32_t)c->op_count);
+    BatchPlan tp = plan_batch(positions, N);
+    plan_tree_nodes(c, p, tp, Geometry(N, B, G), RD_TRACE_LEAF, RD_TRACE_NODE, RD_TRACE_UPPER, 0, false);
+    w.u64(positions.size());
+    for (uint64_t q : positions) { w.u64(W); plan_item(p, (int)((q % B) / c->Bc), RD_LDE_ROW, 0, q, (uint32_t)(W * 16)); }
+    w.raw(c->constraint_root, 32);
+    {
+        std::vector<uint64_t> cpos = constraint_positions(positions);
+        BatchPlan cp = plan_batch(cpos, N / 2);
+        w.u64(cp.values.size());
+        for (uint64_t u : cp.values) { plan_element(c, p, RD_CEVAL, 0, 2 * u, n); plan_element(c, p, RD_CEVAL, 0, 2 * u + 1, n); }
+        plan_tree_nodes(c, p, cp, Geometry(N / 2, B / 2, G), 0, RD_C_NODE, RD_C_UPPER, 0, true);
+        w.u8(cp.depth);
+    }
+    w.u64(W); w.raw(c->deep_z1.data(), W * 16);
+    w.u64(W); w.raw(c->deep_z2.data(), W * 16);
+    std::vector<uint64_t> pos = positions;
+    w.u64((uint64_t)(L - 1));
+    for (int d = 0; d + 1 < L; d++) {
+        const uint64_t size = c->fri_size[d], R = size / 4, nd = size / B;
+        pos = augmented_positions(pos, size);
+        BatchPlan fp = plan_batch(pos, R);
+        w.raw(c->fri_roots[d].data(), 32);
+        w.u64(pos.size());
+        for (uint64_t r : pos) for (uint64_t s4 = 0; s4 < 4; s4++) plan_element(c, p, RD_FRI_E, (uint32_t)d, r + s4 * R, nd);
+        plan_tree_nodes(c, p, fp, Geometry(R, B, G), RD_FRI_LEAF, RD_FRI_NODE, RD_FRI_UPPER, (uint32_t)d, false);
+        w.u8(fp.depth);
+    }
+    w.raw(c->fri_roots[L - 1].data(), 32);
+    const uint64_t rem = c->fri_size[L - 1];
+    w.u64(rem);
+    for (uint64_t i = 0; i < rem; i++) plan_element(c, p, RD_FRI_E, (uint32_t)(L - 1), i, rem / B);
+    w.u64(pow_nonce);
+    w.u8((uint8_t)c->log_b); w.u8((uint8_t)c->prm.num_queries); w.u8((uint8_t)c->prm.grinding_factor); w.u8(0);
+    return DST_OK;
+}
+
+const void* read_source(dst_ctx* c, uint32_t buffer, uint32_t arg) {
+    switch (buffer) {
+        case RD_TRACE_LEAF: return c->trace_leaves;
+        case RD_TRACE_NODE: return c->trace_nodes;
+        case RD_TRACE_UPPER: return c->trace_upper;
+        case RD_CEVAL: return c->cevals;
+        case RD_C_NODE: return c->cnodes;
+        case RD_C_UPPER: return c->c_upper;
+        case RD_FRI_E: return (int)arg < c->num_fri_layers ? c->fri_e[arg] : nullptr;
+        case RD_FRI_LEAF: return (int)arg < c->num_fri_layers ? c->fri_leaves[arg] : nullptr;
+        case RD_FRI_NODE: return (int)arg < c->num_fri_layers ? c->fri_nodes[arg] : nullptr;
+        case RD_FRI_UPPER: return (int)arg < c->num_fri_layers ? c->fri_upper[arg] : nullptr;
+    }
+    return nullptr;
+}
+}  // namespace
+
+// this rank's items, concatenated in request order
+int dst_shard_open(dst_ctx* c, const uint64_t* positions, uint32_t num_positions, uint8_t* blob, size_t cap, size_t* blob_len, uint64_t* all_lens) {
+    if (!c || !positions || !blob_len) return DST_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    OpenPlan p;
+    int rc = build_open_plan(c, positions, num_positions, 0, p);
+    if (rc) return rc;
+    const int me = (int)c->prm.rank;
+    // group the owned requests by (buffer, arg); the blob keeps request order, so remember where each item goes
+    struct Group { uint32_t buffer, arg, bytes; std::vector<uint64_t> idx; std::vector<size_t> dst; };
+    std::vector<Group> groups;
+    size_t total = 0;
+    for (auto& r : p.reqs) {
+        if (!(r.owner == me || (r.owner < 0 && me == 0))) continue;
+        Group* g = nullptr;
+        for (auto& q : groups) if (q.buffer == r.buffer && q.arg == r.arg) { g = &q; break; }
+        if (!g) { groups.push_back({r.buffer, r.arg, r.bytes, {}, {}}); g = &groups.back(); }
+        g->idx.push_back(r.index); g->dst.push_back(total);
+        total += r.bytes;
+    }
+    *blob_len = total;
+    if (all_lens) {                                        // every rank's share follows from the same plan
+        for (uint32_t g = 0; g < c->prm.world; g++) all_lens[g] = 0;
+        for (auto& r : p.reqs) all_lens[r.owner < 0 ? 0 : r.owner] += r.bytes;
+    }
+    if (!blob) return DST_OK;
+    if (cap < total) { c->err = "dst_shard_open: blob buffer too small"; return DST_ERR_ARG; }
+    // one staging layout: [indices of all groups][items of all groups]
+    size_t idx_bytes = 0, out_bytes = 0;
+    for (auto& g : groups) { idx_bytes += (g.idx.size() * 8 + 15) / 16 * 16; out_bytes += g.idx.size() * (size_t)g.bytes; }
+    if (idx_bytes + out_bytes > c->stage_bytes) { c->err = "dst_shard_open: staging buffer too small"; return DST_ERR_ARG; }
+    std::vector<uint8_t> hidx(idx_bytes), hout(out_bytes);
+    size_t io = 0;
+    for (auto& g : groups) { memcpy(hidx.data() + io, g.idx.data(), g.idx.size() * 8); io += (g.idx.size() * 8 + 15) / 16 * 16; }
+    if (idx_bytes) HIP_TRY(c, hipMemcpyAsync(c->d_stage, hidx.data(), idx_bytes, hipMemcpyHostToDevice, c->stream));
+    io = 0; size_t oo = 0;
+    for (auto& g : groups) {
+        const uint64_t* d_idx = (const uint64_t*)(c->d_stage + io);
+        uint8_t* d_out = c->d_stage + idx_bytes + oo;
+        if (g.buffer == RD_LDE_ROW) k_gather_rows(c, d_idx, g.idx.size(), (fe*)d_out);
+        else {
+            const void* src = read_source(c, g.buffer, g.arg);
+            if (!src) { c->err = "dst_shard_open: buffer not allocated"; return DST_ERR_STATE; }
+            k_gather(c, src, g.bytes, d_idx, g.idx.size(), d_out);
+        }
+        io += (g.idx.size() * 8 + 15) / 16 * 16; oo += g.idx.size() * (size_t)g.bytes;
+    }
+    if (out_bytes) HIP_TRY(c, hipMemcpyAsync(hout.data(), c->d_stage + idx_bytes, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    oo = 0;
+    for (auto& g : groups) for (size_t i = 0; i < g.idx.size(); i++) { memcpy(blob + g.dst[i], hout.data() + oo, g.bytes); oo += g.bytes; }
+    return DST_OK;
+}
+
+// blobs: the ranks' blobs back to back, blob_lens[g] bytes each
+int dst_shard_assemble(dst_ctx* c, const uint64_t* positions, uint32_t num_positions, uint64_t pow_nonce, const uint8_t* blobs, const uint64_t* blob_lens,
+                       uint8_t* out, size_t cap, size_t* out_len) {
+    if (!c || !positions || !blobs || !blob_lens || !out_len) return DST_ERR_ARG;
+    OpenPlan p;
+    int rc = build_open_plan(c, positions, num_positions, pow_nonce, p);
+    if (rc) return rc;
+    const size_t G = c->prm.world;
+    std::vector<size_t> cursor(G, 0), base(G, 0);
+    for (size_t g = 1; g < G; g++) base[g] = base[g - 1] + blob_lens[g - 1];
+    for (size_t i = 0; i < p.reqs.size(); i++) {
+        const size_t g = p.reqs[i].owner < 0 ? 0 : (size_t)p.reqs[i].owner;
+        if (cursor[g] + p.reqs[i].bytes > blob_lens[g]) { c->err = "dst_shard_assemble: a rank's blob is shorter than its share of the openings"; return DST_ERR_ARG; }
+        memcpy(p.w.b.data() + p.slot[i], blobs + base[g] + cursor[g], p.reqs[i].bytes);
+        cursor[g] += p.reqs[i].bytes;
+    }
+    for (size_t g = 0; g < G; g++) if (cursor[g] != blob_lens[g]) { c->err = "dst_shard_assemble: a rank's blob is longer than its share of the openings"; return DST_ERR_ARG; }
+    *out_len = p.w.b.size();
+    if (!out) return DST_OK;
+    if (cap < p.w.b.size()) { c->err = "proof buffer too small"; return DST_ERR_ARG; }
+    memcpy(out, p.w.b.data(), p.w.b.size());
     return DST_OK;
 }
 

@@ -23,7 +23,7 @@ EXPORTS = ["dst_ctx_create", "dst_ctx_destroy", "dst_last_error", "dst_phase_ms"
            "dst_build_proof", "dst_prove", "dst_prng_vector", "dst_query_positions", "dst_blake3", "dst_fibonacci_trace",
            "dst_read_buffer", "dst_bench_mulmod", "dst_set_profiling", "dst_kernel_stats", "dst_field_op",
            "dst_shard_commit_trace", "dst_shard_eval_constraints", "dst_shard_combine", "dst_shard_fri_layer", "dst_shard_fri_fold",
-           "dst_shard_export_size", "dst_shard_export", "dst_shard_import", "dst_shard_read", "dst_shard_info"]
+           "dst_shard_export_size", "dst_shard_export", "dst_shard_import", "dst_shard_read", "dst_shard_open", "dst_shard_assemble", "dst_shard_info"]
 
 
 class DistaffError(RuntimeError):
@@ -288,6 +288,28 @@ class Context:
         item = self.W * 16 if buffer == 10 else (16 if buffer in (3, 6) else 32)
         out = np.zeros(len(indices) * item, dtype=np.uint8)
         self._check(self.lib.dst_shard_read(self._h, ctypes.c_uint32(buffer), ctypes.c_uint32(arg), _ptr(idx), ctypes.c_uint32(len(indices)), _ptr(out)))
+        return out.tobytes()
+
+    def shard_open(self, positions):
+        """-> (this rank's blob of openings, [blob length of every rank])"""
+        pos = np.ascontiguousarray(positions, dtype=np.uint64)
+        ln = ctypes.c_size_t(0)
+        lens = np.zeros(self.params.world, dtype=np.uint64)
+        self._check(self.lib.dst_shard_open(self._h, _ptr(pos), ctypes.c_uint32(len(pos)), None, ctypes.c_size_t(0), ctypes.byref(ln), _ptr(lens)))
+        blob = np.zeros(max(ln.value, 1), dtype=np.uint8)
+        self._check(self.lib.dst_shard_open(self._h, _ptr(pos), ctypes.c_uint32(len(pos)), _ptr(blob), ctypes.c_size_t(ln.value), ctypes.byref(ln), None))
+        return blob[:ln.value], [int(v) for v in lens]
+
+    def shard_assemble(self, positions, nonce, blobs, lens):
+        """blobs: uint8 array holding the ranks' blobs back to back"""
+        pos = np.ascontiguousarray(positions, dtype=np.uint64)
+        bl = np.ascontiguousarray(blobs, dtype=np.uint8)
+        ls = np.ascontiguousarray(lens, dtype=np.uint64)
+        ln = ctypes.c_size_t(0)
+        args = (self._h, _ptr(pos), ctypes.c_uint32(len(pos)), ctypes.c_uint64(nonce), _ptr(bl), _ptr(ls))
+        self._check(self.lib.dst_shard_assemble(*args, None, ctypes.c_size_t(0), ctypes.byref(ln)))
+        out = np.zeros(ln.value, dtype=np.uint8)
+        self._check(self.lib.dst_shard_assemble(*args, _ptr(out), ctypes.c_size_t(ln.value), ctypes.byref(ln)))
         return out.tobytes()
 
     def shard_info(self):

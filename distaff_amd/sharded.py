@@ -184,8 +184,8 @@ class TorchComm:
 
 # ---- the SPMD prover ---------------------------------------------------------------------------------------------------------------------
 class ShardedProver:
-    def __init__(self, ctx, comm):
-        self.ctx, self.comm = ctx, comm
+    def __init__(self, ctx, comm, python_openings=False):
+        self.ctx, self.comm, self.python_openings = ctx, comm, python_openings
         self.G, self.rank = comm.world, comm.rank
         assert ctx.params.world == self.G and ctx.params.rank == self.rank
         self.B, self.n, self.N, self.W = ctx.B, ctx.n, ctx.N, ctx.W
@@ -295,7 +295,19 @@ class ShardedProver:
         seed1, nonce = ctx.pow_grind(seed0, p.grinding_factor)
         positions = L.query_positions(seed1, N, B, p.num_queries)
         self._mark("pow_queries")
-        # step 9: every opening of the proof is requested in ONE batch (the positions are all known by now), then serialised
+        if not self.python_openings:
+            # step 9 behind the C-ABI: every rank plans the same openings, gathers the items it owns (one device gather), the blobs
+            # are all-gathered (padded to the longest; the lengths follow from the plan) and every rank fills the same proof
+            blob, lens = ctx.shard_open(positions)
+            width = max(max(lens), 1)
+            padded = np.zeros(width, dtype=np.uint8)
+            padded[:len(blob)] = blob
+            gathered = np.asarray(comm.all_gather(padded)).view(np.uint8).reshape(G, width)
+            blobs = np.concatenate([gathered[g, :lens[g]] for g in range(G)])
+            proof = ctx.shard_assemble(positions, nonce, blobs, lens)
+            self._mark("openings")
+            return proof
+        # step 9 planned in Python (kept as an independent statement of the same plan; tests compare the two)
         op_count, _, stack_depth = ctx.shard_info()
         reqs = []
 
@@ -382,7 +394,7 @@ class ShardedProver:
                 w.raw(items[o]); o += 1
 
 
-def prove_local(columns, log_n, width, ctx_depth, loop_depth, inputs, outputs, world, device=0, **options):
+def prove_local(columns, log_n, width, ctx_depth, loop_depth, inputs, outputs, world, device=0, python_openings=False, **options):
     """Runs the sharded prover with `world` ranks as threads on ONE device (tests / single-GPU validation of the sharded path)."""
     comms = LocalComm.create(world)
     results, errors = [None] * world, [None] * world
@@ -391,7 +403,7 @@ def prove_local(columns, log_n, width, ctx_depth, loop_depth, inputs, outputs, w
         try:
             ctx = L.Context(log_n, width, ctx_depth, loop_depth, device=device, rank=rank, world=world, **options)
             ctx.upload(columns)
-            results[rank] = ShardedProver(ctx, comms[rank]).prove(inputs, outputs)
+            results[rank] = ShardedProver(ctx, comms[rank], python_openings).prove(inputs, outputs)
             ctx.close()
         except BaseException as e:      # noqa: BLE001 -- surfaced below; break the barrier so the other ranks do not hang
             errors[rank] = e

@@ -126,6 +126,14 @@ int dst_shard_import(dst_ctx* ctx, uint32_t what, uint32_t arg, const void* src,
  * evaluations (elements), 4 constraint local nodes, 5 constraint upper nodes, 6 FRI layer `arg` evaluations (elements), 7 FRI leaves,
  * 8 FRI local nodes, 9 FRI upper nodes, 10 LDE rows (idx = natural positions owned by this rank, W elements each). */
 int dst_shard_read(dst_ctx* ctx, uint32_t buffer, uint32_t arg, const uint64_t* idx, uint32_t count, uint8_t* out);
+/* Step 9 across ranks (prover.rs:143-165; merkle.rs:64-124 prove_batch; fri/prover.rs:55-96 build_proof).  Every rank derives the
+ * same ordered list of openings from the query positions.  dst_shard_open returns the items THIS rank owns, concatenated in that
+ * order (blob == NULL: only the sizes; all_lens, if not NULL, receives every rank's blob length, `world` entries);
+ * dst_shard_assemble takes the blobs of all ranks back to back (blob_lens[g] bytes each) and writes the serialised StarkProof
+ * (proof.rs:11-77, bincode as src/main.rs:44) -- identical bytes on every rank. */
+int dst_shard_open(dst_ctx* ctx, const uint64_t* positions, uint32_t num_positions, uint8_t* blob, size_t cap, size_t* blob_len, uint64_t* all_lens);
+int dst_shard_assemble(dst_ctx* ctx, const uint64_t* positions, uint32_t num_positions, uint64_t pow_nonce, const uint8_t* blobs,
+                       const uint64_t* blob_lens, uint8_t* out, size_t cap, size_t* out_len);
 int dst_shard_info(dst_ctx* ctx, uint64_t* op_count, uint32_t* num_fri_layers, uint32_t* stack_depth);
 
 /* ---- inspection (tests and profiling): copies an internal device buffer to the host.  `what` ids are listed in

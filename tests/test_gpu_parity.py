@@ -201,9 +201,10 @@ def test_sharded_prover_equals_single_gpu(oracle, world):
         t = O.fibonacci_trace(1 << log_n)
         op = O.Prover.from_trace(t, 1, ext=1 << log_b, num_queries=nq, grinding=10)
         expected = op.prove()
-        proofs = sharded.prove_local(t.columns, log_n, t.width, t.ctx_depth, t.loop_depth, t.public_inputs, op.outputs, world,
-                                     log_blowup=log_b, num_queries=nq, grinding=10)
-        assert all(p == expected for p in proofs), (world, log_n, log_b)
+        for python_openings in (False, True):                 # openings planned behind the C-ABI / by the Python statement of the plan
+            proofs = sharded.prove_local(t.columns, log_n, t.width, t.ctx_depth, t.loop_depth, t.public_inputs, op.outputs, world,
+                                         python_openings=python_openings, log_blowup=log_b, num_queries=nq, grinding=10)
+            assert all(p == expected for p in proofs), (world, log_n, log_b, python_openings)
 
 
 def test_sharded_prover_reports_invalid_trace(oracle):
