@@ -281,3 +281,41 @@ def test_lde_every_tile_length(oracle, monkeypatch, family, log_n, log_blowup):
     for i in [1, B - 1, B, n * B - 1] + [int(v) for v in rng.integers(0, n * B, size=samples)]:
         assert O.poly_eval(poly, O.exp(g_N, i)) == O.to_ints(lde[i:i + 1])[0], ("extension", i)
     assert (lde[::B] == cols[c]).all()                                 # coset 0 of the extension is the trace itself
+
+
+def test_config3_full_size_proof_is_accepted_and_tamper_evident(oracle):
+    """BASELINE config 3 at full size (2^20-step Fibonacci trace, default ProofOptions).  The oracle cannot produce this proof in
+    seconds, so the checks are size-independent: the oracle's restatement of the reference verifier accepts the GPU proof for the
+    right public data, and rejects it for a wrong output, a wrong program hash and a flipped byte, with the reference's error strings."""
+    import distaff_amd as D
+    O = oracle
+    cols, program_hash, result = D.fibonacci_trace(20)
+    ctx = D.Context(20, 20, 1, 0)
+    ctx.upload(cols)
+    proof = ctx.prove([1, 0], [result])
+    again = ctx.prove([1, 0], [result])
+    ctx.close()
+    assert proof == again                                            # deterministic
+    ok, err = O.verify(proof, program_hash, [1, 0], [result])
+    assert ok, err
+    ok, err = O.verify(proof, program_hash, [1, 0], [result + 1])
+    assert not ok and "verification of low-degree proof failed" in err
+    ok, err = O.verify(proof, bytes(32), [1, 0], [result])
+    assert not ok
+    bad = bytearray(proof); bad[40] ^= 1
+    ok, err = O.verify(bytes(bad), program_hash, [1, 0], [result])
+    assert not ok
+
+
+def test_fibonacci_2_16_proof_bytes_equal_oracle(oracle):
+    """Largest size at which the oracle's own prover finishes in about ten seconds: byte-identical proofs, default ProofOptions."""
+    import distaff_amd as D
+    O = oracle
+    t = O.fibonacci_trace(1 << 16)
+    expected = O.Prover.from_trace(t, 1).prove()
+    cols, program_hash, result = D.fibonacci_trace(16)
+    assert (cols == t.columns).all()                                 # the library's own trace generator (host_vm.h) against the oracle VM
+    ctx = D.Context(16, 20, 1, 0)
+    ctx.upload(cols)
+    assert ctx.prove([1, 0], [result]) == expected
+    ctx.close()
