@@ -53,15 +53,16 @@ __device__ __forceinline__ fe dpow(const AirArgs& a, uint64_t e) {
 __device__ __forceinline__ fe bnot(const fe& v) { return fe_sub(fe_one(), v); }
 __device__ __forceinline__ fe is_bin(const fe& v) { return fe_sub(fe_sqr(v), v); }
 
+// MDS matrix times state: every row is a sum of Wd products with one reduction (fe_acc)
 template <int Wd>
 __device__ __forceinline__ void matmul(fe* s, const fe* m) {
     fe r[Wd];
 #pragma unroll
     for (int i = 0; i < Wd; i++) {
-        fe acc = fe_mul(m[i * Wd], s[0]);
+        fe_acc A; fe_acc_zero(A);
 #pragma unroll
-        for (int j = 1; j < Wd; j++) acc = fe_add(acc, fe_mul(m[i * Wd + j], s[j]));
-        r[i] = acc;
+        for (int j = 0; j < Wd; j++) fe_acc_mac(A, m[i * Wd + j], s[j]);
+        r[i] = fe_acc_reduce(A);
     }
 #pragma unroll
     for (int i = 0; i < Wd; i++) s[i] = r[i];
@@ -142,8 +143,9 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
 #pragma unroll 1
         for (int pass = 0; pass < 2; pass++) {
             const fe* cc = a.coef + pass * 94;
-            fe res = fe_zero(), adj = fe_zero();
-            auto term = [&](const fe& v, uint32_t idx) { res = fe_add(res, fe_mul(v, cc[idx])); adj = fe_add(adj, fe_mul(v, cc[idx + 1])); };
+            // two sums of ~25 products each, reduced once (fe_acc)
+            fe_acc R, A; fe_acc_zero(R); fe_acc_zero(A);
+            auto term = [&](const fe& v, uint32_t idx) { fe_acc_mac(R, v, cc[idx]); fe_acc_mac(A, v, cc[idx + 1]); };
             term(pass ? fe_sub(c_opc, a.op_count) : c_opc, 0);
             if (pass == 0) { for (int i = 0; i < 4; i++) term(c_sp[i], 2 + 2 * i); }
             else { for (int i = 0; i < 2; i++) term(fe_sub(c_sp[i], a.program_hash[i]), 2 + 2 * i); }
@@ -155,8 +157,9 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
             const uint32_t nio = pass ? a.num_outputs : a.num_inputs;
 #pragma unroll
             for (int i = 0; i < 8; i++) if ((uint32_t)i < nio) term(fe_sub(o[i], pass ? a.outputs[i] : a.inputs[i]), 78 + 2 * i);
-            res = fe_add(res, fe_mul(adj, xp));
-            a.out[((size_t)pass * gridDim.y + ql) * a.n + k] = res;
+            const fe adj = fe_acc_reduce(A);
+            fe_acc_mac(R, adj, xp);
+            a.out[((size_t)pass * gridDim.y + ql) * a.n + k] = fe_acc_reduce(R);
         }
     }
 

@@ -236,6 +236,102 @@ __device__ __forceinline__ fe fe_mul_gfx950(const fe& a, const fe& b) {
 #undef FE_HI
     return c ? fe_make(z0, z1, z2, z3) : fe_make(y0, y1, y2, y3);
 }
+
+// ---- sums of products with ONE reduction ----------------------------------------------------------------------------------------
+// A dot product sum_i a_i * b_i accumulates the 256-bit partial products in the same even/odd 64-bit windows as fe_mul (every
+// accumulating mad counts its carry-out) and folds once at the end: 32 instructions per term + one reduction instead of a full
+// multiplication (89) and a modular addition (14) per term.  Up to 64 terms (the overflow limb stays below 2^7).
+struct fe_acc {
+    uint64_t E0, E1, E2, E3, O0, O1, O2;              // windows at limbs 0, 2, 4, 6 and 1, 3, 5
+    uint32_t cE0, cE1, cE2, cE3, cO0, cO1, cO2;       // 2^64 overflows of each window
+};
+__device__ __forceinline__ void fe_acc_zero(fe_acc& A) {
+    A.E0 = A.E1 = A.E2 = A.E3 = A.O0 = A.O1 = A.O2 = 0;
+    A.cE0 = A.cE1 = A.cE2 = A.cE3 = A.cO0 = A.cO1 = A.cO2 = 0;
+}
+__device__ __forceinline__ void fe_acc_mac(fe_acc& A, const fe& a, const fe& b) {
+    fe_mac_c(A.E0, A.cE0, a.v[0], b.v[0]);
+    fe_mac_c(A.E1, A.cE1, a.v[0], b.v[2]); fe_mac_c(A.E1, A.cE1, a.v[1], b.v[1]); fe_mac_c(A.E1, A.cE1, a.v[2], b.v[0]);
+    fe_mac_c(A.E2, A.cE2, a.v[1], b.v[3]); fe_mac_c(A.E2, A.cE2, a.v[2], b.v[2]); fe_mac_c(A.E2, A.cE2, a.v[3], b.v[1]);
+    fe_mac_c(A.E3, A.cE3, a.v[3], b.v[3]);
+    fe_mac_c(A.O0, A.cO0, a.v[0], b.v[1]); fe_mac_c(A.O0, A.cO0, a.v[1], b.v[0]);
+    fe_mac_c(A.O1, A.cO1, a.v[0], b.v[3]); fe_mac_c(A.O1, A.cO1, a.v[1], b.v[2]); fe_mac_c(A.O1, A.cO1, a.v[2], b.v[1]); fe_mac_c(A.O1, A.cO1, a.v[3], b.v[0]);
+    fe_mac_c(A.O2, A.cO2, a.v[2], b.v[3]); fe_mac_c(A.O2, A.cO2, a.v[3], b.v[2]);
+}
+// adds a field element (weight 1) to the sum
+__device__ __forceinline__ void fe_acc_add(fe_acc& A, const fe& a) {
+    fe_mac_c(A.E0, A.cE0, a.v[0], 1u); fe_mac_c(A.O0, A.cO0, a.v[1], 1u); fe_mac_c(A.E1, A.cE1, a.v[2], 1u); fe_mac_c(A.O1, A.cO1, a.v[3], 1u);
+}
+__device__ __forceinline__ fe fe_acc_reduce(const fe_acc& A) {
+#define FE_LO(x) ((uint32_t)(x))
+#define FE_HI(x) ((uint32_t)((x) >> 32))
+    uint32_t t0, t1, t2, t3, t4, t5, t6, t7, t8, c, bw;
+    t0 = FE_LO(A.E0);
+    t1 = fe_addc(FE_HI(A.E0), FE_LO(A.O0), 0, &c);
+    t2 = fe_addc(FE_LO(A.E1), FE_HI(A.O0), c, &c);
+    t3 = fe_addc(FE_HI(A.E1), FE_LO(A.O1), c, &c);
+    t4 = fe_addc(FE_LO(A.E2), FE_HI(A.O1), c, &c);
+    t5 = fe_addc(FE_HI(A.E2), FE_LO(A.O2), c, &c);
+    t6 = fe_addc(FE_LO(A.E3), FE_HI(A.O2), c, &c);
+    t7 = fe_addc(FE_HI(A.E3), 0, c, &c);
+    t8 = c;
+    t2 = fe_addc(t2, A.cE0, 0, &c);
+    t3 = fe_addc(t3, A.cO0, c, &c);
+    t4 = fe_addc(t4, A.cE1, c, &c);
+    t5 = fe_addc(t5, A.cO1, c, &c);
+    t6 = fe_addc(t6, A.cE2, c, &c);
+    t7 = fe_addc(t7, A.cO2, c, &c);
+    t8 = t8 + A.cE3 + c;
+    // fold 1: v = lo + ((hi * K) << 32) - hi, hi = t8:t7:t6:t5:t4 < 2^135
+    uint64_t P0 = (uint64_t)t4 * FE_K, P1 = (uint64_t)t5 * FE_K, P2 = (uint64_t)t6 * FE_K, P3 = (uint64_t)t7 * FE_K, P4 = (uint64_t)t8 * FE_K;
+    uint32_t u1, u2, u3, u4, u5;
+    u1 = fe_addc(t1, FE_LO(P0), 0, &c);
+    u2 = fe_addc(t2, FE_LO(P1), c, &c);
+    u3 = fe_addc(t3, FE_LO(P2), c, &c);
+    u4 = fe_addc(FE_LO(P3), 0, c, &c);
+    u5 = FE_LO(P4) + c;                                  // P4 < 2^21: no carry out
+    u2 = fe_addc(u2, FE_HI(P0), 0, &c);
+    u3 = fe_addc(u3, FE_HI(P1), c, &c);
+    u4 = fe_addc(u4, FE_HI(P2), c, &c);
+    u5 = u5 + FE_HI(P3) + c;                             // < 2^22 + 2^14
+    uint32_t v0, v1, v2, v3, v4, v5;
+    v0 = fe_subb(t0, t4, 0, &bw);
+    v1 = fe_subb(u1, t5, bw, &bw);
+    v2 = fe_subb(u2, t6, bw, &bw);
+    v3 = fe_subb(u3, t7, bw, &bw);
+    v4 = fe_subb(u4, t8, bw, &bw);
+    v5 = u5 - bw;
+    // fold 2: y = v_lo + ((V * K) << 32) - V, V = v5:v4 < 2^54, V * K = w0 + x0 * 2^32 + x1 * 2^64
+    uint64_t w = (uint64_t)v4 * FE_K;
+    uint64_t x = (uint64_t)v5 * FE_K + FE_HI(w);
+    uint32_t y0, y1, y2, y3, y4;
+    y1 = fe_addc(v1, FE_LO(w), 0, &c);
+    y2 = fe_addc(v2, FE_LO(x), c, &c);
+    y3 = fe_addc(v3, FE_HI(x), c, &c);
+    y4 = c;
+    y0 = fe_subb(v0, v4, 0, &bw);
+    y1 = fe_subb(y1, v5, bw, &bw);
+    y2 = fe_subb(y2, 0, bw, &bw);
+    y3 = fe_subb(y3, 0, bw, &bw);
+    y4 = y4 - bw;
+    // fold 3 + canonical form (see fe_mul_gfx950)
+    uint32_t z0, z1, z2, z3;
+    z0 = fe_addc(y0, FE_C0, 0, &c);
+    z1 = fe_addc(y1, FE_C1, c, &c);
+    z2 = fe_addc(y2, 0, c, &c);
+    z3 = fe_addc(y3, 0, c, &c);
+    c |= y4;
+#undef FE_LO
+#undef FE_HI
+    return c ? fe_make(z0, z1, z2, z3) : fe_make(y0, y1, y2, y3);
+}
+#else
+// host pass of the same translation units: same interface, plain modular arithmetic (never on a hot path)
+struct fe_acc { fe sum; };
+FE_HD void fe_acc_zero(fe_acc& A) { A.sum = fe_zero(); }
+FE_HD void fe_acc_mac(fe_acc& A, const fe& a, const fe& b) { A.sum = fe_add(A.sum, fe_mul_portable(a, b)); }
+FE_HD void fe_acc_add(fe_acc& A, const fe& a) { A.sum = fe_add(A.sum, a); }
+FE_HD fe fe_acc_reduce(const fe_acc& A) { return A.sum; }
 #endif
 
 FE_HD fe fe_mul(const fe& a, const fe& b) {

@@ -376,6 +376,13 @@ __global__ void field_op_kernel(int op, const fe* a, const fe* b, fe* out, size_
         case 3: r = fe_mul_portable(x, y); break;
         case 4: r = fe_inv(x); break;
         case 5: r = fe_pow(x, y); break;
+        case 6: {   // sum_{j<40} a[(i + j) % count] * b[(i + 7j) % count] + a[i], one reduction (fe_acc)
+            fe_acc A; fe_acc_zero(A);
+            for (size_t j = 0; j < 40; j++) fe_acc_mac(A, a[(i + j) % count], b[(i + 7 * j) % count]);
+            fe_acc_add(A, x);
+            r = fe_acc_reduce(A);
+            break;
+        }
         default: r = fe_zero();
     }
     out[i] = r;

@@ -327,7 +327,7 @@ class Context:
         return json.loads(buf.value.decode())
 
     def field_op(self, op, a, b):
-        ops = {"add": 0, "sub": 1, "mul": 2, "mul_portable": 3, "inv": 4, "pow": 5}
+        ops = {"add": 0, "sub": 1, "mul": 2, "mul_portable": 3, "inv": 4, "pow": 5, "dot40": 6}
         a = np.ascontiguousarray(a, dtype=np.uint64); b = np.ascontiguousarray(b, dtype=np.uint64)
         out = np.zeros_like(a)
         self._check(self.lib.dst_field_op(self._h, ops[op], _ptr(a), _ptr(b), _ptr(out), ctypes.c_size_t(a.shape[0])))

@@ -186,6 +186,12 @@ def test_device_field_arithmetic(oracle):
     assert D.arr_to_ints(ctx.field_op("sub", A, B)) == [(x - y) % P for x, y in zip(a, b)]
     assert D.arr_to_ints(ctx.field_op("inv", A[:300], B[:300])) == [pow(x, P - 2, P) for x in a[:300]]
     assert D.arr_to_ints(ctx.field_op("pow", A[:300], B[:300])) == [pow(x, y, P) if x else 0 for x, y in zip(a[:300], b[:300])]
+    # sums of 40 products + one element with a single reduction (fe_acc), incl. the all-maximal case
+    n = 20000
+    want = [(sum(a[(i + j) % n] * b[(i + 7 * j) % n] for j in range(40)) + a[i]) % P for i in range(n)]
+    assert D.arr_to_ints(ctx.field_op("dot40", A[:n], B[:n])) == want
+    top = D.ints_to_arr([P - 1] * 256)
+    assert D.arr_to_ints(ctx.field_op("dot40", top, top)) == [(40 * (P - 1) * (P - 1) + P - 1) % P] * 256
     ctx.close()
 
 
