@@ -457,17 +457,20 @@ void k_lde_columns(dst_ctx* c, const fe* polys, fe* lde, size_t ncols) {
 // d_j[m0] = w_N^(j*m0) * sum_{m1<8} c[m0 + n*m1] * w_B^(j*m1); followed by a plain size-n NTT per coset.
 __global__ void fold8_kernel(const fe* __restrict__ poly, fe* __restrict__ out, const fe* tw_lo, const fe* tw_hi, uint32_t lo_bits,
                              uint32_t log_n, uint32_t log_N, uint32_t j0) {
+    // the eight factors w_B^(j*m1) depend on the coset only: one lane each forms them, the workgroup reads them from LDS
+    __shared__ fe cj[8];
     const size_t n = (size_t)1 << log_n;
     const uint64_t nmask = ((uint64_t)1 << log_N) - 1;
+    const uint32_t jg = j0 + blockIdx.y;
+    if (threadIdx.x < 8) cj[threadIdx.x] = dom_pow(tw_lo, tw_hi, lo_bits, ((uint64_t)jg * threadIdx.x << log_n) & nmask);
+    __syncthreads();
     size_t m0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m0 >= n) return;
-    uint32_t jg = j0 + blockIdx.y;
-    fe acc = poly[m0];
-    for (uint32_t m1 = 1; m1 < 8; m1++) {
-        uint64_t e = ((uint64_t)jg * m1 << log_n) & nmask;
-        fe v = poly[m0 + n * m1];
-        acc = fe_add(acc, e ? fe_mul(v, dom_pow(tw_lo, tw_hi, lo_bits, e)) : v);
-    }
+    fe_acc A; fe_acc_zero(A);                        // eight products, one reduction
+    fe_acc_add(A, poly[m0]);
+#pragma unroll
+    for (uint32_t m1 = 1; m1 < 8; m1++) fe_acc_mac(A, poly[m0 + n * m1], cj[m1]);
+    fe acc = fe_acc_reduce(A);
     uint64_t e0 = ((uint64_t)jg * m0) & nmask;
     if (e0) acc = fe_mul(acc, dom_pow(tw_lo, tw_hi, lo_bits, e0));
     out[(size_t)blockIdx.y * n + m0] = acc;
