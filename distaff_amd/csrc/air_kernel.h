@@ -14,6 +14,7 @@
 // so a wavefront reads 64 consecutive elements of each register -- unit stride, no halo.
 #pragma once
 #include "ctx.h"
+#include <type_traits>
 
 #define AIR_THREADS 128
 #ifndef AIR_WAVES_PER_SIMD
@@ -66,6 +67,137 @@ __device__ __forceinline__ void matmul(fe* s, const fe* m) {
     }
 #pragma unroll
     for (int i = 0; i < Wd; i++) s[i] = r[i];
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for_air(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for_air<I + 1, N>(f); }
+}
+
+// ---- low-degree stack operations as nested sums (stack depth 4) ---------------------------------------------------------------
+// The flag of low-degree operation `op` is lo2[op & 3] * mid[(op >> 2) & 3] * top[op >> 4] (trace_state.rs:281-350), and every
+// stack constraint is sum_op flag(op) * term(op, slot) (constraints/stack/mod.rs:117-195).  Written as
+//     sum_c top[c] * ( sum_b mid[b] * ( sum_a lo2[a] * term(a + 4b + 16c, slot) ) )
+// the 32 flags are never formed and every level is a sum of products with one reduction (fe_acc): ~13k instructions per point
+// instead of ~21k for flag products + per-term multiply-adds.  st_term states, per operation and slot, exactly what the
+// per-operation code below passes to agg(): slots 0..3 are the stack constraints, 4 and 5 the two auxiliary constraints.
+struct StackRows { fe o[8], nw[8], hd0; };
+
+template <int OP, int I> constexpr bool st_has() {
+    constexpr bool slot = I < 4, aux0 = I == 4, aux1 = I == 5;
+    switch (OP) {
+        case 0x00: case 0x01: case 0x05: case 0x06: case 0x07: return slot || aux0;       // ASSERT, ASSERTEQ, CHOOSE, CHOOSE2, CSWAP2
+        case 0x02: case 0x0E: return slot || aux0;                                       // EQ, NOT
+        case 0x03: case 0x04: case 0x08: case 0x09: case 0x0C: case 0x0D: return slot;   // DROP, DROP4, ADD, MUL, INV, NEG
+        case 0x0A: case 0x0B: return slot || aux0 || aux1;                               // AND, OR
+        case 0x10: return I >= 1 && slot;                                                // READ
+        case 0x11: return I >= 2 && slot;                                                // READ2
+        case 0x12: case 0x13: case 0x14: case 0x15: return slot;                         // DUP, DUP2, DUP4, PAD2
+        case 0x18: return I == 0 || I == 2 || I == 3;                                    // SWAP: both constraints in slot 0 (manipulation.rs:63-64)
+        case 0x19: case 0x1A: case 0x1B: case 0x1C: case 0x1D: return slot;              // SWAP2, SWAP4, ROLL4, ROLL8, BINACC
+        default: return false;
+    }
+}
+
+template <int OP, int I>
+__device__ __forceinline__ fe st_term(const StackRows& s) {
+    const fe* o = s.o; const fe* nw = s.nw;
+    constexpr int i = I < 4 ? I : 0;
+    auto L = [&](int num) { return fe_sub(o[i + num], nw[i]); };          // left shift by num
+    auto R = [&](int num) { return fe_sub(o[i - num < 0 ? 0 : i - num], nw[i]); };   // right shift by num
+    auto C = [&]() { return fe_sub(o[i], nw[i]); };                       // copy
+    if constexpr (OP == 0x00) { if constexpr (I == 4) return fe_mul(s.hd0, bnot(o[0])); else return fe_mul(s.hd0, L(1)); }   // ASSERT flag carries hd[0] (trace_state.rs:346)
+    else if constexpr (OP == 0x01) { if constexpr (I == 4) return fe_sub(o[0], o[1]); else return L(2); }
+    else if constexpr (OP == 0x02) {
+        const fe diff = fe_sub(o[1], o[2]);
+        if constexpr (I == 4) return fe_mul(nw[0], diff);
+        else if constexpr (I == 0) return fe_sub(nw[0], bnot(fe_mul(diff, o[0])));
+        else return L(2);
+    }
+    else if constexpr (OP == 0x03) return L(1);
+    else if constexpr (OP == 0x04) return L(4);
+    else if constexpr (OP == 0x05) {
+        if constexpr (I == 4) return is_bin(o[2]);
+        else if constexpr (I == 0) return fe_sub(nw[0], fe_add(fe_mul(o[2], o[0]), fe_mul(bnot(o[2]), o[1])));
+        else return L(2);
+    }
+    else if constexpr (OP == 0x06) {
+        if constexpr (I == 4) return is_bin(o[4]);
+        else if constexpr (I == 0) return fe_sub(nw[0], fe_add(fe_mul(o[4], o[0]), fe_mul(bnot(o[4]), o[2])));
+        else if constexpr (I == 1) return fe_sub(nw[1], fe_add(fe_mul(o[4], o[1]), fe_mul(bnot(o[4]), o[3])));
+        else return L(4);
+    }
+    else if constexpr (OP == 0x07) {
+        if constexpr (I == 4) return is_bin(o[4]);
+        else if constexpr (I == 0) return fe_sub(nw[0], fe_add(fe_mul(o[4], o[2]), fe_mul(bnot(o[4]), o[0])));
+        else if constexpr (I == 1) return fe_sub(nw[1], fe_add(fe_mul(o[4], o[3]), fe_mul(bnot(o[4]), o[1])));
+        else if constexpr (I == 2) return fe_sub(nw[2], fe_add(fe_mul(o[4], o[0]), fe_mul(bnot(o[4]), o[2])));
+        else return fe_sub(nw[3], fe_add(fe_mul(o[4], o[1]), fe_mul(bnot(o[4]), o[3])));
+    }
+    else if constexpr (OP == 0x08) { if constexpr (I == 0) return fe_sub(nw[0], fe_add(o[0], o[1])); else return L(1); }
+    else if constexpr (OP == 0x09) { if constexpr (I == 0) return fe_sub(nw[0], fe_mul(o[0], o[1])); else return L(1); }
+    else if constexpr (OP == 0x0A) {
+        if constexpr (I == 4) return is_bin(o[0]);
+        else if constexpr (I == 5) return is_bin(o[1]);
+        else if constexpr (I == 0) return fe_sub(nw[0], fe_mul(o[0], o[1]));
+        else return L(1);
+    }
+    else if constexpr (OP == 0x0B) {
+        if constexpr (I == 4) return is_bin(o[0]);
+        else if constexpr (I == 5) return is_bin(o[1]);
+        else if constexpr (I == 0) return fe_sub(nw[0], bnot(fe_mul(bnot(o[0]), bnot(o[1]))));
+        else return L(1);
+    }
+    else if constexpr (OP == 0x0C) { if constexpr (I == 0) return fe_sub(fe_one(), fe_mul(nw[0], o[0])); else return C(); }
+    else if constexpr (OP == 0x0D) { if constexpr (I == 0) return fe_add(nw[0], o[0]); else return C(); }
+    else if constexpr (OP == 0x0E) {
+        if constexpr (I == 4) return is_bin(o[0]);
+        else if constexpr (I == 0) return fe_sub(nw[0], bnot(o[0]));
+        else return C();
+    }
+    else if constexpr (OP == 0x10) return R(1);
+    else if constexpr (OP == 0x11) return R(2);
+    else if constexpr (OP == 0x12) { if constexpr (I == 0) return fe_sub(nw[0], o[0]); else return R(1); }
+    else if constexpr (OP == 0x13) { if constexpr (I < 2) return fe_sub(nw[i], o[i]); else return R(2); }
+    else if constexpr (OP == 0x14) return fe_sub(nw[i], o[i]);
+    else if constexpr (OP == 0x15) { if constexpr (I < 2) return nw[i]; else return R(2); }
+    else if constexpr (OP == 0x18) { if constexpr (I == 0) return fe_add(fe_sub(nw[0], o[1]), fe_sub(nw[1], o[0])); else return C(); }
+    else if constexpr (OP == 0x19) return fe_sub(nw[i], o[i ^ 2]);
+    else if constexpr (OP == 0x1A) return fe_sub(nw[i], o[4 + i]);
+    else if constexpr (OP == 0x1B) return fe_sub(nw[i], o[(i + 3) & 3]);
+    else if constexpr (OP == 0x1C) return fe_sub(nw[i], o[(i + 7) & 7]);
+    else if constexpr (OP == 0x1D) {
+        if constexpr (I == 0) return is_bin(nw[0]);
+        else if constexpr (I == 1) return nw[1];
+        else if constexpr (I == 2) return fe_sub(nw[2], fe_double(o[2]));
+        else return fe_sub(nw[3], fe_add(o[3], fe_mul(nw[0], o[2])));
+    }
+    else return fe_zero();
+}
+
+// slot I of the low-degree part: the three nested sums
+template <int I>
+__device__ __forceinline__ fe st_low_degree(const StackRows& s, const fe* lo2, const fe* mid, const fe* top) {
+    fe_acc outer; fe_acc_zero(outer);
+    static_for_air<0, 2>([&](auto c_) {
+        constexpr int c = decltype(c_)::value;
+        fe_acc middle; fe_acc_zero(middle);
+        static_for_air<0, 4>([&](auto b_) {
+            constexpr int b = decltype(b_)::value;
+            constexpr int base = 4 * b + 16 * c;
+            constexpr bool any = st_has<base, I>() || st_has<base + 1, I>() || st_has<base + 2, I>() || st_has<base + 3, I>();
+            if constexpr (any) {
+                fe_acc inner; fe_acc_zero(inner);
+                static_for_air<0, 4>([&](auto a_) {
+                    constexpr int a = decltype(a_)::value;
+                    if constexpr (st_has<base + a, I>()) fe_acc_mac(inner, lo2[a], st_term<base + a, I>(s));
+                });
+                fe_acc_mac(middle, mid[b], fe_acc_reduce(inner));
+            }
+        });
+        fe_acc_mac(outer, top[c], fe_acc_reduce(middle));
+    });
+    return fe_acc_reduce(outer);
 }
 
 // degree-group slots: 2->0 3->1 4->2 6->3 7->4 8->5
@@ -317,7 +449,20 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
             }
         };
         fe f;
-        if constexpr ((SECT & 8) != 0) {
+        if constexpr (SD == 4 && (SECT & 8) != 0) {
+            // stack depth 4: all low-degree operations (both halves) as nested sums, see st_low_degree
+            StackRows rows;
+#pragma unroll
+            for (int i = 0; i < 8; i++) { rows.o[i] = o[i]; rows.nw[i] = nw[i]; }
+            rows.hd0 = hd[0];
+            ev[0] = st_low_degree<0>(rows, lo2, mid, top);
+            ev[1] = st_low_degree<1>(rows, lo2, mid, top);
+            ev[2] = st_low_degree<2>(rows, lo2, mid, top);
+            ev[3] = st_low_degree<3>(rows, lo2, mid, top);
+            aux0 = st_low_degree<4>(rows, lo2, mid, top);
+            aux1 = st_low_degree<5>(rows, lo2, mid, top);
+        }
+        if constexpr (SD != 4 && (SECT & 8) != 0) {
         // flags that only shift / copy are merged before the multiplications
         // right shift by 1: READ (0x10), DUP (0x12)  (PUSH is with the high-degree ops)
         f = LDF(0x12); agg(0, f, fe_sub(nw[0], o[0]));
@@ -358,7 +503,7 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
         for (int i = 1; i < 8; i++) agg(i, f, fe_sub(nw[i], o[i - 1]));
         copy_from(8, f);
         }   // low-degree ops that only move stack items
-        if constexpr ((SECT & 32) != 0) {
+        if constexpr (SD != 4 && (SECT & 32) != 0) {
         // ADD (0x08), MUL (0x09), AND (0x0A), OR (0x0B): left shift (2,1)
         {
             fe xy = fe_mul(o[0], o[1]);
