@@ -5,7 +5,5 @@ void air_launch_sd4(dst_ctx* c, const AirArgs& a, uint32_t Q) {
     launch_air<2, 1, 4, 8, 2, true, false>(c, a, Q);      // op bits (starts the partial sums)
     launch_air<2, 1, 4, 8, 1, false, false>(c, a, Q);     // boundary constraints (own outputs, no partial sums)
     launch_air<2, 1, 4, 8, 4, false, false>(c, a, Q);     // sponge, loop image, context / loop stacks
-    launch_air<2, 1, 4, 8, 8, false, false>(c, a, Q);     // stack: all low-degree ops (nested sums, air_kernel.h st_low_degree)
-    launch_air<2, 1, 4, 8, 16, false, false>(c, a, Q);    // stack: PUSH, CMP, BEGIN / NOOP
-    launch_air<2, 1, 4, 8, 64, false, true>(c, a, Q);     // stack: RESCR + combination
+    launch_air<2, 1, 4, 8, 88, false, true>(c, a, Q);     // stack: low-degree ops as nested sums (st_low_degree), PUSH, CMP, BEGIN / NOOP, RESCR + combination
 }
