@@ -69,7 +69,7 @@ static std::vector<fe> build_periodic_table() {
 }
 
 static void free_all(dst_ctx* c) {
-    void* ptrs[] = {c->tw_lo, c->tw_hi, c->itw_lo, c->itw_hi, c->w1f, c->w2f, c->w1i, c->w2i, c->prescale, c->periodic, c->trace, c->polys, c->lde, c->tmp,
+    void* ptrs[] = {c->tw_lo, c->tw_hi, c->itw_lo, c->itw_hi, c->w1f, c->w2f, c->w1i, c->w2i, c->prescale, c->tw4_lde, c->tw4_fwd, c->tw4_inv, c->periodic, c->trace, c->polys, c->lde, c->tmp,
                     c->trace_leaves, c->trace_nodes, c->air_consts, c->ceval, c->cwork, c->cpoly, c->cevals, c->cnodes, c->comp_poly, c->comp, c->scratch, c->d_u64, c->d_stage};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->gather_buf) hipFree(c->gather_buf);
@@ -145,6 +145,9 @@ static int ctx_init(dst_ctx* c) {
     if ((r = dev_upload(c, &c->w1i, h_powers(h_inv(w1), (size_t)1 << (pl.log_n1 - 1))))) return r;
     if ((r = dev_upload(c, &c->w2i, h_powers(h_inv(w2), (size_t)1 << (pl.log_n2 - 1))))) return r;
     if ((r = dev_upload(c, &c->prescale, h_powers(h_root_of_unity(c->log_b + pl.log_n1), (size_t)1 << (c->log_b + pl.log_n1))))) return r;
+    if ((r = dev_alloc(c, &c->tw4_lde, c->Bc * c->n))) return r;
+    if ((r = dev_alloc(c, &c->tw4_fwd, c->n))) return r;
+    if ((r = dev_alloc(c, &c->tw4_inv, c->n))) return r;
     if ((r = dev_upload(c, &c->periodic, build_periodic_table()))) return r;
     c->n_inv = fe_from_u128(hf_pow((u128)c->n, FIELD_P - 2));
     c->eight_inv = fe_from_u128(hf_pow(8, FIELD_P - 2));
@@ -187,7 +190,7 @@ static int ctx_init(dst_ctx* c) {
         sz /= 4;
     }
     c->num_fri_layers = d + 1;
-    return DST_OK;
+    return k_build_twiddle_tables(c);
 }
 
 static const fe* as_fe(const uint8_t* p) { return reinterpret_cast<const fe*>(p); }

@@ -68,6 +68,10 @@ struct dst_ctx {
     uint32_t tw_lo_bits = 0;
     fe *w1f = nullptr, *w2f = nullptr, *w1i = nullptr, *w2i = nullptr;   // stage twiddles w_{n1}^t, w_{n2}^t and inverses
     fe *prescale = nullptr;                      // w_{B*n1}^t, t < B*n1
+    // four-step twiddles of pass A as full tables in output order [k1][m2] (one multiplication per element instead of a two-level
+    // lookup + two; the extra 16 B/element read is free: the pass runs at a tenth of the HBM bandwidth)
+    fe *tw4_lde = nullptr;                       // [Bc][n]: w_N^(m2 * (B*k1 + j)), local cosets j
+    fe *tw4_fwd = nullptr, *tw4_inv = nullptr;   // [n]: w_n^(m2*k1) and its inverse
     fe *periodic = nullptr;                      // [128][23] extended Rescue round constants + cycle masks
     void *air_consts = nullptr;                  // AirConsts (Rescue MDS matrices) in device memory
     fe c16f[8], c16i[8];                         // w_16^j and w_16^-j, j < 8 (passed to the NTT kernels by value)
@@ -139,6 +143,7 @@ struct KScope {
 
 // ---- kernel launchers (kernels_*.hip) ------------------------------------------------------------------------------------
 // NTT / LDE
+int k_build_twiddle_tables(dst_ctx* c);                                                 // fills tw4_lde / tw4_fwd / tw4_inv (context creation)
 void k_intt_columns(dst_ctx* c, const fe* src, fe* dst, size_t ncols);                  // size-n inverse NTT of ncols contiguous columns
 void k_lde_columns(dst_ctx* c, const fe* polys, fe* lde, size_t ncols);                 // n coefficients -> coset-major [Bc][n] per column
 void k_lde_fold8(dst_ctx* c, const fe* poly8n, fe* out);                                // 8n coefficients -> coset-major [Bc][n]

@@ -23,11 +23,14 @@ struct NttArgs {
     const fe* stage_tw;        // w_len^t, t < len/2 (forward or inverse)
     const fe* tw_lo; const fe* tw_hi;           // two-level table of the domain generator (forward or inverse, maybe pre-scaled)
     const fe* prescale;        // w_{B*n1}^t or nullptr
+    const fe* tw4;             // four-step twiddles in output order [coset][k1][m2] (coset stride tw4_coset_stride) or nullptr
+    size_t tw4_coset_stride;
     uint32_t log_n1, log_n2, tile /* log2 of the tile width */, lo_bits, log_N, log_b;
     uint32_t j0;               // global index of the first local coset (0 when `coset_twiddle` is off)
     uint32_t coset_twiddle;    // 1: four-step twiddle includes the coset offset j (LDE), 0: plain transform
     uint32_t has_scale;        // 1: multiply the result by `scale` (1/n of inverse transforms)
     uint32_t tiles_per_block;  // adjacent tiles one workgroup walks through
+    uint32_t debug;            // DISTAFF_NTT_DEBUG ablation bits (timing experiments only): 1 no pre-scale, 2 no four-step twiddle
     fe scale;
 };
 
@@ -106,12 +109,14 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_a(NttArgs a, const fe
     const uint32_t pmask = (1u << (a.log_b + a.log_n1)) - 1u;
     const uint64_t nmask = (1ull << a.log_N) - 1ull;
     for (uint32_t i = threadIdx.x; i < n1 / 2; i += NTT_THREADS) TW[i] = a.stage_tw[i];
-    const bool scaled = a.prescale != nullptr && jg != 0;
+    const bool scaled = a.prescale != nullptr && jg != 0 && !(a.debug & 1u);
     fe pre0 = fe_zero(), pre1 = fe_zero(), pre2 = fe_zero(), pre3 = fe_zero(), pre4 = fe_zero(), pre5 = fe_zero(), pre6 = fe_zero(), pre7 = fe_zero();
     const uint32_t count = n1 * T;
 #define NTT_FETCH_A1(e, var, m2_0) { uint32_t idx = threadIdx.x + (e) * NTT_THREADS; idx = idx < count ? idx : 0u; /* branch-free: a lane past the tile re-reads element 0 */ var = src[((size_t)(idx >> log_t) << a.log_n2) + (m2_0) + (idx & (T - 1))]; }
 #define NTT_FETCH_A(tile) { const uint32_t f0 = (tile) * T; NTT_FETCH_A1(0, pre0, f0) NTT_FETCH_A1(1, pre1, f0) NTT_FETCH_A1(2, pre2, f0) NTT_FETCH_A1(3, pre3, f0) \
                                                         NTT_FETCH_A1(4, pre4, f0) NTT_FETCH_A1(5, pre5, f0) NTT_FETCH_A1(6, pre6, f0) NTT_FETCH_A1(7, pre7, f0) }
+    const uint32_t jtw = a.coset_twiddle ? jg : 0u;
+    const fe* __restrict__ tw4 = a.tw4 ? a.tw4 + (size_t)jl * a.tw4_coset_stride : nullptr;
     const uint32_t tile0 = blockIdx.x * a.tiles_per_block;
     NTT_FETCH_A(tile0)
     for (uint32_t it = 0; it < a.tiles_per_block; it++) {
@@ -124,14 +129,29 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_a(NttArgs a, const fe
         __syncthreads();
         if (it + 1 < a.tiles_per_block) NTT_FETCH_A(tile0 + it + 1)
         lds_ntt_dif(L, TW, a.log_n1, log_t);
-        for (uint32_t idx = threadIdx.x; idx < n1 * T; idx += NTT_THREADS) {
-            uint32_t t = idx & (T - 1), r = idx >> log_t;
-            uint32_t k1 = __brev(r) >> (32 - a.log_n1);
-            uint32_t m2 = m2_0 + t;
-            uint64_t e = ((uint64_t)m2 * (((uint64_t)k1 << a.log_b) + (a.coset_twiddle ? jg : 0u))) & nmask;
-            fe v = L[idx];
-            if (e != 0) v = fe_mul(v, dom_pow(a.tw_lo, a.tw_hi, a.lo_bits, e));
-            dst[((size_t)k1 << a.log_n2) + m2] = v;
+        // read-out in batches of four elements per lane: the four twiddle loads are in flight together
+        for (uint32_t base = 0; base < count; base += 4 * NTT_THREADS) {
+            fe v[4], w[4]; uint32_t k1s[4], m2s[4]; bool ok[4], scale[4];
+            static_for<0, 4>([&](auto q_) {
+                constexpr int q = decltype(q_)::value;
+                uint32_t idx = base + q * NTT_THREADS + threadIdx.x;
+                ok[q] = idx < count;
+                idx = ok[q] ? idx : 0u;
+                const uint32_t t = idx & (T - 1), r = idx >> log_t;
+                k1s[q] = __brev(r) >> (32 - a.log_n1);
+                m2s[q] = m2_0 + t;
+                v[q] = L[idx];
+                if (a.debug & 2u) { scale[q] = false; w[q] = fe_one(); }
+                else if (tw4 != nullptr) { scale[q] = (k1s[q] | jtw) != 0 && m2s[q] != 0; w[q] = tw4[((size_t)k1s[q] << a.log_n2) + m2s[q]]; }
+                else {
+                    const uint64_t e = ((uint64_t)m2s[q] * (((uint64_t)k1s[q] << a.log_b) + jtw)) & nmask;
+                    scale[q] = e != 0; w[q] = dom_pow(a.tw_lo, a.tw_hi, a.lo_bits, e);
+                }
+            });
+            static_for<0, 4>([&](auto q_) {
+                constexpr int q = decltype(q_)::value;
+                if (ok[q]) dst[((size_t)k1s[q] << a.log_n2) + m2s[q]] = scale[q] ? fe_mul(v[q], w[q]) : v[q];
+            });
         }
     }
 }
@@ -403,9 +423,11 @@ static void launch_pass_lds(dst_ctx* c, bool pass_b, const fe* src, size_t src_c
     a.tw_hi = inverse ? c->itw_hi : c->tw_hi;
     a.prescale = lde ? c->prescale : nullptr;
     a.has_scale = inverse ? 1u : 0u; a.scale = c->n_inv;
+    { const char* dbg = getenv("DISTAFF_NTT_DEBUG"); a.debug = dbg ? (uint32_t)atoi(dbg) : 0u; }
     a.src = src; a.src_col_stride = src_col_stride; a.src_coset_stride = src_coset_stride;
     a.dst = dst; a.dst_col_stride = dst_col_stride; a.dst_coset_stride = dst_coset_stride;
     if (!pass_b) {
+        a.tw4 = lde ? c->tw4_lde : (inverse ? c->tw4_inv : c->tw4_fwd); a.tw4_coset_stride = lde ? c->n : 0;
         a.stage_tw = inverse ? c->w1i : c->w1f; a.tile = (uint32_t)__builtin_ctz(p.tile_a);
         size_t lds_a = (((size_t)1 << p.log_n1) * p.tile_a + ((size_t)1 << p.log_n1) / 2) * sizeof(fe);
         const uint32_t tiles = (1u << p.log_n2) / p.tile_a;
@@ -430,6 +452,29 @@ static void launch_two_pass(dst_ctx* c, const fe* src, size_t src_col_stride, si
     // pass A: src -> tmp, pass B: tmp -> dst
     (c->plan.reg_a ? launch_pass_reg : launch_pass_lds)(c, false, src, src_col_stride, src_coset_stride, c->tmp, c->n * cosets, c->n, cosets, cols, inverse, lde);
     (c->plan.reg_b ? launch_pass_reg : launch_pass_lds)(c, true, c->tmp, c->n * cosets, c->n, dst, dst_col_stride, dst_coset_stride, cosets, cols, inverse, lde);
+}
+
+// ---- four-step twiddle tables -------------------------------------------------------------------------------------------------------
+__global__ void twiddle_table_kernel(fe* out, const fe* tw_lo, const fe* tw_hi, uint32_t lo_bits, uint32_t log_n2, uint32_t log_n, uint32_t log_b,
+                                     uint32_t log_N, uint32_t j0, uint32_t coset_twiddle) {
+    const size_t n = (size_t)1 << log_n;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k1 = i >> log_n2, m2 = i & (((size_t)1 << log_n2) - 1);
+    const uint64_t jg = coset_twiddle ? j0 + blockIdx.y : 0;
+    const uint64_t e = (m2 * ((k1 << log_b) + jg)) & (((uint64_t)1 << log_N) - 1);
+    out[(size_t)blockIdx.y * n + i] = dom_pow(tw_lo, tw_hi, lo_bits, e);
+}
+int k_build_twiddle_tables(dst_ctx* c) {
+    const NttPlan& p = c->plan;
+    dim3 g((unsigned)((c->n + 255) / 256), (unsigned)c->Bc);
+    hipLaunchKernelGGL(twiddle_table_kernel, g, dim3(256), 0, c->stream, c->tw4_lde, c->tw_lo, c->tw_hi, c->tw_lo_bits, p.log_n2, c->log_n, c->log_b, c->log_N, (uint32_t)c->j0, 1u);
+    g.y = 1;
+    hipLaunchKernelGGL(twiddle_table_kernel, g, dim3(256), 0, c->stream, c->tw4_fwd, c->tw_lo, c->tw_hi, c->tw_lo_bits, p.log_n2, c->log_n, c->log_b, c->log_N, 0u, 0u);
+    hipLaunchKernelGGL(twiddle_table_kernel, g, dim3(256), 0, c->stream, c->tw4_inv, c->itw_lo, c->itw_hi, c->tw_lo_bits, p.log_n2, c->log_n, c->log_b, c->log_N, 0u, 0u);
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    return DST_OK;
 }
 
 // how many (coset x column) size-n arrays fit in c->tmp
