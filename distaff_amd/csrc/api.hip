@@ -196,6 +196,8 @@ static int ctx_init(dst_ctx* c) {
 static const fe* as_fe(const uint8_t* p) { return reinterpret_cast<const fe*>(p); }
 static std::vector<fe> copy_fe(const uint8_t* p, size_t count) { std::vector<fe> v(count); memcpy(v.data(), p, count * 16); return v; }
 
+extern "C" int dst_internal_build_proof(dst_ctx* c, const uint64_t* positions, uint32_t num_positions, uint64_t pow_nonce, std::vector<uint8_t>& proof);   // shard.hip
+
 extern "C" {
 
 int dst_ctx_create(const dst_params* params, dst_ctx** out) {
@@ -232,6 +234,7 @@ int dst_commit_trace(dst_ctx* c, uint8_t trace_root[32]) {
     if (!c || !trace_root) return DST_ERR_ARG;
     if (!c->have_trace) { c->err = "dst_commit_trace: no trace uploaded"; return DST_ERR_STATE; }
     HIP_TRY(c, hipSetDevice(c->device));
+    c->sharded_layout = false;
     double t0 = wall_ms();
     k_intt_columns(c, c->trace, c->polys, c->W);                 // interpolate_fft_twiddles (trace_table.rs:159)
     k_lde_columns(c, c->polys, c->lde, c->W);                    // eval_fft_twiddles over the LDE domain (trace_table.rs:166)
@@ -416,128 +419,25 @@ int dst_pow_grind(dst_ctx* c, const uint8_t seed[32], uint32_t grinding_factor, 
 }
 
 // ---- step 9 ---------------------------------------------------------------------------------------------------------------------
-// runs a gather of `count` items through the staging buffer and returns them on the host
-static int fetch(dst_ctx* c, const void* src, size_t item_bytes, const std::vector<uint64_t>& idx, std::vector<uint8_t>& out) {
-    out.resize(idx.size() * item_bytes);
-    if (idx.empty()) return DST_OK;
-    size_t idx_bytes = (idx.size() * 8 + 15) / 16 * 16;
-    if (idx_bytes + out.size() > c->stage_bytes) { c->err = "staging buffer too small"; return DST_ERR_ARG; }
-    uint64_t* d_idx = (uint64_t*)c->d_stage;
-    uint8_t* d_out = c->d_stage + idx_bytes;
-    HIP_TRY(c, hipMemcpyAsync(d_idx, idx.data(), idx.size() * 8, hipMemcpyHostToDevice, c->stream));
-    k_gather(c, src, item_bytes, d_idx, idx.size(), d_out);
-    HIP_TRY(c, hipMemcpyAsync(out.data(), d_out, out.size(), hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    return DST_OK;
-}
-// element index of natural position `pos` inside a coset-major [Bc][n] array
-static inline uint64_t cm_index(const dst_ctx* c, uint64_t pos) { return ((pos & (c->B - 1)) - c->j0) * c->n + (pos >> c->log_b); }
-
-// writes one BatchMerkleProof's `nodes` (Vec<Vec<[u8;32]>>) given leaf and node sources
-static int emit_batch_nodes(dst_ctx* c, const BatchPlan& plan, const void* leaves_dev, const void* nodes_dev, bool raw_pair_leaves, Writer& w) {
-    std::vector<uint64_t> leaf_idx, node_idx;
-    for (auto& l : plan.nodes) for (auto& r : l) (r.is_leaf ? leaf_idx : node_idx).push_back(r.index);
-    std::vector<uint8_t> leaf_data, node_data;
-    int rc;
-    if (raw_pair_leaves) {
-        // constraint tree: leaf u = evaluations at natural positions 2u, 2u+1 of the coset-major cevals
-        std::vector<uint64_t> el;
-        for (uint64_t u : leaf_idx) { el.push_back(cm_index(c, 2 * u)); el.push_back(cm_index(c, 2 * u + 1)); }
-        if ((rc = fetch(c, leaves_dev, 16, el, leaf_data))) return rc;
-    } else if ((rc = fetch(c, leaves_dev, 32, leaf_idx, leaf_data))) return rc;
-    if ((rc = fetch(c, nodes_dev, 32, node_idx, node_data))) return rc;
-    size_t li = 0, ni = 0;
-    w.u64(plan.nodes.size());
-    for (auto& l : plan.nodes) {
-        w.u64(l.size());
-        for (auto& r : l) {
-            if (r.is_leaf) { w.raw(leaf_data.data() + 32 * li, 32); li++; }
-            else { w.raw(node_data.data() + 32 * ni, 32); ni++; }
-        }
-    }
-    return DST_OK;
-}
-
+// (openings are planned, gathered and serialised in shard.hip: dst_shard_open / dst_shard_assemble)
 int dst_build_proof(dst_ctx* c, const uint64_t* positions_in, uint32_t num_positions, uint64_t pow_nonce, uint8_t* out, size_t cap, size_t* out_len) {
     if (!c || !positions_in || !out_len) return DST_ERR_ARG;
     if (!c->composed || c->fri_committed != c->num_fri_layers) { c->err = "dst_build_proof: FRI commit phase not finished"; return DST_ERR_STATE; }
     if (c->prm.world != 1) { c->err = "dst_build_proof: single-GPU contexts only"; return DST_ERR_ARG; }
     HIP_TRY(c, hipSetDevice(c->device));
     double t0 = wall_ms();
-    std::vector<uint64_t> positions(positions_in, positions_in + num_positions);
-    for (uint64_t p : positions) if (p >= c->N) { c->err = "query position out of range"; return DST_ERR_ARG; }
-    Writer w;
-    int rc;
-    // StarkProof (proof.rs:11-22): trace_root, trace_info, trace_nodes, trace_evaluations, constraint_root, constraint_proof,
-    // deep_values, degree_proof, pow_nonce, options
-    w.raw(c->trace_root, 32);
-    uint8_t domain_depth = (uint8_t)c->log_N;
-    w.u8(domain_depth); w.u8((uint8_t)c->prm.ctx_depth); w.u8((uint8_t)c->prm.loop_depth); w.u8((uint8_t)c->stack_depth); w.u32((uint32_t)c->op_count);
-    BatchPlan tp = plan_batch(positions, c->N);
-    if ((rc = emit_batch_nodes(c, tp, c->trace_leaves, c->trace_nodes, false, w))) return rc;
-    {   // trace_evaluations: Vec<Vec<u128>>, one row of W registers per position (trace_table.rs:127)
-        size_t bytes = positions.size() * c->W * 16, idx_bytes = (positions.size() * 8 + 15) / 16 * 16;
-        if (idx_bytes + bytes > c->stage_bytes) { c->err = "staging buffer too small"; return DST_ERR_ARG; }
-        HIP_TRY(c, hipMemcpyAsync(c->d_stage, positions.data(), positions.size() * 8, hipMemcpyHostToDevice, c->stream));
-        k_gather_rows(c, (const uint64_t*)c->d_stage, positions.size(), (fe*)(c->d_stage + idx_bytes));
-        std::vector<uint8_t> rows(bytes);
-        HIP_TRY(c, hipMemcpyAsync(rows.data(), c->d_stage + idx_bytes, bytes, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
-        w.u64(positions.size());
-        for (size_t p = 0; p < positions.size(); p++) { w.u64(c->W); w.raw(rows.data() + p * c->W * 16, c->W * 16); }
-    }
-    w.raw(c->constraint_root, 32);
-    {   // constraint_proof: BatchMerkleProof { values, nodes, depth } over positions / 2 (utils/mod.rs:46)
-        std::vector<uint64_t> cpos = constraint_positions(positions);
-        BatchPlan cp = plan_batch(cpos, c->N / 2);
-        std::vector<uint64_t> el;
-        for (uint64_t u : cp.values) { el.push_back(cm_index(c, 2 * u)); el.push_back(cm_index(c, 2 * u + 1)); }
-        std::vector<uint8_t> vals;
-        if ((rc = fetch(c, c->cevals, 16, el, vals))) return rc;
-        w.u64(cp.values.size()); w.raw(vals.data(), vals.size());
-        if ((rc = emit_batch_nodes(c, cp, c->cevals, c->cnodes, true, w))) return rc;
-        w.u8(cp.depth);
-    }
-    w.u64(c->W); w.raw(c->deep_z1.data(), c->W * 16);             // DeepValues (proof.rs:24-28)
-    w.u64(c->W); w.raw(c->deep_z2.data(), c->W * 16);
-    {   // FriProof { layers, rem_root, rem_values } (fri/prover.rs:55-95)
-        std::vector<uint64_t> pos = positions;
-        int L = c->num_fri_layers;
-        w.u64((uint64_t)(L - 1));
-        for (int d = 0; d + 1 < L; d++) {
-            uint64_t size = c->fri_size[d], R = size / 4;
-            pos = augmented_positions(pos, size);
-            BatchPlan fp = plan_batch(pos, R);
-            w.raw(c->fri_roots[d].data(), 32);
-            std::vector<uint64_t> el;
-            for (uint64_t r : pos) for (uint64_t s = 0; s < 4; s++) { uint64_t i = r + s * R; el.push_back(d == 0 ? cm_index(c, i) : i); }
-            std::vector<uint8_t> vals;
-            if ((rc = fetch(c, c->fri_e[d], 16, el, vals))) return rc;
-            w.u64(pos.size()); w.raw(vals.data(), vals.size());   // values: Vec<[u128; 4]>
-            if ((rc = emit_batch_nodes(c, fp, c->fri_leaves[d], c->fri_nodes[d], false, w))) return rc;
-            w.u8(fp.depth);
+    // one plan, one batched device gather, one fill (shard.hip; the single-GPU case is the plan with every item local)
+    std::vector<uint8_t> proof;
+    int rc = dst_internal_build_proof(c, positions_in, num_positions, pow_nonce, proof);
+    if (rc == DST_OK) {
+        *out_len = proof.size();
+        if (out) {
+            if (cap < proof.size()) { c->err = "proof buffer too small"; rc = DST_ERR_ARG; }
+            else memcpy(out, proof.data(), proof.size());
         }
-        w.raw(c->fri_roots[L - 1].data(), 32);
-        size_t rem = c->fri_size[L - 1];
-        std::vector<uint8_t> remv(rem * 16);
-        if (L - 1 == 0) {   // cannot happen for n >= 64 (N >= 1024), kept for completeness
-            std::vector<uint64_t> el; for (uint64_t i = 0; i < rem; i++) el.push_back(cm_index(c, i));
-            if ((rc = fetch(c, c->fri_e[0], 16, el, remv))) return rc;
-        } else {
-            HIP_TRY(c, hipMemcpyAsync(remv.data(), c->fri_e[L - 1], rem * 16, hipMemcpyDeviceToHost, c->stream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-        }
-        w.u64(rem); w.raw(remv.data(), remv.size());
     }
-    w.u64(pow_nonce);
-    w.u8((uint8_t)c->log_b); w.u8((uint8_t)c->prm.num_queries); w.u8((uint8_t)c->prm.grinding_factor); w.u8(0);   // options.rs:16-27,107
-    HIP_TRY(c, hipGetLastError());
-    *out_len = w.b.size();
     c->phase_ms[8] = wall_ms() - t0;
-    if (!out) return DST_OK;
-    if (cap < w.b.size()) { c->err = "proof buffer too small"; return DST_ERR_ARG; }
-    memcpy(out, w.b.data(), w.b.size());
-    return DST_OK;
+    return rc;
 }
 
 // ---- the whole prover -----------------------------------------------------------------------------------------------------------

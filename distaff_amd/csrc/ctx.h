@@ -61,6 +61,7 @@ struct dst_ctx {
     size_t Bc = 0, j0 = 0;              // local cosets
     size_t stack_depth = 0;
     NttPlan plan;
+    bool sharded_layout = false;        // FRI layers >= 1 coset-major with per-rank tree heaps (dst_shard_* phases) instead of natural order / full heaps
 
     // tables (device)
     fe *tw_lo = nullptr, *tw_hi = nullptr;       // w_N^t, two-level: e = (hi << lo_bits) | lo

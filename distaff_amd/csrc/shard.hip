@@ -54,6 +54,7 @@ int dst_shard_commit_trace(dst_ctx* c) {
     HIP_TRY(c, hipSetDevice(c->device));
     int r = ensure_shard_buffers(c);
     if (r) return r;
+    c->sharded_layout = true;
     k_intt_columns(c, c->trace, c->polys, c->W);
     k_lde_columns(c, c->polys, c->lde, c->W);
     k_trace_leaves(c);
@@ -270,6 +271,7 @@ void plan_item(OpenPlan& p, int owner, uint32_t buffer, uint32_t arg, uint64_t i
 }
 // element at natural position pos of a coset-major [B][nd] array
 void plan_element(const dst_ctx* c, OpenPlan& p, uint32_t buffer, uint32_t arg, uint64_t pos, uint64_t nd) {
+    if (buffer == RD_FRI_E && arg > 0 && !c->sharded_layout) { plan_item(p, 0, buffer, arg, pos, 16); return; }     // single-GPU phases keep layers >= 1 in natural order
     uint64_t k = pos / c->B, j = pos % c->B, g = j / c->Bc;
     plan_item(p, (int)g, buffer, arg, (j - g * c->Bc) * nd + k, 16);
 }
@@ -341,50 +343,37 @@ const void* read_source(dst_ctx* c, uint32_t buffer, uint32_t arg) {
     switch (buffer) {
         case RD_TRACE_LEAF: return c->trace_leaves;
         case RD_TRACE_NODE: return c->trace_nodes;
-        case RD_TRACE_UPPER: return c->trace_upper;
+        case RD_TRACE_UPPER: return c->sharded_layout ? c->trace_upper : c->trace_nodes;      // single-GPU phases: one full heap per tree
         case RD_CEVAL: return c->cevals;
         case RD_C_NODE: return c->cnodes;
-        case RD_C_UPPER: return c->c_upper;
+        case RD_C_UPPER: return c->sharded_layout ? c->c_upper : c->cnodes;
         case RD_FRI_E: return (int)arg < c->num_fri_layers ? c->fri_e[arg] : nullptr;
         case RD_FRI_LEAF: return (int)arg < c->num_fri_layers ? c->fri_leaves[arg] : nullptr;
         case RD_FRI_NODE: return (int)arg < c->num_fri_layers ? c->fri_nodes[arg] : nullptr;
-        case RD_FRI_UPPER: return (int)arg < c->num_fri_layers ? c->fri_upper[arg] : nullptr;
+        case RD_FRI_UPPER: return (int)arg < c->num_fri_layers ? (c->sharded_layout ? c->fri_upper[arg] : c->fri_nodes[arg]) : nullptr;
     }
     return nullptr;
 }
 }  // namespace
 
-// this rank's items, concatenated in request order
-int dst_shard_open(dst_ctx* c, const uint64_t* positions, uint32_t num_positions, uint8_t* blob, size_t cap, size_t* blob_len, uint64_t* all_lens) {
-    if (!c || !positions || !blob_len) return DST_ERR_ARG;
-    HIP_TRY(c, hipSetDevice(c->device));
-    OpenPlan p;
-    int rc = build_open_plan(c, positions, num_positions, 0, p);
-    if (rc) return rc;
-    const int me = (int)c->prm.rank;
-    // group the owned requests by (buffer, arg); the blob keeps request order, so remember where each item goes
+// gathers the requests selected by `mine` (one staging upload, one gather launch per source buffer, one copy back) into `blob`,
+// concatenated in request order
+static int gather_requests(dst_ctx* c, const OpenPlan& p, int me, bool everything, std::vector<uint8_t>& blob) {
     struct Group { uint32_t buffer, arg, bytes; std::vector<uint64_t> idx; std::vector<size_t> dst; };
     std::vector<Group> groups;
     size_t total = 0;
     for (auto& r : p.reqs) {
-        if (!(r.owner == me || (r.owner < 0 && me == 0))) continue;
+        if (!(everything || r.owner == me || (r.owner < 0 && me == 0))) continue;
         Group* g = nullptr;
         for (auto& q : groups) if (q.buffer == r.buffer && q.arg == r.arg) { g = &q; break; }
         if (!g) { groups.push_back({r.buffer, r.arg, r.bytes, {}, {}}); g = &groups.back(); }
         g->idx.push_back(r.index); g->dst.push_back(total);
         total += r.bytes;
     }
-    *blob_len = total;
-    if (all_lens) {                                        // every rank's share follows from the same plan
-        for (uint32_t g = 0; g < c->prm.world; g++) all_lens[g] = 0;
-        for (auto& r : p.reqs) all_lens[r.owner < 0 ? 0 : r.owner] += r.bytes;
-    }
-    if (!blob) return DST_OK;
-    if (cap < total) { c->err = "dst_shard_open: blob buffer too small"; return DST_ERR_ARG; }
-    // one staging layout: [indices of all groups][items of all groups]
+    blob.resize(total);
     size_t idx_bytes = 0, out_bytes = 0;
     for (auto& g : groups) { idx_bytes += (g.idx.size() * 8 + 15) / 16 * 16; out_bytes += g.idx.size() * (size_t)g.bytes; }
-    if (idx_bytes + out_bytes > c->stage_bytes) { c->err = "dst_shard_open: staging buffer too small"; return DST_ERR_ARG; }
+    if (idx_bytes + out_bytes > c->stage_bytes) { c->err = "openings: staging buffer too small"; return DST_ERR_ARG; }
     std::vector<uint8_t> hidx(idx_bytes), hout(out_bytes);
     size_t io = 0;
     for (auto& g : groups) { memcpy(hidx.data() + io, g.idx.data(), g.idx.size() * 8); io += (g.idx.size() * 8 + 15) / 16 * 16; }
@@ -396,7 +385,7 @@ int dst_shard_open(dst_ctx* c, const uint64_t* positions, uint32_t num_positions
         if (g.buffer == RD_LDE_ROW) k_gather_rows(c, d_idx, g.idx.size(), (fe*)d_out);
         else {
             const void* src = read_source(c, g.buffer, g.arg);
-            if (!src) { c->err = "dst_shard_open: buffer not allocated"; return DST_ERR_STATE; }
+            if (!src) { c->err = "openings: buffer not allocated"; return DST_ERR_STATE; }
             k_gather(c, src, g.bytes, d_idx, g.idx.size(), d_out);
         }
         io += (g.idx.size() * 8 + 15) / 16 * 16; oo += g.idx.size() * (size_t)g.bytes;
@@ -405,7 +394,43 @@ int dst_shard_open(dst_ctx* c, const uint64_t* positions, uint32_t num_positions
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     oo = 0;
-    for (auto& g : groups) for (size_t i = 0; i < g.idx.size(); i++) { memcpy(blob + g.dst[i], hout.data() + oo, g.bytes); oo += g.bytes; }
+    for (auto& g : groups) for (size_t i = 0; i < g.idx.size(); i++) { memcpy(blob.data() + g.dst[i], hout.data() + oo, g.bytes); oo += g.bytes; }
+    return DST_OK;
+}
+
+// single-GPU dst_build_proof (api.hip): one plan, every item local
+int dst_internal_build_proof(dst_ctx* c, const uint64_t* positions, uint32_t num_positions, uint64_t pow_nonce, std::vector<uint8_t>& proof) {
+    OpenPlan p;
+    int rc = build_open_plan(c, positions, num_positions, pow_nonce, p);
+    if (rc) return rc;
+    std::vector<uint8_t> blob;
+    if ((rc = gather_requests(c, p, 0, true, blob))) return rc;
+    size_t cur = 0;
+    for (size_t i = 0; i < p.reqs.size(); i++) { memcpy(p.w.b.data() + p.slot[i], blob.data() + cur, p.reqs[i].bytes); cur += p.reqs[i].bytes; }
+    proof.swap(p.w.b);
+    return DST_OK;
+}
+
+// this rank's items, concatenated in request order
+int dst_shard_open(dst_ctx* c, const uint64_t* positions, uint32_t num_positions, uint8_t* blob, size_t cap, size_t* blob_len, uint64_t* all_lens) {
+    if (!c || !positions || !blob_len) return DST_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    OpenPlan p;
+    int rc = build_open_plan(c, positions, num_positions, 0, p);
+    if (rc) return rc;
+    const int me = (int)c->prm.rank;
+    size_t total = 0;
+    for (auto& r : p.reqs) if (r.owner == me || (r.owner < 0 && me == 0)) total += r.bytes;
+    *blob_len = total;
+    if (all_lens) {                                        // every rank's share follows from the same plan
+        for (uint32_t g = 0; g < c->prm.world; g++) all_lens[g] = 0;
+        for (auto& r : p.reqs) all_lens[r.owner < 0 ? 0 : r.owner] += r.bytes;
+    }
+    if (!blob) return DST_OK;
+    if (cap < total) { c->err = "dst_shard_open: blob buffer too small"; return DST_ERR_ARG; }
+    std::vector<uint8_t> mine;
+    if ((rc = gather_requests(c, p, me, false, mine))) return rc;
+    memcpy(blob, mine.data(), mine.size());
     return DST_OK;
 }
 
