@@ -1,3 +1,6 @@
+#!/bin/bash
+# Quick GPU round trip used during development (run through gpurun from the repo root): the parity tests that finish in seconds,
+# then three timed proofs with the per-phase and per-kernel breakdown.
 timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "not every_tile" 2>&1 | grep -E "passed|failed|Error|error" | head
 python bench.py --steps 3 --warmup 1 --no-cpu-baseline 2>/dev/null | grep '^{"metric' | python -c "
 import json,sys
