@@ -1,0 +1,39 @@
+"""Host side of libdistaff_hip.so that needs no GPU (runs under -m "not gpu"): the Fibonacci trace generator (host_vm.h), the
+Fiat-Shamir helpers (host_util.h: BLAKE3, StdRng/Uniform draws, query positions) against the oracle's restatements, which are
+themselves pinned by the reference's vectors (tests/test_oracle_*.py)."""
+import numpy as np
+import pytest
+
+
+@pytest.mark.parametrize("log_n", [7, 8, 10, 13])
+def test_library_trace_generator_equals_oracle_vm(oracle, log_n):
+    """dst_fibonacci_trace (host_vm.h: decoder, Rescue sponge accumulator, context stack, user stack, VOID padding) against
+    the oracle VM on the assembled program (processor/mod.rs:23-143, programs/blocks/mod.rs:149-178)."""
+    import distaff_amd as D
+    cols, program_hash, result = D.fibonacci_trace(log_n)
+    t = oracle.fibonacci_trace(1 << log_n)
+    assert cols.shape == (20, 1 << log_n, 2)
+    assert (cols == t.columns).all()
+    assert program_hash == t.program_hash
+    assert result == oracle.to_ints(t.columns[16, -1:])[0]            # top of the user stack in the last row
+
+
+def test_library_fiat_shamir_helpers_equal_oracle(oracle):
+    import distaff_amd as D
+    O = oracle
+    for i in range(20):
+        seed = O.blake3(bytes([i]) * (i + 1))
+        assert D.blake3(bytes([i]) * (i + 1)) == seed
+        for count in (1, 2, 344, 516):
+            assert (D.prng_vector(seed, count) == O.prng_vector(seed, count)).all()
+        for (N, ext, nq) in ((1 << 12, 32, 50), (1 << 25, 32, 50), (1 << 28, 16, 100), (1 << 10, 64, 30)):
+            got = D.query_positions(seed, N, ext, nq)
+            assert got == O.query_positions(seed, N, ext, nq)
+            assert all(p % ext != 0 for p in got) and len(set(got)) == len(got)
+
+
+def test_blake3_lengths(oracle):
+    import distaff_amd as D
+    data = bytes(range(256)) * 5
+    for n in (0, 1, 31, 32, 33, 63, 64, 65, 127, 128):
+        assert D.blake3(data[:n]) == oracle.blake3(data[:n])
