@@ -37,3 +37,20 @@ def test_blake3_lengths(oracle):
     data = bytes(range(256)) * 5
     for n in (0, 1, 31, 32, 33, 63, 64, 65, 127, 128):
         assert D.blake3(data[:n]) == oracle.blake3(data[:n])
+
+
+def test_context_creation_validates_and_fails_loudly_without_gpu():
+    """The product path has no CPU fallback: bad parameters are argument errors; on a box without a GPU a valid request is a HIP error."""
+    import torch
+    import distaff_amd as D
+    for kw in (dict(log_n=5), dict(log_n=25), dict(log_blowup=3), dict(log_blowup=9), dict(width=15), dict(width=128), dict(num_queries=0),
+               dict(world=3), dict(world=16), dict(rank=2, world=2), dict(world=8, log_blowup=4)):
+        args = dict(log_n=8, width=20, ctx_depth=1, loop_depth=0, log_blowup=5, num_queries=50, grinding=20, rank=0, world=1)
+        args.update(kw)
+        with pytest.raises(D.DistaffError) as e:
+            D.Context(args.pop("log_n"), args.pop("width"), args.pop("ctx_depth"), args.pop("loop_depth"), **args)
+        assert e.value.code == D.DST_ERR_ARG, kw
+    if not torch.cuda.is_available():
+        with pytest.raises(D.DistaffError) as e:
+            D.Context(8, 20, 1, 0)
+        assert e.value.code == D.DST_ERR_HIP
