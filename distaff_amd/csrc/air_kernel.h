@@ -202,12 +202,13 @@ __device__ __forceinline__ fe st_low_degree(const StackRows& s, const fe* lo2, c
 
 // degree-group slots: 2->0 3->1 4->2 6->3 7->4 8->5
 struct Acc {
+    fe_acc res_acc;        // sum over all constraints of value * coefficient: one reduction at the end of the launch (fe_acc)
     fe res, adj[6];
     bool nonzero;
     const fe* tc; uint32_t nc;
     __device__ __forceinline__ void emit(uint32_t cidx, int slot, const fe& d) {
         nonzero |= !fe_is_zero(d);
-        res = fe_add(res, fe_mul(d, tc[cidx]));
+        fe_acc_mac(res_acc, d, tc[cidx]);
         adj[slot] = fe_add(adj[slot], fe_mul(d, tc[nc + cidx]));
     }
 };
@@ -326,7 +327,7 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
 
     const fe* per = a.periodic + (size_t)(step & 127u) * 23;
     Acc acc;
-    acc.res = fe_zero(); acc.nonzero = false; acc.tc = a.tc; acc.nc = 20 + cl + ll + 2 + sd;
+    fe_acc_zero(acc.res_acc); acc.res = fe_zero(); acc.nonzero = false; acc.tc = a.tc; acc.nc = 20 + cl + ll + 2 + sd;
 #pragma unroll
     for (int i = 0; i < 6; i++) acc.adj[i] = fe_zero();
     const size_t pstride = (size_t)gridDim.y * a.n, pidx = (size_t)ql * a.n + k;
@@ -610,6 +611,7 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
     if (on_trace && k + 1 != a.n && acc.nonzero) atomicMin(a.bad_step, (unsigned long long)k);      // evaluator.rs:152-158
     // the partial sums of the previous launches join at the end (they are not live during the evaluation); a launch only moves the
     // degree-group sums its sections emit into: op bits {2,3,4,6,8}, sponge / context / loop {4,6,7}, stack {7}
+    acc.res = fe_acc_reduce(acc.res_acc);
     constexpr uint32_t USED = ((SECT & 2) ? 0x2Fu : 0u) | ((SECT & 4) ? 0x1Cu : 0u) | ((SECT & 120) ? 0x10u : 0u);
     if constexpr (!FIRST) {
         acc.res = fe_add(acc.res, a.partial[pidx]);
