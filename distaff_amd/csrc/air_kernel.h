@@ -201,15 +201,19 @@ __device__ __forceinline__ fe st_low_degree(const StackRows& s, const fe* lo2, c
 }
 
 // degree-group slots: 2->0 3->1 4->2 6->3 7->4 8->5
+// ADJ_ACC: the degree-group sums are fe_acc accumulators too (launches that emit into few groups; an accumulator is 21 registers)
+template <bool ADJ_ACC>
 struct Acc {
     fe_acc res_acc;        // sum over all constraints of value * coefficient: one reduction at the end of the launch (fe_acc)
+    fe_acc adj_acc[ADJ_ACC ? 6 : 1];
     fe res, adj[6];
     bool nonzero;
     const fe* tc; uint32_t nc;
     __device__ __forceinline__ void emit(uint32_t cidx, int slot, const fe& d) {
         nonzero |= !fe_is_zero(d);
         fe_acc_mac(res_acc, d, tc[cidx]);
-        adj[slot] = fe_add(adj[slot], fe_mul(d, tc[nc + cidx]));
+        if constexpr (ADJ_ACC) fe_acc_mac(adj_acc[slot], d, tc[nc + cidx]);
+        else adj[slot] = fe_add(adj[slot], fe_mul(d, tc[nc + cidx]));
     }
 };
 
@@ -326,7 +330,12 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
     }
 
     const fe* per = a.periodic + (size_t)(step & 127u) * 23;
-    Acc acc;
+    constexpr bool ADJ_ACC = (SECT & 2) == 0 && SD != 0;      // op bits emit into five groups: too many accumulators
+    Acc<ADJ_ACC> acc;
+    if constexpr (ADJ_ACC) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) fe_acc_zero(acc.adj_acc[i]);
+    }
     fe_acc_zero(acc.res_acc); acc.res = fe_zero(); acc.nonzero = false; acc.tc = a.tc; acc.nc = 20 + cl + ll + 2 + sd;
 #pragma unroll
     for (int i = 0; i < 6; i++) acc.adj[i] = fe_zero();
@@ -613,6 +622,10 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
     // degree-group sums its sections emit into: op bits {2,3,4,6,8}, sponge / context / loop {4,6,7}, stack {7}
     acc.res = fe_acc_reduce(acc.res_acc);
     constexpr uint32_t USED = ((SECT & 2) ? 0x2Fu : 0u) | ((SECT & 4) ? 0x1Cu : 0u) | ((SECT & 120) ? 0x10u : 0u);
+    if constexpr (ADJ_ACC) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) if ((USED >> i) & 1u) acc.adj[i] = fe_acc_reduce(acc.adj_acc[i]);
+    }
     if constexpr (!FIRST) {
         acc.res = fe_add(acc.res, a.partial[pidx]);
 #pragma unroll
