@@ -120,7 +120,7 @@ static int ctx_init(dst_ctx* c) {
     {
         const bool reg_ok = pl.log_n2 >= 6 && pl.log_n1 <= 12;
         const char* force = getenv("DISTAFF_NTT");
-        pl.reg_a = reg_ok && false; pl.reg_b = reg_ok && pl.log_n2 >= 12;
+        pl.reg_a = reg_ok && pl.log_n1 >= 12; pl.reg_b = reg_ok && pl.log_n2 >= 12;      // 4096-point tiles: the LDS family is down to one column (16-byte segments)
         if (force && !strcmp(force, "reg") && reg_ok) pl.reg_a = pl.reg_b = true;
         if (force && !strcmp(force, "lds")) pl.reg_a = pl.reg_b = false;
     }
