@@ -325,3 +325,17 @@ def test_fibonacci_2_16_proof_bytes_equal_oracle(oracle):
     ctx.upload(cols)
     assert ctx.prove([1, 0], [result]) == expected
     ctx.close()
+
+
+def test_sharded_world8_at_2_16_equals_single_context():
+    """Buffer sizing of the sharded path at a non-toy size: 8 thread-ranks on one GPU, 2^16-step Fibonacci trace, default options;
+    the single-context proof of the same trace is the reference (it equals the oracle's in test_fibonacci_2_16_proof_bytes_equal_oracle)."""
+    import distaff_amd as D
+    from distaff_amd import sharded
+    cols, program_hash, result = D.fibonacci_trace(16)
+    ctx = D.Context(16, 20, 1, 0)
+    ctx.upload(cols)
+    expected = ctx.prove([1, 0], [result])
+    ctx.close()
+    proofs = sharded.prove_local(cols, 16, 20, 1, 0, [1, 0], [result], 8)
+    assert all(p == expected for p in proofs)
