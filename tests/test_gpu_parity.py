@@ -339,3 +339,14 @@ def test_sharded_world8_at_2_16_equals_single_context():
     ctx.close()
     proofs = sharded.prove_local(cols, 16, 20, 1, 0, [1, 0], [result], 8)
     assert all(p == expected for p in proofs)
+
+
+def test_plain_c_host_produces_the_oracle_proof(oracle, tmp_path):
+    """examples/prove_fibonacci.c (C99, only include/distaff_hip.h and the shared library) writes the same bytes as the oracle."""
+    import subprocess
+    from test_host_logic import _compile_c_host
+    exe = _compile_c_host(tmp_path)
+    out = tmp_path / "proof.bin"
+    subprocess.check_call([exe, "10", str(out)])
+    t = oracle.fibonacci_trace(1 << 10)
+    assert out.read_bytes() == oracle.Prover.from_trace(t, 1).prove()

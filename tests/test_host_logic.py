@@ -54,3 +54,23 @@ def test_context_creation_validates_and_fails_loudly_without_gpu():
         with pytest.raises(D.DistaffError) as e:
             D.Context(8, 20, 1, 0)
         assert e.value.code == D.DST_ERR_HIP
+
+
+def _compile_c_host(tmp_path):
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "prove_fibonacci")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "prove_fibonacci.c"),
+                           "-L" + os.path.join(root, "distaff_amd"), "-ldistaff_hip", "-Wl,-rpath," + os.path.join(root, "distaff_amd"), "-o", exe])
+    return exe
+
+
+def test_c_abi_header_is_plain_c_and_links(tmp_path):
+    """include/distaff_hip.h compiles as C99 and examples/prove_fibonacci.c links against libdistaff_hip.so (no torch, no Python)."""
+    import subprocess
+    import torch
+    exe = _compile_c_host(tmp_path)
+    if not torch.cuda.is_available():                      # without a GPU the host fails loudly at context creation (no CPU fallback)
+        r = subprocess.run([exe, "8"], capture_output=True, text=True)
+        assert r.returncode == 1 and "dst_ctx_create" in r.stderr
