@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
+#include <memory>
 #include <string>
 #include <map>
 #include <vector>
@@ -61,6 +62,8 @@ struct dst_ctx {
     size_t Bc = 0, j0 = 0;              // local cosets
     size_t stack_depth = 0;
     NttPlan plan;
+    std::shared_ptr<void> open_plan;   // shard.hip: plan of the last dst_shard_open, reused by dst_shard_assemble for the same positions
+    std::vector<uint64_t> open_plan_positions;
     bool sharded_layout = false;        // FRI layers >= 1 coset-major with per-rank tree heaps (dst_shard_* phases) instead of natural order / full heaps
 
     // tables (device)

@@ -242,6 +242,33 @@ int dst_shard_read(dst_ctx* c, uint32_t buffer, uint32_t arg, const uint64_t* id
     return DST_OK;
 }
 
+// One FRI layer in two calls around the all-gather (fri/prover.rs:11-53): begin = leaves + local tree levels of the next layer and
+// its boundary nodes into the caller's send buffer; end = import of the gathered boundary nodes (layer root), and, if another
+// layer follows, the Fiat-Shamir draw from that root (field::prng) and the fold.
+int dst_shard_fri_begin(dst_ctx* c, void* send, int send_is_device, size_t cap, size_t* bytes, int* more) {
+    if (!c || !send || !bytes || !more) return DST_ERR_ARG;
+    int r = dst_shard_fri_layer(c, more);
+    if (r) return r;
+    const uint32_t d = (uint32_t)c->fri_committed - 1;
+    if ((r = dst_shard_export_size(c, SH_FRI_TREE, d, bytes))) return r;
+    if (*bytes > cap) { c->err = "dst_shard_fri_begin: send buffer too small"; return DST_ERR_ARG; }
+    return dst_shard_export(c, SH_FRI_TREE, d, send, send_is_device);
+}
+int dst_shard_fri_end(dst_ctx* c, const void* gathered, int src_is_device, uint8_t root_out[32]) {
+    if (!c || !gathered || !root_out) return DST_ERR_ARG;
+    if (c->fri_committed == 0) { c->err = "dst_shard_fri_end: no layer in flight"; return DST_ERR_STATE; }
+    const uint32_t d = (uint32_t)c->fri_committed - 1;
+    int r = dst_shard_import(c, SH_FRI_TREE, d, gathered, src_is_device, root_out);
+    if (r) return r;
+    if ((int)d + 1 < c->num_fri_layers) {
+        fe x;
+        prng_vector(root_out, 1, &x);                          // fri/prover.rs:40 field::prng(root)
+        uint8_t xb[16]; memcpy(xb, &x, 16);
+        r = dst_shard_fri_fold(c, xb);
+    }
+    return r;
+}
+
 // ---- step 9 across ranks -------------------------------------------------------------------------------------------------------------
 // Every rank derives the same ordered request list from the query positions (which leaf / node / element / row the proof
 // needs, who owns it, where it sits in the owner's buffers) and the same proof template with one slot per request.
@@ -415,9 +442,16 @@ int dst_internal_build_proof(dst_ctx* c, const uint64_t* positions, uint32_t num
 int dst_shard_open(dst_ctx* c, const uint64_t* positions, uint32_t num_positions, uint8_t* blob, size_t cap, size_t* blob_len, uint64_t* all_lens) {
     if (!c || !positions || !blob_len) return DST_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    OpenPlan p;
-    int rc = build_open_plan(c, positions, num_positions, 0, p);
-    if (rc) return rc;
+    std::shared_ptr<OpenPlan> sp;
+    const std::vector<uint64_t> key(positions, positions + num_positions);
+    if (c->open_plan && c->open_plan_positions == key) sp = std::static_pointer_cast<OpenPlan>(c->open_plan);   // the size query just before
+    int rc = DST_OK;
+    if (!sp) {
+        sp = std::make_shared<OpenPlan>();
+        if ((rc = build_open_plan(c, positions, num_positions, 0, *sp))) return rc;
+        c->open_plan = sp; c->open_plan_positions = key;
+    }
+    OpenPlan& p = *sp;
     const int me = (int)c->prm.rank;
     size_t total = 0;
     for (auto& r : p.reqs) if (r.owner == me || (r.owner < 0 && me == 0)) total += r.bytes;
@@ -438,9 +472,16 @@ int dst_shard_open(dst_ctx* c, const uint64_t* positions, uint32_t num_positions
 int dst_shard_assemble(dst_ctx* c, const uint64_t* positions, uint32_t num_positions, uint64_t pow_nonce, const uint8_t* blobs, const uint64_t* blob_lens,
                        uint8_t* out, size_t cap, size_t* out_len) {
     if (!c || !positions || !blobs || !blob_lens || !out_len) return DST_ERR_ARG;
+    // the plan of the preceding dst_shard_open for the same positions is reused (a copy: the slots get filled); the nonce is the only
+    // field that was not known then and sits 12 bytes before the end of the template
     OpenPlan p;
-    int rc = build_open_plan(c, positions, num_positions, pow_nonce, p);
-    if (rc) return rc;
+    int rc = DST_OK;
+    const std::vector<uint64_t> key(positions, positions + num_positions);
+    if (c->open_plan && c->open_plan_positions == key) {
+        p = *std::static_pointer_cast<OpenPlan>(c->open_plan);
+        for (int i = 0; i < 8; i++) p.w.b[p.w.b.size() - 12 + i] = (uint8_t)(pow_nonce >> (8 * i));
+        c->open_plan.reset(); c->open_plan_positions.clear();
+    } else if ((rc = build_open_plan(c, positions, num_positions, pow_nonce, p))) return rc;
     const size_t G = c->prm.world;
     std::vector<size_t> cursor(G, 0), base(G, 0);
     for (size_t g = 1; g < G; g++) base[g] = base[g - 1] + blob_lens[g - 1];

@@ -23,7 +23,7 @@ EXPORTS = ["dst_ctx_create", "dst_ctx_destroy", "dst_last_error", "dst_phase_ms"
            "dst_build_proof", "dst_prove", "dst_prng_vector", "dst_query_positions", "dst_blake3", "dst_fibonacci_trace",
            "dst_read_buffer", "dst_bench_mulmod", "dst_set_profiling", "dst_kernel_stats", "dst_field_op",
            "dst_shard_commit_trace", "dst_shard_eval_constraints", "dst_shard_combine", "dst_shard_fri_layer", "dst_shard_fri_fold",
-           "dst_shard_export_size", "dst_shard_export", "dst_shard_import", "dst_shard_read", "dst_shard_open", "dst_shard_assemble", "dst_shard_info"]
+           "dst_shard_export_size", "dst_shard_export", "dst_shard_import", "dst_shard_read", "dst_shard_fri_begin", "dst_shard_fri_end", "dst_shard_open", "dst_shard_assemble", "dst_shard_info"]
 
 
 class DistaffError(RuntimeError):
@@ -289,6 +289,18 @@ class Context:
         out = np.zeros(len(indices) * item, dtype=np.uint8)
         self._check(self.lib.dst_shard_read(self._h, ctypes.c_uint32(buffer), ctypes.c_uint32(arg), _ptr(idx), ctypes.c_uint32(len(indices)), _ptr(out)))
         return out.tobytes()
+
+    def shard_fri_begin(self, send_ptr, is_device, cap):
+        """-> (bytes written into the send buffer, another layer follows)"""
+        n, more = ctypes.c_size_t(0), ctypes.c_int(0)
+        self._check(self.lib.dst_shard_fri_begin(self._h, ctypes.c_void_p(send_ptr), ctypes.c_int(1 if is_device else 0), ctypes.c_size_t(cap),
+                                                 ctypes.byref(n), ctypes.byref(more)))
+        return n.value, bool(more.value)
+
+    def shard_fri_end(self, gathered_ptr, is_device):
+        root = ctypes.create_string_buffer(32)
+        self._check(self.lib.dst_shard_fri_end(self._h, ctypes.c_void_p(gathered_ptr), ctypes.c_int(1 if is_device else 0), root))
+        return root.raw
 
     def shard_open(self, positions):
         """-> (this rank's blob of openings, [blob length of every rank])"""

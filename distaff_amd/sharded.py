@@ -278,16 +278,30 @@ class ShardedProver:
         draws = L.prng_vector(constraint_root, 516)
         z1, z2 = ctx.compose(draws)
         self._mark("deep_composition")
-        # step 7
-        fri_roots, d = [], 0
+        # step 7: per layer two library calls around one all-gather (leaves + local levels + export | import + draw + fold)
+        fri_roots = []
+        cap = ctx.shard_export_size(SH_FRI_TREE, 0)                    # layer 0 has the most boundary nodes
+        device_path = getattr(comm, "device_path", False)
+        if device_path:
+            torch = comm.torch
+            send_t = torch.empty(cap, dtype=torch.uint8, device=comm.device)
+            recv_t = torch.empty(cap * G, dtype=torch.uint8, device=comm.device)
+        else:
+            send_h = np.empty(cap, dtype=np.uint8)
         while True:
-            more = ctx.shard_fri_layer()
-            root = self._exchange(SH_FRI_TREE, d)
+            if device_path:
+                size, more = ctx.shard_fri_begin(send_t.data_ptr(), True, cap)
+                out = recv_t[:size * G]
+                comm.dist.all_gather_into_tensor(out, send_t[:size])
+                torch.cuda.synchronize(comm.device)
+                root = ctx.shard_fri_end(out.data_ptr(), True)
+            else:
+                size, more = ctx.shard_fri_begin(send_h.ctypes.data, False, cap)
+                gathered = np.ascontiguousarray(comm.all_gather(send_h[:size]))
+                root = ctx.shard_fri_end(gathered.ctypes.data, False)
             fri_roots.append(root)
             if not more:
                 break
-            ctx.fri_fold_shard(L.arr_to_ints(L.prng_vector(root, 1))[0])
-            d += 1
         layers = len(fri_roots)
         self._mark("fri")
         # step 8

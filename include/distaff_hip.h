@@ -126,6 +126,12 @@ int dst_shard_import(dst_ctx* ctx, uint32_t what, uint32_t arg, const void* src,
  * evaluations (elements), 4 constraint local nodes, 5 constraint upper nodes, 6 FRI layer `arg` evaluations (elements), 7 FRI leaves,
  * 8 FRI local nodes, 9 FRI upper nodes, 10 LDE rows (idx = natural positions owned by this rank, W elements each). */
 int dst_shard_read(dst_ctx* ctx, uint32_t buffer, uint32_t arg, const uint64_t* idx, uint32_t count, uint8_t* out);
+/* One FRI layer (fri/prover.rs:11-53) around its all-gather in two calls: dst_shard_fri_begin = dst_shard_fri_layer + export of the
+ * boundary nodes into `send` (*bytes of them, per rank); dst_shard_fri_end = import of the gathered nodes (layer root) and, when
+ * another layer follows, the fold at field::prng(root). */
+int dst_shard_fri_begin(dst_ctx* ctx, void* send, int send_is_device, size_t cap, size_t* bytes, int* more);
+int dst_shard_fri_end(dst_ctx* ctx, const void* gathered, int src_is_device, uint8_t root_out[32]);
+
 /* Step 9 across ranks (prover.rs:143-165; merkle.rs:64-124 prove_batch; fri/prover.rs:55-96 build_proof).  Every rank derives the
  * same ordered list of openings from the query positions.  dst_shard_open returns the items THIS rank owns, concatenated in that
  * order (blob == NULL: only the sizes; all_lens, if not NULL, receives every rank's blob length, `world` entries);
