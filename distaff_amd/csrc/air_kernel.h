@@ -106,6 +106,7 @@ __device__ __forceinline__ fe st_term(const StackRows& s) {
     auto L = [&](int num) { return fe_sub(o[i + num], nw[i]); };          // left shift by num
     auto R = [&](int num) { return fe_sub(o[i - num < 0 ? 0 : i - num], nw[i]); };   // right shift by num
     auto C = [&]() { return fe_sub(o[i], nw[i]); };                       // copy
+    auto sel = [&](const fe& c, const fe& x, const fe& y) { return fe_add(y, fe_mul(c, fe_sub(x, y))); };   // c*x + (1-c)*y with one multiplication
     if constexpr (OP == 0x00) { if constexpr (I == 4) return fe_mul(s.hd0, bnot(o[0])); else return fe_mul(s.hd0, L(1)); }   // ASSERT flag carries hd[0] (trace_state.rs:346)
     else if constexpr (OP == 0x01) { if constexpr (I == 4) return fe_sub(o[0], o[1]); else return L(2); }
     else if constexpr (OP == 0x02) {
@@ -118,21 +119,21 @@ __device__ __forceinline__ fe st_term(const StackRows& s) {
     else if constexpr (OP == 0x04) return L(4);
     else if constexpr (OP == 0x05) {
         if constexpr (I == 4) return is_bin(o[2]);
-        else if constexpr (I == 0) return fe_sub(nw[0], fe_add(fe_mul(o[2], o[0]), fe_mul(bnot(o[2]), o[1])));
+        else if constexpr (I == 0) return fe_sub(nw[0], sel(o[2], o[0], o[1]));
         else return L(2);
     }
     else if constexpr (OP == 0x06) {
         if constexpr (I == 4) return is_bin(o[4]);
-        else if constexpr (I == 0) return fe_sub(nw[0], fe_add(fe_mul(o[4], o[0]), fe_mul(bnot(o[4]), o[2])));
-        else if constexpr (I == 1) return fe_sub(nw[1], fe_add(fe_mul(o[4], o[1]), fe_mul(bnot(o[4]), o[3])));
+        else if constexpr (I == 0) return fe_sub(nw[0], sel(o[4], o[0], o[2]));
+        else if constexpr (I == 1) return fe_sub(nw[1], sel(o[4], o[1], o[3]));
         else return L(4);
     }
     else if constexpr (OP == 0x07) {
         if constexpr (I == 4) return is_bin(o[4]);
-        else if constexpr (I == 0) return fe_sub(nw[0], fe_add(fe_mul(o[4], o[2]), fe_mul(bnot(o[4]), o[0])));
-        else if constexpr (I == 1) return fe_sub(nw[1], fe_add(fe_mul(o[4], o[3]), fe_mul(bnot(o[4]), o[1])));
-        else if constexpr (I == 2) return fe_sub(nw[2], fe_add(fe_mul(o[4], o[0]), fe_mul(bnot(o[4]), o[2])));
-        else return fe_sub(nw[3], fe_add(fe_mul(o[4], o[1]), fe_mul(bnot(o[4]), o[3])));
+        else if constexpr (I == 0) return fe_sub(nw[0], sel(o[4], o[2], o[0]));
+        else if constexpr (I == 1) return fe_sub(nw[1], sel(o[4], o[3], o[1]));
+        else if constexpr (I == 2) return fe_sub(nw[2], sel(o[4], o[0], o[2]));
+        else return fe_sub(nw[3], sel(o[4], o[1], o[3]));
     }
     else if constexpr (OP == 0x08) { if constexpr (I == 0) return fe_sub(nw[0], fe_add(o[0], o[1])); else return L(1); }
     else if constexpr (OP == 0x09) { if constexpr (I == 0) return fe_sub(nw[0], fe_mul(o[0], o[1])); else return L(1); }
@@ -145,7 +146,7 @@ __device__ __forceinline__ fe st_term(const StackRows& s) {
     else if constexpr (OP == 0x0B) {
         if constexpr (I == 4) return is_bin(o[0]);
         else if constexpr (I == 5) return is_bin(o[1]);
-        else if constexpr (I == 0) return fe_sub(nw[0], bnot(fe_mul(bnot(o[0]), bnot(o[1]))));
+        else if constexpr (I == 0) return fe_sub(nw[0], fe_sub(fe_add(o[0], o[1]), fe_mul(o[0], o[1])));     // 1 - (1-x)(1-y) = x + y - xy (shares xy with MUL / AND)
         else return L(1);
     }
     else if constexpr (OP == 0x0C) { if constexpr (I == 0) return fe_sub(fe_one(), fe_mul(nw[0], o[0])); else return C(); }
