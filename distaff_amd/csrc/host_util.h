@@ -36,16 +36,30 @@ inline void b3_chunk(const uint8_t* p, size_t len, uint32_t chunk_index, bool ro
         b3_compress(cv, m, chunk_index, 0, (uint32_t)bl, flags);
     }
 }
+// chaining value of the subtree over `len` > 1024 bytes starting at chunk `chunk0`, or of a single chunk (never the root)
+inline void b3_subtree(const uint8_t* in, size_t len, uint64_t chunk0, uint32_t cv[8]) {
+    if (len <= 1024) { b3_chunk(in, len, chunk0, false, cv); return; }
+    size_t left = 1024;                                  // largest power-of-two number of chunks that leaves >= 1 byte on the right
+    while (left * 2 < len) left *= 2;
+    uint32_t m[16];
+    b3_subtree(in, left, chunk0, m);
+    b3_subtree(in + left, len - left, chunk0 + left / 1024, m + 8);
+    b3_iv(cv);
+    b3_compress(cv, m, 0, 0, 64, B3_PARENT);
+}
+// BLAKE3 of any length (the prover itself only hashes rows of at most two chunks and 64-byte node pairs)
 inline bool blake3_short(const uint8_t* in, size_t len, uint8_t out[32]) {
     uint32_t cv[8];
     if (len <= 1024) b3_chunk(in, len, 0, true, cv);
-    else if (len <= 2048) {
+    else {
+        size_t left = 1024;
+        while (left * 2 < len) left *= 2;
         uint32_t m[16];
-        b3_chunk(in, 1024, 0, false, m);
-        b3_chunk(in + 1024, len - 1024, 1, false, m + 8);
+        b3_subtree(in, left, 0, m);
+        b3_subtree(in + left, len - left, left / 1024, m + 8);
         b3_iv(cv);
         b3_compress(cv, m, 0, 0, 64, B3_PARENT | B3_ROOT);
-    } else return false;
+    }
     memcpy(out, cv, 32);
     return true;
 }

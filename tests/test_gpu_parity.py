@@ -350,3 +350,20 @@ def test_plain_c_host_produces_the_oracle_proof(oracle, tmp_path):
     subprocess.check_call([exe, "10", str(out)])
     t = oracle.fibonacci_trace(1 << 10)
     assert out.read_bytes() == oracle.Prover.from_trace(t, 1).prove()
+
+
+def test_gpu_proofs_match_golden_digests():
+    """Committed fixtures (tests/golden/proof_digests.json, made by the oracle): no oracle run involved on the GPU box."""
+    import json
+    import os
+    import distaff_amd as D
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "proof_digests.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        cols, program_hash, result = D.fibonacci_trace(c["log_n"])
+        assert program_hash.hex() == c["program_hash"]
+        ctx = D.Context(c["log_n"], 20, 1, 0, log_blowup=c["extension_factor"].bit_length() - 1, num_queries=c["num_queries"], grinding=c["grinding_factor"])
+        ctx.upload(cols)
+        proof = ctx.prove([1, 0], [result])
+        ctx.close()
+        assert len(proof) == c["proof_bytes"] and D.blake3(proof).hex() == c["proof_blake3"], c

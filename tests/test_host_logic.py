@@ -35,7 +35,8 @@ def test_library_fiat_shamir_helpers_equal_oracle(oracle):
 def test_blake3_lengths(oracle):
     import distaff_amd as D
     data = bytes(range(256)) * 5
-    for n in (0, 1, 31, 32, 33, 63, 64, 65, 127, 128):
+    data = data * 60
+    for n in (0, 1, 31, 32, 33, 63, 64, 65, 127, 128, 1023, 1024, 1025, 2048, 2049, 3072, 3073, 4096, 5000, 7 * 1024 + 1, 54239, 65536):
         assert D.blake3(data[:n]) == oracle.blake3(data[:n])
 
 

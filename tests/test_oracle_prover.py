@@ -125,3 +125,19 @@ def test_stepwise_equals_one_shot_and_challenge_override(oracle):
     c.step(1); c.step(2); c.step(3, a.get("constraint_draws")); c.step(4); c.step(5); c.step(6, a.get("deep_draws"))
     assert c.get_bytes("roots") == a.get_bytes("roots")
     assert (c.get("composed_evaluations") == a.get("composed_evaluations")).all()
+
+
+def test_oracle_reproduces_golden_proof_digests(oracle):
+    """End-to-end regression pin: the oracle's serialised proofs hash to the committed digests (tests/golden/proof_digests.json)."""
+    import json
+    import os
+    O = oracle
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "proof_digests.json")) as f:
+        cases = json.load(f)["cases"]
+    for c in cases:
+        if c["log_n"] > 10:
+            continue                                               # keep the CPU suite short; the GPU test covers every case
+        t = O.fibonacci_trace(1 << c["log_n"])
+        proof = O.Prover.from_trace(t, 1, ext=c["extension_factor"], num_queries=c["num_queries"], grinding=c["grinding_factor"]).prove()
+        assert len(proof) == c["proof_bytes"] and O.blake3(proof).hex() == c["proof_blake3"], c
+        assert t.program_hash.hex() == c["program_hash"]
