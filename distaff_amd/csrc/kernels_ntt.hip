@@ -375,12 +375,12 @@ static void dispatch_ntt_reg(dst_ctx* c, uint32_t log_len, const NttRegArgs& a, 
 }
 
 static void launch_pass_reg(dst_ctx* c, bool pass_b, const fe* src, size_t src_col_stride, size_t src_coset_stride,
-                            fe* dst, size_t dst_col_stride, size_t dst_coset_stride, size_t cosets, size_t cols, bool inverse, bool lde) {
+                            fe* dst, size_t dst_col_stride, size_t dst_coset_stride, size_t cosets, size_t cols, bool inverse, bool lde, uint32_t skip) {
     const NttPlan& p = c->plan;
     const size_t n1 = (size_t)1 << p.log_n1, n2 = (size_t)1 << p.log_n2;
     NttRegArgs a{};
     a.log_N = c->log_N; a.log_b = c->log_b; a.lo_bits = c->tw_lo_bits;
-    a.j0 = lde ? (uint32_t)c->j0 : 0u; a.coset_twiddle = lde ? 1u : 0u;
+    a.j0 = lde ? (uint32_t)c->j0 + skip : 0u; a.coset_twiddle = lde ? 1u : 0u;
     for (int j = 0; j < 8; j++) a.c16[j] = inverse ? c->c16i[j] : c->c16f[j];
     a.src = src; a.src_col_stride = src_col_stride; a.src_coset_stride = src_coset_stride;
     a.dst = dst; a.dst_col_stride = dst_col_stride; a.dst_coset_stride = dst_coset_stride;
@@ -408,7 +408,7 @@ static uint32_t ntt_tiles_per_block(uint32_t tiles, size_t arrays) {
     return k;
 }
 static void launch_pass_lds(dst_ctx* c, bool pass_b, const fe* src, size_t src_col_stride, size_t src_coset_stride,
-                            fe* dst, size_t dst_col_stride, size_t dst_coset_stride, size_t cosets, size_t cols, bool inverse, bool lde) {
+                            fe* dst, size_t dst_col_stride, size_t dst_coset_stride, size_t cosets, size_t cols, bool inverse, bool lde, uint32_t skip) {
     const NttPlan& p = c->plan;
     static bool lds_limit_raised[64] = {};
     if (c->device >= 0 && c->device < 64 && !lds_limit_raised[c->device]) {     // tile + stage twiddles can exceed the 64 KiB default
@@ -418,7 +418,7 @@ static void launch_pass_lds(dst_ctx* c, bool pass_b, const fe* src, size_t src_c
     }
     NttArgs a{};
     a.log_n1 = p.log_n1; a.log_n2 = p.log_n2; a.log_N = c->log_N; a.log_b = c->log_b; a.lo_bits = c->tw_lo_bits;
-    a.j0 = lde ? (uint32_t)c->j0 : 0u; a.coset_twiddle = lde ? 1u : 0u;
+    a.j0 = lde ? (uint32_t)c->j0 + skip : 0u; a.coset_twiddle = lde ? 1u : 0u;
     a.tw_lo = inverse ? c->itw_lo : c->tw_lo;
     a.tw_hi = inverse ? c->itw_hi : c->tw_hi;
     a.prescale = lde ? c->prescale : nullptr;
@@ -427,7 +427,7 @@ static void launch_pass_lds(dst_ctx* c, bool pass_b, const fe* src, size_t src_c
     a.src = src; a.src_col_stride = src_col_stride; a.src_coset_stride = src_coset_stride;
     a.dst = dst; a.dst_col_stride = dst_col_stride; a.dst_coset_stride = dst_coset_stride;
     if (!pass_b) {
-        a.tw4 = lde ? c->tw4_lde : (inverse ? c->tw4_inv : c->tw4_fwd); a.tw4_coset_stride = lde ? c->n : 0;
+        a.tw4 = lde ? c->tw4_lde + (size_t)skip * c->n : (inverse ? c->tw4_inv : c->tw4_fwd); a.tw4_coset_stride = lde ? c->n : 0;
         a.stage_tw = inverse ? c->w1i : c->w1f; a.tile = (uint32_t)__builtin_ctz(p.tile_a);
         size_t lds_a = (((size_t)1 << p.log_n1) * p.tile_a + ((size_t)1 << p.log_n1) / 2) * sizeof(fe);
         const uint32_t tiles = (1u << p.log_n2) / p.tile_a;
@@ -446,12 +446,13 @@ static void launch_pass_lds(dst_ctx* c, bool pass_b, const fe* src, size_t src_c
     }
 }
 
+// skip: number of leading local cosets left out (their outputs are produced elsewhere); dst points at the first coset computed
 static void launch_two_pass(dst_ctx* c, const fe* src, size_t src_col_stride, size_t src_coset_stride,
                             fe* dst, size_t dst_col_stride, size_t dst_coset_stride,
-                            size_t cosets, size_t cols, bool inverse, bool lde) {
+                            size_t cosets, size_t cols, bool inverse, bool lde, uint32_t skip = 0) {
     // pass A: src -> tmp, pass B: tmp -> dst
-    (c->plan.reg_a ? launch_pass_reg : launch_pass_lds)(c, false, src, src_col_stride, src_coset_stride, c->tmp, c->n * cosets, c->n, cosets, cols, inverse, lde);
-    (c->plan.reg_b ? launch_pass_reg : launch_pass_lds)(c, true, c->tmp, c->n * cosets, c->n, dst, dst_col_stride, dst_coset_stride, cosets, cols, inverse, lde);
+    (c->plan.reg_a ? launch_pass_reg : launch_pass_lds)(c, false, src, src_col_stride, src_coset_stride, c->tmp, c->n * cosets, c->n, cosets, cols, inverse, lde, skip);
+    (c->plan.reg_b ? launch_pass_reg : launch_pass_lds)(c, true, c->tmp, c->n * cosets, c->n, dst, dst_col_stride, dst_coset_stride, cosets, cols, inverse, lde, skip);
 }
 
 // ---- four-step twiddle tables -------------------------------------------------------------------------------------------------------
@@ -490,10 +491,14 @@ void k_intt_columns(dst_ctx* c, const fe* src, fe* dst, size_t ncols) {
 }
 
 void k_lde_columns(dst_ctx* c, const fe* polys, fe* lde, size_t ncols) {
+    // coset 0 of the extension is the trace itself (T(w_n^k) for the interpolant T): when this rank owns it and the polynomials are
+    // the interpolated trace, it is copied instead of transformed (1/B of the extension work)
+    const uint32_t skip = (c->j0 == 0 && polys == c->polys && c->Bc > 1) ? 1u : 0u;
+    if (skip) (void)hipMemcpy2DAsync(lde, c->Bc * c->n * sizeof(fe), c->trace, c->n * sizeof(fe), c->n * sizeof(fe), ncols, hipMemcpyDeviceToDevice, c->stream);
     size_t cap = tmp_capacity_arrays(c) / c->Bc;
     for (size_t done = 0; done < ncols;) {
         size_t cols = ncols - done < cap ? ncols - done : cap;
-        launch_two_pass(c, polys + done * c->n, c->n, 0, lde + done * c->Bc * c->n, c->Bc * c->n, c->n, c->Bc, cols, false, true);
+        launch_two_pass(c, polys + done * c->n, c->n, 0, lde + done * c->Bc * c->n + (size_t)skip * c->n, c->Bc * c->n, c->n, c->Bc - skip, cols, false, true, skip);
         done += cols;
     }
 }
