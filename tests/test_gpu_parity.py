@@ -367,3 +367,51 @@ def test_gpu_proofs_match_golden_digests():
         proof = ctx.prove([1, 0], [result])
         ctx.close()
         assert len(proof) == c["proof_bytes"] and D.blake3(proof).hex() == c["proof_blake3"], c
+
+
+_GLOO_WORKER = r'''
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np
+import torch.distributed as dist
+import distaff_amd as D
+from distaff_amd import sharded
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+cols, program_hash, result = D.fibonacci_trace(12)
+ctx = D.Context(12, 20, 1, 0, device=0, rank=rank, world=world)       # both ranks share GPU 0; shards travel through the host (gloo)
+ctx.upload(cols)
+comm = sharded.TorchComm(dist, None, device_path=False)
+proof = sharded.ShardedProver(ctx, comm).prove([1, 0], [result])
+open(os.path.join(%r, "proof_%%d.bin" %% rank), "wb").write(proof)
+ctx.close()
+dist.destroy_process_group()
+print("ok")
+'''
+
+
+def test_sharded_prover_two_processes_over_gloo(tmp_path):
+    """The multi-process form of the sharded prover (one process per rank, torch.distributed collectives, host-staged shard hand-off)
+    with both processes on the one GPU of the test box: every rank writes the single-context proof."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    import distaff_amd as D
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER % (root, str(tmp_path)))
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    cols, program_hash, result = D.fibonacci_trace(12)
+    ctx = D.Context(12, 20, 1, 0)
+    ctx.upload(cols)
+    expected = ctx.prove([1, 0], [result])
+    ctx.close()
+    for r in range(2):
+        assert (tmp_path / ("proof_%d.bin" % r)).read_bytes() == expected
