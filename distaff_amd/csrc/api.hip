@@ -69,7 +69,7 @@ static std::vector<fe> build_periodic_table() {
 }
 
 static void free_all(dst_ctx* c) {
-    void* ptrs[] = {c->tw_lo, c->tw_hi, c->itw_lo, c->itw_hi, c->w1f, c->w2f, c->w1i, c->w2i, c->prescale, c->tw4_lde, c->tw4_fwd, c->tw4_inv, c->periodic, c->trace, c->polys, c->lde, c->tmp,
+    void* ptrs[] = {c->tw_lo, c->tw_hi, c->itw_lo, c->itw_hi, c->w1f, c->w2f, c->w1i, c->w2i, c->prescale, c->tw4_lde, c->tw4_fwd, c->tw4_inv, c->tw4_row_fwd, c->tw4_row_inv, c->w3f, c->w3i, c->tmp2, c->periodic, c->trace, c->polys, c->lde, c->tmp,
                     c->trace_leaves, c->trace_nodes, c->air_consts, c->ceval, c->cwork, c->cpoly, c->cevals, c->cnodes, c->comp_poly, c->comp, c->scratch, c->d_u64, c->d_stage};
     for (void* p : ptrs) if (p) hipFree(p);
     if (c->gather_buf) hipFree(c->gather_buf);
@@ -105,21 +105,25 @@ static int ctx_init(dst_ctx* c) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamCreate(&c->stream));
 
-    // NTT plan: n = n1 * n2, tiles bounded by 64 KiB of LDS
+    // NTT plan: n = n1 * n2 in two HBM passes, tiles bounded by 64 KiB of LDS; from n = 2^22 (measured cross-over) three passes n = 2^8 * 2^8 * n3 with
+    // 16-column tiles (256-byte HBM segments) instead of 4096-point tiles that hold one or two columns
     NttPlan& pl = c->plan;
-    pl.log_n = c->log_n; pl.log_n1 = (c->log_n + 1) / 2; pl.log_n2 = c->log_n / 2;
-    auto tile_for = [](uint32_t log_len, uint32_t other_len_log) {
-        uint32_t t = 4;
+    const char* force = getenv("DISTAFF_NTT");
+    const bool three = (c->log_n >= 22 && !(force && (!strcmp(force, "reg") || !strcmp(force, "lds")))) || (force && !strcmp(force, "3pass") && c->log_n >= 20);
+    pl.log_n = c->log_n;
+    if (three) { pl.log_n1 = 8; pl.log_n2 = c->log_n - 8; pl.log_n3 = c->log_n - 16; }
+    else { pl.log_n1 = (c->log_n + 1) / 2; pl.log_n2 = c->log_n / 2; pl.log_n3 = 0; }
+    auto tile_for = [](uint32_t log_len, uint32_t other_len_log, uint32_t cap) {
+        uint32_t t = cap;
         while (t > 1 && (((size_t)1 << log_len) * t * sizeof(fe) > 65536 || t > (1u << other_len_log))) t >>= 1;
         return t;
     };
-    pl.tile_a = tile_for(pl.log_n1, pl.log_n2);
-    pl.tile_b = tile_for(pl.log_n2, pl.log_n1);
+    pl.tile_a = tile_for(pl.log_n1, pl.log_n2, three ? 16 : 4);
+    pl.tile_b = three ? tile_for(pl.log_n3, 8, 16) : tile_for(pl.log_n2, pl.log_n1, 4);
     // kernel choice per pass (measured): the LDS radix-2 kernels win while a tile holds >= 2 columns in 64 KiB of LDS; the
-    // register-radix kernels take over for 4096-point tiles.  DISTAFF_NTT=reg|lds forces one family (tests run both).
+    // register-radix kernels take over for 4096-point tiles.  DISTAFF_NTT=reg|lds forces one two-pass family (tests run both).
     {
-        const bool reg_ok = pl.log_n2 >= 6 && pl.log_n1 <= 12;
-        const char* force = getenv("DISTAFF_NTT");
+        const bool reg_ok = !three && pl.log_n2 >= 6 && pl.log_n1 <= 12;
         pl.reg_a = reg_ok && pl.log_n1 >= 12; pl.reg_b = reg_ok && pl.log_n2 >= 12;      // 4096-point tiles: the LDS family is down to one column (16-byte segments)
         if (force && !strcmp(force, "reg") && reg_ok) pl.reg_a = pl.reg_b = true;
         if (force && !strcmp(force, "lds")) pl.reg_a = pl.reg_b = false;
@@ -139,11 +143,19 @@ static int ctx_init(dst_ctx* c) {
     if ((r = dev_upload(c, &c->tw_hi, h_powers(h_pow(wN, (u128)1 << c->tw_lo_bits), (size_t)1 << hi_bits)))) return r;
     if ((r = dev_upload(c, &c->itw_lo, h_powers(wN_inv, (size_t)1 << c->tw_lo_bits)))) return r;
     if ((r = dev_upload(c, &c->itw_hi, h_powers(h_pow(wN_inv, (u128)1 << c->tw_lo_bits), (size_t)1 << hi_bits)))) return r;
-    fe w1 = h_root_of_unity(pl.log_n1), w2 = h_root_of_unity(pl.log_n2);
+    const uint32_t log_second = pl.log_n3 ? 8 : pl.log_n2;        // three-pass: w2* serve the middle pass (length 2^8)
+    fe w1 = h_root_of_unity(pl.log_n1), w2 = h_root_of_unity(log_second);
     if ((r = dev_upload(c, &c->w1f, h_powers(w1, (size_t)1 << (pl.log_n1 - 1))))) return r;
-    if ((r = dev_upload(c, &c->w2f, h_powers(w2, (size_t)1 << (pl.log_n2 - 1))))) return r;
+    if ((r = dev_upload(c, &c->w2f, h_powers(w2, (size_t)1 << (log_second - 1))))) return r;
     if ((r = dev_upload(c, &c->w1i, h_powers(h_inv(w1), (size_t)1 << (pl.log_n1 - 1))))) return r;
-    if ((r = dev_upload(c, &c->w2i, h_powers(h_inv(w2), (size_t)1 << (pl.log_n2 - 1))))) return r;
+    if ((r = dev_upload(c, &c->w2i, h_powers(h_inv(w2), (size_t)1 << (log_second - 1))))) return r;
+    if (pl.log_n3) {
+        fe w3 = h_root_of_unity(pl.log_n3);
+        if ((r = dev_upload(c, &c->w3f, h_powers(w3, (size_t)1 << (pl.log_n3 - 1))))) return r;
+        if ((r = dev_upload(c, &c->w3i, h_powers(h_inv(w3), (size_t)1 << (pl.log_n3 - 1))))) return r;
+        if ((r = dev_alloc(c, &c->tw4_row_fwd, (size_t)1 << pl.log_n2))) return r;
+        if ((r = dev_alloc(c, &c->tw4_row_inv, (size_t)1 << pl.log_n2))) return r;
+    }
     if ((r = dev_upload(c, &c->prescale, h_powers(h_root_of_unity(c->log_b + pl.log_n1), (size_t)1 << (c->log_b + pl.log_n1))))) return r;
     if ((r = dev_alloc(c, &c->tw4_lde, c->Bc * c->n))) return r;
     if ((r = dev_alloc(c, &c->tw4_fwd, c->n))) return r;
@@ -162,6 +174,7 @@ static int ctx_init(dst_ctx* c) {
     if ((r = dev_alloc(c, &c->polys, c->W * n))) return r;
     if ((r = dev_alloc(c, &c->lde, c->W * Nl))) return r;
     if ((r = dev_alloc(c, &c->tmp, c->Bc * 4 * n))) return r;
+    if (pl.log_n3 && (r = dev_alloc(c, &c->tmp2, c->Bc * 4 * n))) return r;
     if ((r = dev_alloc(c, &c->trace_leaves, Nl))) return r;
     if ((r = dev_alloc(c, &c->trace_nodes, Nl))) return r;
     if ((r = dev_alloc(c, &c->ceval, 3 * 8 * n))) return r;

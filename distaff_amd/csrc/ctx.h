@@ -45,7 +45,8 @@ enum {
 };
 
 struct NttPlan {
-    uint32_t log_n = 0, log_n1 = 0, log_n2 = 0;      // n = n1 * n2, n1 >= n2
+    uint32_t log_n = 0, log_n1 = 0, log_n2 = 0;      // n = n1 * n2: first pass length, rest
+    uint32_t log_n3 = 0;                             // 0: two passes (second pass length n2); else three passes n = n1 * (n2/n3) * n3
     uint32_t tile_a = 1, tile_b = 1;                 // columns per workgroup tile in pass A / pass B
     bool reg_a = false, reg_b = false;               // per pass: register-radix kernel (tile lengths 2^6 .. 2^12) instead of the LDS radix-2 one
 };
@@ -76,6 +77,9 @@ struct dst_ctx {
     // lookup + two; the extra 16 B/element read is free: the pass runs at a tenth of the HBM bandwidth)
     fe *tw4_lde = nullptr;                       // [Bc][n]: w_N^(m2 * (B*k1 + j)), local cosets j
     fe *tw4_fwd = nullptr, *tw4_inv = nullptr;   // [n]: w_n^(m2*k1) and its inverse
+    fe *tw4_row_fwd = nullptr, *tw4_row_inv = nullptr;   // three-pass plans: [n2] twiddles w_{n2}^(k2*m3) of the middle pass and inverse
+    fe *w3f = nullptr, *w3i = nullptr;           // three-pass plans: stage twiddles of the last pass (length n3)
+    fe *tmp2 = nullptr;                          // three-pass plans: second staging buffer
     fe *periodic = nullptr;                      // [128][23] extended Rescue round constants + cycle masks
     void *air_consts = nullptr;                  // AirConsts (Rescue MDS matrices) in device memory
     fe c16f[8], c16i[8];                         // w_16^j and w_16^-j, j < 8 (passed to the NTT kernels by value)

@@ -31,6 +31,10 @@ struct NttArgs {
     uint32_t has_scale;        // 1: multiply the result by `scale` (1/n of inverse transforms)
     uint32_t tiles_per_block;  // adjacent tiles one workgroup walks through
     uint32_t debug;            // DISTAFF_NTT_DEBUG ablation bits (timing experiments only): 1 no pre-scale, 2 no four-step twiddle
+    // pass B addressing (two-pass plans: row stride n2, frequency stride n1, no batch); three-pass plans run the last pass once per
+    // middle frequency k2 (batch index = low bits of blockIdx.x): source rows (k1, k2, .) and destination k1 + n1 * (k2 + n2' * k3)
+    size_t src_row_stride, dst_k_stride, src_batch_stride, dst_batch_stride;
+    uint32_t batch_log;
     fe scale;
 };
 
@@ -162,16 +166,17 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_b(NttArgs a, const fe
     const uint32_t log_t = a.tile, T = 1u << log_t, n1 = 1u << a.log_n1, n2 = 1u << a.log_n2;
     fe* TW = L + n2 * T;
     const uint32_t jl = blockIdx.y;
-    const fe* __restrict__ src = src_base + (size_t)blockIdx.z * a.src_col_stride + (size_t)jl * a.src_coset_stride;
-    fe* __restrict__ dst = dst_base + (size_t)blockIdx.z * a.dst_col_stride + (size_t)jl * a.dst_coset_stride;
+    const uint32_t batch = blockIdx.x & ((1u << a.batch_log) - 1u), group = blockIdx.x >> a.batch_log;
+    const fe* __restrict__ src = src_base + (size_t)blockIdx.z * a.src_col_stride + (size_t)jl * a.src_coset_stride + (size_t)batch * a.src_batch_stride;
+    fe* __restrict__ dst = dst_base + (size_t)blockIdx.z * a.dst_col_stride + (size_t)jl * a.dst_coset_stride + (size_t)batch * a.dst_batch_stride;
     for (uint32_t i = threadIdx.x; i < n2 / 2; i += NTT_THREADS) TW[i] = a.stage_tw[i];
     fe pre0 = fe_zero(), pre1 = fe_zero(), pre2 = fe_zero(), pre3 = fe_zero(), pre4 = fe_zero(), pre5 = fe_zero(), pre6 = fe_zero(), pre7 = fe_zero();
     const uint32_t count = n2 * T;
     // contiguous along m2
-#define NTT_FETCH_B1(e, var, k1_0) { uint32_t idx = threadIdx.x + (e) * NTT_THREADS; idx = idx < count ? idx : 0u; var = src[((size_t)((k1_0) + (idx >> a.log_n2)) << a.log_n2) + (idx & (n2 - 1))]; }
+#define NTT_FETCH_B1(e, var, k1_0) { uint32_t idx = threadIdx.x + (e) * NTT_THREADS; idx = idx < count ? idx : 0u; var = src[(size_t)((k1_0) + (idx >> a.log_n2)) * a.src_row_stride + (idx & (n2 - 1))]; }
 #define NTT_FETCH_B(tile) { const uint32_t f0 = (tile) * T; NTT_FETCH_B1(0, pre0, f0) NTT_FETCH_B1(1, pre1, f0) NTT_FETCH_B1(2, pre2, f0) NTT_FETCH_B1(3, pre3, f0) \
                                                         NTT_FETCH_B1(4, pre4, f0) NTT_FETCH_B1(5, pre5, f0) NTT_FETCH_B1(6, pre6, f0) NTT_FETCH_B1(7, pre7, f0) }
-    const uint32_t tile0 = blockIdx.x * a.tiles_per_block;
+    const uint32_t tile0 = group * a.tiles_per_block;
     NTT_FETCH_B(tile0)
     for (uint32_t it = 0; it < a.tiles_per_block; it++) {
         const uint32_t k1_0 = (tile0 + it) * T;
@@ -187,7 +192,7 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_b(NttArgs a, const fe
             uint32_t k2 = a.log_n2 ? (__brev(r) >> (32 - a.log_n2)) : 0u;
             fe v = L[idx];
             if (a.has_scale) v = fe_mul(v, a.scale);
-            dst[((size_t)k2 << a.log_n1) + k1_0 + t] = v;
+            dst[(size_t)k2 * a.dst_k_stride + k1_0 + t] = v;
         }
     }
 }
@@ -437,6 +442,7 @@ static void launch_pass_lds(dst_ctx* c, bool pass_b, const fe* src, size_t src_c
         hipLaunchKernelGGL(ntt_pass_a, ga, dim3(NTT_THREADS), lds_a, c->stream, a, a.src, a.dst);
     } else {
         a.stage_tw = inverse ? c->w2i : c->w2f; a.tile = (uint32_t)__builtin_ctz(p.tile_b);
+        a.src_row_stride = (size_t)1 << p.log_n2; a.dst_k_stride = (size_t)1 << p.log_n1; a.batch_log = 0; a.src_batch_stride = a.dst_batch_stride = 0;
         size_t lds_b = (((size_t)1 << p.log_n2) * p.tile_b + ((size_t)1 << p.log_n2) / 2) * sizeof(fe);
         const uint32_t tiles = (1u << p.log_n1) / p.tile_b;
         a.tiles_per_block = ntt_tiles_per_block(tiles, cosets * cols);
@@ -446,16 +452,90 @@ static void launch_pass_lds(dst_ctx* c, bool pass_b, const fe* src, size_t src_c
     }
 }
 
+// n = 2^8 * 2^8 * n3 in three HBM passes with 16-column tiles, all on the LDS-family kernels:
+//   pass 1 (ntt_pass_a, shape 2^8 x n/2^8): as the first pass of a two-pass plan (coset pre-scale, twiddle w_N^(m'*(B*k1+j)));
+//   pass 2 (ntt_pass_a, shape 2^8 x n3 on each of the cosets*2^8 rows of n/2^8 points): twiddle w_{n/2^8}^(k2*m3);
+//   pass 3 (ntt_pass_b, n3 points, tile = 16 adjacent k1, one batch per k2): natural-order store at k1 + 2^8*(k2 + 2^8*k3).
+static void launch_three_pass(dst_ctx* c, const fe* src, size_t src_col_stride, size_t src_coset_stride,
+                              fe* dst, size_t dst_col_stride, size_t dst_coset_stride,
+                              size_t cosets, size_t cols, bool inverse, bool lde, uint32_t skip) {
+    const NttPlan& p = c->plan;
+    const uint32_t log_mid = p.log_n2 - p.log_n3;                      // 8
+    const size_t n = c->n, nrow = (size_t)1 << p.log_n2, n3 = (size_t)1 << p.log_n3, n1 = (size_t)1 << p.log_n1;
+    static bool lds_limit_raised[64] = {};
+    if (c->device >= 0 && c->device < 64 && !lds_limit_raised[c->device]) {
+        (void)hipFuncSetAttribute((const void*)ntt_pass_a, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        (void)hipFuncSetAttribute((const void*)ntt_pass_b, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        lds_limit_raised[c->device] = true;
+    }
+    NttArgs a{};
+    a.log_N = c->log_N; a.log_b = c->log_b; a.lo_bits = c->tw_lo_bits;
+    a.tw_lo = inverse ? c->itw_lo : c->tw_lo; a.tw_hi = inverse ? c->itw_hi : c->tw_hi;
+    a.scale = c->n_inv;
+    { const char* dbg = getenv("DISTAFF_NTT_DEBUG"); a.debug = dbg ? (uint32_t)atoi(dbg) : 0u; }
+    // pass 1: src -> tmp
+    a.log_n1 = p.log_n1; a.log_n2 = p.log_n2; a.tile = (uint32_t)__builtin_ctz(p.tile_a);
+    a.j0 = lde ? (uint32_t)c->j0 + skip : 0u; a.coset_twiddle = lde ? 1u : 0u;
+    a.prescale = lde ? c->prescale : nullptr; a.has_scale = 0;
+    a.tw4 = lde ? c->tw4_lde + (size_t)skip * n : (inverse ? c->tw4_inv : c->tw4_fwd); a.tw4_coset_stride = lde ? n : 0;
+    a.stage_tw = inverse ? c->w1i : c->w1f;
+    a.src = src; a.src_col_stride = src_col_stride; a.src_coset_stride = src_coset_stride;
+    a.dst = c->tmp; a.dst_col_stride = n * cosets; a.dst_coset_stride = n;
+    {
+        const uint32_t tiles = (uint32_t)(nrow / p.tile_a);
+        a.tiles_per_block = ntt_tiles_per_block(tiles, cosets * cols);
+        const size_t lds = (n1 * p.tile_a + n1 / 2) * sizeof(fe);
+        dim3 g((unsigned)(tiles / a.tiles_per_block), (unsigned)cosets, (unsigned)cols);
+        KScope ks_(c, "ntt_pass_a", 16.0 * n * cols * (lde ? (1 + cosets) : 2 * cosets));
+        hipLaunchKernelGGL(ntt_pass_a, g, dim3(NTT_THREADS), lds, c->stream, a, a.src, a.dst);
+    }
+    // pass 2: tmp -> tmp2, every (coset, k1) row of nrow points is an array of shape 2^log_mid x n3
+    a.log_n1 = log_mid; a.log_n2 = p.log_n3; a.tile = (uint32_t)__builtin_ctz(p.tile_b);
+    a.j0 = 0; a.coset_twiddle = 0; a.prescale = nullptr;
+    a.tw4 = inverse ? c->tw4_row_inv : c->tw4_row_fwd; a.tw4_coset_stride = 0;
+    a.stage_tw = inverse ? c->w2i : c->w2f;
+    a.src = c->tmp; a.src_col_stride = n * cosets; a.src_coset_stride = nrow;
+    a.dst = c->tmp2; a.dst_col_stride = n * cosets; a.dst_coset_stride = nrow;
+    {
+        const uint32_t tiles = (uint32_t)(n3 / p.tile_b);
+        const size_t rows = cosets * n1;
+        a.tiles_per_block = ntt_tiles_per_block(tiles, rows * cols);
+        const size_t lds = (((size_t)1 << log_mid) * p.tile_b + ((size_t)1 << log_mid) / 2) * sizeof(fe);
+        dim3 g((unsigned)(tiles / a.tiles_per_block), (unsigned)rows, (unsigned)cols);
+        KScope ks_(c, "ntt_pass_mid", 32.0 * n * cols * cosets);
+        hipLaunchKernelGGL(ntt_pass_a, g, dim3(NTT_THREADS), lds, c->stream, a, a.src, a.dst);
+    }
+    // pass 3: tmp2 -> dst
+    a.log_n1 = p.log_n1; a.log_n2 = p.log_n3; a.tile = (uint32_t)__builtin_ctz(p.tile_b);
+    a.tw4 = nullptr; a.has_scale = inverse ? 1u : 0u;
+    a.stage_tw = inverse ? c->w3i : c->w3f;
+    a.src = c->tmp2; a.src_col_stride = n * cosets; a.src_coset_stride = n;
+    a.dst = dst; a.dst_col_stride = dst_col_stride; a.dst_coset_stride = dst_coset_stride;
+    a.src_row_stride = nrow; a.src_batch_stride = n3; a.batch_log = log_mid;
+    a.dst_k_stride = n1 << log_mid; a.dst_batch_stride = n1;
+    {
+        const uint32_t tiles = (uint32_t)(n1 / p.tile_b);
+        a.tiles_per_block = ntt_tiles_per_block(tiles, ((size_t)cosets << log_mid) * cols);
+        const size_t lds = (n3 * p.tile_b + n3 / 2) * sizeof(fe);
+        dim3 g((unsigned)((tiles / a.tiles_per_block) << log_mid), (unsigned)cosets, (unsigned)cols);
+        KScope ks_(c, "ntt_pass_b", 32.0 * n * cols * cosets);
+        hipLaunchKernelGGL(ntt_pass_b, g, dim3(NTT_THREADS), lds, c->stream, a, a.src, a.dst);
+    }
+}
+
 // skip: number of leading local cosets left out (their outputs are produced elsewhere); dst points at the first coset computed
 static void launch_two_pass(dst_ctx* c, const fe* src, size_t src_col_stride, size_t src_coset_stride,
                             fe* dst, size_t dst_col_stride, size_t dst_coset_stride,
                             size_t cosets, size_t cols, bool inverse, bool lde, uint32_t skip = 0) {
+    if (c->plan.log_n3) { launch_three_pass(c, src, src_col_stride, src_coset_stride, dst, dst_col_stride, dst_coset_stride, cosets, cols, inverse, lde, skip); return; }
     // pass A: src -> tmp, pass B: tmp -> dst
     (c->plan.reg_a ? launch_pass_reg : launch_pass_lds)(c, false, src, src_col_stride, src_coset_stride, c->tmp, c->n * cosets, c->n, cosets, cols, inverse, lde, skip);
     (c->plan.reg_b ? launch_pass_reg : launch_pass_lds)(c, true, c->tmp, c->n * cosets, c->n, dst, dst_col_stride, dst_coset_stride, cosets, cols, inverse, lde, skip);
 }
 
 // ---- four-step twiddle tables -------------------------------------------------------------------------------------------------------
+// out[coset][k1][m2] = w_N^(m2 * ((k1 << log_b) + j)) for a transform of 2^log_n points whose inner dimension has 2^log_n2 points;
+// a sub-transform of length n' = n / 2^s is expressed with log_b + s (its root is w_N^(B * 2^s))
 __global__ void twiddle_table_kernel(fe* out, const fe* tw_lo, const fe* tw_hi, uint32_t lo_bits, uint32_t log_n2, uint32_t log_n, uint32_t log_b,
                                      uint32_t log_N, uint32_t j0, uint32_t coset_twiddle) {
     const size_t n = (size_t)1 << log_n;
@@ -473,6 +553,11 @@ int k_build_twiddle_tables(dst_ctx* c) {
     g.y = 1;
     hipLaunchKernelGGL(twiddle_table_kernel, g, dim3(256), 0, c->stream, c->tw4_fwd, c->tw_lo, c->tw_hi, c->tw_lo_bits, p.log_n2, c->log_n, c->log_b, c->log_N, 0u, 0u);
     hipLaunchKernelGGL(twiddle_table_kernel, g, dim3(256), 0, c->stream, c->tw4_inv, c->itw_lo, c->itw_hi, c->tw_lo_bits, p.log_n2, c->log_n, c->log_b, c->log_N, 0u, 0u);
+    if (p.log_n3) {       // middle pass of a three-pass plan: rows of n' = n2 points, w_{n'}^(k2*m3) = w_N^(m3 * (k2 << (log_b + log_n1)))
+        dim3 gr((unsigned)((((size_t)1 << p.log_n2) + 255) / 256), 1u);
+        hipLaunchKernelGGL(twiddle_table_kernel, gr, dim3(256), 0, c->stream, c->tw4_row_fwd, c->tw_lo, c->tw_hi, c->tw_lo_bits, p.log_n3, p.log_n2, c->log_b + p.log_n1, c->log_N, 0u, 0u);
+        hipLaunchKernelGGL(twiddle_table_kernel, gr, dim3(256), 0, c->stream, c->tw4_row_inv, c->itw_lo, c->itw_hi, c->tw_lo_bits, p.log_n3, p.log_n2, c->log_b + p.log_n1, c->log_N, 0u, 0u);
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     return DST_OK;
