@@ -82,9 +82,12 @@ __device__ __forceinline__ void static_for_air(F&& f) {
 // instead of ~21k for flag products + per-term multiply-adds.  st_term states, per operation and slot, exactly what the
 // per-operation code below passes to agg(): slots 0..3 are the stack constraints, 4 and 5 the two auxiliary constraints.
 struct StackRows { fe o[8], nw[8], hd0; };
+#define ST_AUX0 8
+#define ST_AUX1 9
 
+// stack slots 0..7 (the slice always has max(depth, 8) = 8 items for depth <= 8), ST_AUX0, ST_AUX1
 template <int OP, int I> constexpr bool st_has() {
-    constexpr bool slot = I < 4, aux0 = I == 4, aux1 = I == 5;
+    constexpr bool slot = I < 8, aux0 = I == ST_AUX0, aux1 = I == ST_AUX1;
     switch (OP) {
         case 0x00: case 0x01: case 0x05: case 0x06: case 0x07: return slot || aux0;       // ASSERT, ASSERTEQ, CHOOSE, CHOOSE2, CSWAP2
         case 0x02: case 0x0E: return slot || aux0;                                       // EQ, NOT
@@ -93,7 +96,7 @@ template <int OP, int I> constexpr bool st_has() {
         case 0x10: return I >= 1 && slot;                                                // READ
         case 0x11: return I >= 2 && slot;                                                // READ2
         case 0x12: case 0x13: case 0x14: case 0x15: return slot;                         // DUP, DUP2, DUP4, PAD2
-        case 0x18: return I == 0 || I == 2 || I == 3;                                    // SWAP: both constraints in slot 0 (manipulation.rs:63-64)
+        case 0x18: return slot && I != 1;                                                // SWAP: both constraints in slot 0 (manipulation.rs:63-64)
         case 0x19: case 0x1A: case 0x1B: case 0x1C: case 0x1D: return slot;              // SWAP2, SWAP4, ROLL4, ROLL8, BINACC
         default: return false;
     }
@@ -102,57 +105,59 @@ template <int OP, int I> constexpr bool st_has() {
 template <int OP, int I>
 __device__ __forceinline__ fe st_term(const StackRows& s) {
     const fe* o = s.o; const fe* nw = s.nw;
-    constexpr int i = I < 4 ? I : 0;
-    auto L = [&](int num) { return fe_sub(o[i + num], nw[i]); };          // left shift by num
-    auto R = [&](int num) { return fe_sub(o[i - num < 0 ? 0 : i - num], nw[i]); };   // right shift by num
+    constexpr int i = I < 8 ? I : 0;
+    // the shift helpers of constraints/stack/mod.rs on an 8-item slice: a left shift by num zero-fills the last num slots
+    auto L = [&](int num) { return i + num < 8 ? fe_sub(o[i + num < 8 ? i + num : 0], nw[i]) : nw[i]; };
+    auto R = [&](int num) { return fe_sub(o[i - num < 0 ? 0 : i - num], nw[i]); };   // right shift by num (callers: i >= num)
     auto C = [&]() { return fe_sub(o[i], nw[i]); };                       // copy
     auto sel = [&](const fe& c, const fe& x, const fe& y) { return fe_add(y, fe_mul(c, fe_sub(x, y))); };   // c*x + (1-c)*y with one multiplication
-    if constexpr (OP == 0x00) { if constexpr (I == 4) return fe_mul(s.hd0, bnot(o[0])); else return fe_mul(s.hd0, L(1)); }   // ASSERT flag carries hd[0] (trace_state.rs:346)
-    else if constexpr (OP == 0x01) { if constexpr (I == 4) return fe_sub(o[0], o[1]); else return L(2); }
+    if constexpr (OP == 0x00) { if constexpr (I == ST_AUX0) return fe_mul(s.hd0, bnot(o[0])); else return fe_mul(s.hd0, L(1)); }   // ASSERT flag carries hd[0] (trace_state.rs:346)
+    else if constexpr (OP == 0x01) { if constexpr (I == ST_AUX0) return fe_sub(o[0], o[1]); else return L(2); }
     else if constexpr (OP == 0x02) {
         const fe diff = fe_sub(o[1], o[2]);
-        if constexpr (I == 4) return fe_mul(nw[0], diff);
+        if constexpr (I == ST_AUX0) return fe_mul(nw[0], diff);
         else if constexpr (I == 0) return fe_sub(nw[0], bnot(fe_mul(diff, o[0])));
         else return L(2);
     }
     else if constexpr (OP == 0x03) return L(1);
     else if constexpr (OP == 0x04) return L(4);
     else if constexpr (OP == 0x05) {
-        if constexpr (I == 4) return is_bin(o[2]);
+        if constexpr (I == ST_AUX0) return is_bin(o[2]);
         else if constexpr (I == 0) return fe_sub(nw[0], sel(o[2], o[0], o[1]));
         else return L(2);
     }
     else if constexpr (OP == 0x06) {
-        if constexpr (I == 4) return is_bin(o[4]);
+        if constexpr (I == ST_AUX0) return is_bin(o[4]);
         else if constexpr (I == 0) return fe_sub(nw[0], sel(o[4], o[0], o[2]));
         else if constexpr (I == 1) return fe_sub(nw[1], sel(o[4], o[1], o[3]));
         else return L(4);
     }
     else if constexpr (OP == 0x07) {
-        if constexpr (I == 4) return is_bin(o[4]);
+        if constexpr (I == ST_AUX0) return is_bin(o[4]);
         else if constexpr (I == 0) return fe_sub(nw[0], sel(o[4], o[2], o[0]));
         else if constexpr (I == 1) return fe_sub(nw[1], sel(o[4], o[3], o[1]));
         else if constexpr (I == 2) return fe_sub(nw[2], sel(o[4], o[0], o[2]));
-        else return fe_sub(nw[3], sel(o[4], o[1], o[3]));
+        else if constexpr (I == 3) return fe_sub(nw[3], sel(o[4], o[1], o[3]));
+        else return L(2);
     }
     else if constexpr (OP == 0x08) { if constexpr (I == 0) return fe_sub(nw[0], fe_add(o[0], o[1])); else return L(1); }
     else if constexpr (OP == 0x09) { if constexpr (I == 0) return fe_sub(nw[0], fe_mul(o[0], o[1])); else return L(1); }
     else if constexpr (OP == 0x0A) {
-        if constexpr (I == 4) return is_bin(o[0]);
-        else if constexpr (I == 5) return is_bin(o[1]);
+        if constexpr (I == ST_AUX0) return is_bin(o[0]);
+        else if constexpr (I == ST_AUX1) return is_bin(o[1]);
         else if constexpr (I == 0) return fe_sub(nw[0], fe_mul(o[0], o[1]));
         else return L(1);
     }
     else if constexpr (OP == 0x0B) {
-        if constexpr (I == 4) return is_bin(o[0]);
-        else if constexpr (I == 5) return is_bin(o[1]);
+        if constexpr (I == ST_AUX0) return is_bin(o[0]);
+        else if constexpr (I == ST_AUX1) return is_bin(o[1]);
         else if constexpr (I == 0) return fe_sub(nw[0], fe_sub(fe_add(o[0], o[1]), fe_mul(o[0], o[1])));     // 1 - (1-x)(1-y) = x + y - xy (shares xy with MUL / AND)
         else return L(1);
     }
     else if constexpr (OP == 0x0C) { if constexpr (I == 0) return fe_sub(fe_one(), fe_mul(nw[0], o[0])); else return C(); }
     else if constexpr (OP == 0x0D) { if constexpr (I == 0) return fe_add(nw[0], o[0]); else return C(); }
     else if constexpr (OP == 0x0E) {
-        if constexpr (I == 4) return is_bin(o[0]);
+        if constexpr (I == ST_AUX0) return is_bin(o[0]);
         else if constexpr (I == 0) return fe_sub(nw[0], bnot(o[0]));
         else return C();
     }
@@ -160,18 +165,19 @@ __device__ __forceinline__ fe st_term(const StackRows& s) {
     else if constexpr (OP == 0x11) return R(2);
     else if constexpr (OP == 0x12) { if constexpr (I == 0) return fe_sub(nw[0], o[0]); else return R(1); }
     else if constexpr (OP == 0x13) { if constexpr (I < 2) return fe_sub(nw[i], o[i]); else return R(2); }
-    else if constexpr (OP == 0x14) return fe_sub(nw[i], o[i]);
+    else if constexpr (OP == 0x14) { if constexpr (I < 4) return fe_sub(nw[i], o[i]); else return R(4); }
     else if constexpr (OP == 0x15) { if constexpr (I < 2) return nw[i]; else return R(2); }
     else if constexpr (OP == 0x18) { if constexpr (I == 0) return fe_add(fe_sub(nw[0], o[1]), fe_sub(nw[1], o[0])); else return C(); }
-    else if constexpr (OP == 0x19) return fe_sub(nw[i], o[i ^ 2]);
-    else if constexpr (OP == 0x1A) return fe_sub(nw[i], o[4 + i]);
-    else if constexpr (OP == 0x1B) return fe_sub(nw[i], o[(i + 3) & 3]);
+    else if constexpr (OP == 0x19) { if constexpr (I < 4) return fe_sub(nw[i], o[i ^ 2]); else return C(); }
+    else if constexpr (OP == 0x1A) return fe_sub(nw[i], o[i ^ 4]);
+    else if constexpr (OP == 0x1B) { if constexpr (I < 4) return fe_sub(nw[i], o[(i + 3) & 3]); else return C(); }
     else if constexpr (OP == 0x1C) return fe_sub(nw[i], o[(i + 7) & 7]);
     else if constexpr (OP == 0x1D) {
         if constexpr (I == 0) return is_bin(nw[0]);
         else if constexpr (I == 1) return nw[1];
         else if constexpr (I == 2) return fe_sub(nw[2], fe_double(o[2]));
-        else return fe_sub(nw[3], fe_add(o[3], fe_mul(nw[0], o[2])));
+        else if constexpr (I == 3) return fe_sub(nw[3], fe_add(o[3], fe_mul(nw[0], o[2])));
+        else return C();
     }
     else return fe_zero();
 }
@@ -331,7 +337,7 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
     }
 
     const fe* per = a.periodic + (size_t)(step & 127u) * 23;
-    constexpr bool ADJ_ACC = (SECT & 2) == 0 && SD != 0;      // op bits emit into five groups: too many accumulators
+    constexpr bool ADJ_ACC = (SECT & 2) == 0 && (SD != 0 || SLCAP == 8);      // op bits emit into five groups: too many accumulators
     Acc<ADJ_ACC> acc;
     if constexpr (ADJ_ACC) {
 #pragma unroll
@@ -460,8 +466,9 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
             }
         };
         fe f;
-        if constexpr (SD == 4 && (SECT & 8) != 0) {
-            // stack depth 4: all low-degree operations (both halves) as nested sums, see st_low_degree
+        constexpr bool NESTED = SD == 4 || (SD == 0 && SLCAP == 8);      // depth 4 exactly, or any depth <= 8 (all 8 slots, `sd` of them emitted)
+        if constexpr (NESTED && (SECT & 8) != 0) {
+            // all low-degree operations (both halves) as nested sums, see st_low_degree
             StackRows rows;
 #pragma unroll
             for (int i = 0; i < 8; i++) { rows.o[i] = o[i]; rows.nw[i] = nw[i]; }
@@ -470,10 +477,16 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
             ev[1] = st_low_degree<1>(rows, lo2, mid, top);
             ev[2] = st_low_degree<2>(rows, lo2, mid, top);
             ev[3] = st_low_degree<3>(rows, lo2, mid, top);
-            aux0 = st_low_degree<4>(rows, lo2, mid, top);
-            aux1 = st_low_degree<5>(rows, lo2, mid, top);
+            if constexpr (SD != 4) {
+                ev[4] = st_low_degree<4>(rows, lo2, mid, top);
+                ev[5] = st_low_degree<5>(rows, lo2, mid, top);
+                ev[6] = st_low_degree<6>(rows, lo2, mid, top);
+                ev[7] = st_low_degree<7>(rows, lo2, mid, top);
+            }
+            aux0 = st_low_degree<ST_AUX0>(rows, lo2, mid, top);
+            aux1 = st_low_degree<ST_AUX1>(rows, lo2, mid, top);
         }
-        if constexpr (SD != 4 && (SECT & 8) != 0) {
+        if constexpr (!NESTED && (SECT & 8) != 0) {
         // flags that only shift / copy are merged before the multiplications
         // right shift by 1: READ (0x10), DUP (0x12)  (PUSH is with the high-degree ops)
         f = LDF(0x12); agg(0, f, fe_sub(nw[0], o[0]));
@@ -514,7 +527,7 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
         for (int i = 1; i < 8; i++) agg(i, f, fe_sub(nw[i], o[i - 1]));
         copy_from(8, f);
         }   // low-degree ops that only move stack items
-        if constexpr (SD != 4 && (SECT & 32) != 0) {
+        if constexpr (!NESTED && (SECT & 32) != 0) {
         // ADD (0x08), MUL (0x09), AND (0x0A), OR (0x0B): left shift (2,1)
         {
             fe xy = fe_mul(o[0], o[1]);

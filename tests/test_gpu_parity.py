@@ -94,6 +94,17 @@ def test_other_program_shapes(oracle):
                       num_outputs=3)                                                                      # stack deeper than 8
 
 
+def test_program_shapes_with_stack_depth_5_to_8(oracle):
+    """Stack depth 5..8 (with and without a context register): the depth <= 8 kernel instance evaluates the low-degree stack
+    operations as nested sums over all eight slots."""
+    import distaff_amd as D
+    O = oracle
+    _check_all_phases(O, D, O.Trace("begin push.3 push.4 push.5 mul add dup.2 add drop end", [1, 2]), num_outputs=2)                       # depth 5
+    _check_all_phases(O, D, O.Trace("begin dup.4 add mul swap.2 add drop drop block push.9 mul end end", [1, 2, 3, 4]), num_outputs=2)     # depth 8
+    _check_all_phases(O, D, O.Trace("begin dup.4 add mul swap.2 add block dup.2 add drop push.9 mul end drop end", [1, 2, 3, 4]), num_outputs=3)
+    _check_all_phases(O, D, O.Trace("begin dup.2 dup.2 dup.2 add mul block swap.2 dup.2 drop add end mul end", [1, 2]), num_outputs=4)
+
+
 def test_blowup_16_and_64(oracle):
     import distaff_amd as D
     _check_all_phases(oracle, D, oracle.fibonacci_trace(256), log_blowup=4, num_queries=100)       # config 5's options
