@@ -2,7 +2,17 @@
 #include "air_kernel.h"
 #include "rescue_constants.h"
 
-void air_launch_generic(dst_ctx* c, const AirArgs& a, uint32_t Q) { launch_air<16, 8, 0, 32, 127, true, true>(c, a, Q); }
+void air_launch_generic(dst_ctx* c, const AirArgs& a, uint32_t Q) {
+    // any shape the VM can produce (up to 16 context, 8 loop and 32 stack registers, known at run time), per-operation formulation,
+    // cut into the same section launches as the specialised instances
+    launch_air<16, 8, 0, 32, 2, true, false>(c, a, Q);     // op bits
+    launch_air<16, 8, 0, 32, 1, false, false>(c, a, Q);    // boundary
+    launch_air<16, 8, 0, 32, 4, false, false>(c, a, Q);    // sponge, loop image, context / loop stacks
+    launch_air<16, 8, 0, 32, 8, false, false>(c, a, Q);    // stack: low-degree ops that move items
+    launch_air<16, 8, 0, 32, 32, false, false>(c, a, Q);   // stack: low-degree arithmetic / selection ops
+    launch_air<16, 8, 0, 32, 16, false, false>(c, a, Q);   // stack: PUSH, CMP, BEGIN / NOOP
+    launch_air<16, 8, 0, 32, 64, false, true>(c, a, Q);    // stack: RESCR + combination
+}
 
 
 int k_eval_constraints(dst_ctx* c, const fe* coeffs_dev, const fe* tc_dev, int64_t* bad_step) {
@@ -31,8 +41,11 @@ int k_eval_constraints(dst_ctx* c, const fe* coeffs_dev, const fe* tc_dev, int64
     HIP_TRY(c, hipMemcpyAsync(c->d_u64, &init, 8, hipMemcpyHostToDevice, c->stream));
     const uint32_t cd = c->prm.ctx_depth, lp = c->prm.loop_depth, sd = (uint32_t)c->stack_depth;
     a.cl = cd > 1 ? cd : 1; a.ll = lp > 1 ? lp : 1; a.sl = sd > 8 ? sd : 8;
-    if (a.cl <= 2 && a.ll <= 1 && sd == 4) air_launch_sd4(c, a, Q);
-    else if (a.cl <= 2 && a.ll <= 1 && sd <= 8) air_launch_small(c, a, Q);
+    // DISTAFF_AIR=generic|small forces a more general instance than the shape needs (tests run the same trace through all of them)
+    const char* force = getenv("DISTAFF_AIR");
+    const bool want_generic = force && !strcmp(force, "generic"), want_small = force && !strcmp(force, "small");
+    if (a.cl <= 2 && a.ll <= 1 && sd == 4 && !want_generic && !want_small) air_launch_sd4(c, a, Q);
+    else if (a.cl <= 2 && a.ll <= 1 && sd <= 8 && !want_generic) air_launch_small(c, a, Q);
     else air_launch_generic(c, a, Q);
     unsigned long long res = 0;
     HIP_TRY(c, hipMemcpyAsync(&res, c->d_u64, 8, hipMemcpyDeviceToHost, c->stream));

@@ -426,3 +426,12 @@ def test_sharded_prover_two_processes_over_gloo(tmp_path):
     ctx.close()
     for r in range(2):
         assert (tmp_path / ("proof_%d.bin" % r)).read_bytes() == expected
+
+
+@pytest.mark.parametrize("instance", ["small", "generic"])
+def test_general_constraint_instances_on_the_fibonacci_trace(oracle, monkeypatch, instance):
+    """The depth <= 8 and the any-shape instances of the constraint kernel, forced onto a trace the depth-4 instance would take:
+    same evaluations, same proof (DISTAFF_AIR is read by the library at every evaluation)."""
+    import distaff_amd as D
+    monkeypatch.setenv("DISTAFF_AIR", instance)
+    _check_all_phases(oracle, D, oracle.fibonacci_trace(1 << 10))
