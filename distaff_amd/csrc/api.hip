@@ -105,13 +105,19 @@ static int ctx_init(dst_ctx* c) {
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamCreate(&c->stream));
 
-    // NTT plan: n = n1 * n2 in two HBM passes, tiles bounded by 64 KiB of LDS; from n = 2^22 (measured cross-over) three passes n = 2^8 * 2^8 * n3 with
+    // NTT plan: n = n1 * n2 in two HBM passes, tiles bounded by 64 KiB of LDS; from n = 2^21 (measured cross-over) three passes n = n1 * nm * n3 with
     // 16-column tiles (256-byte HBM segments) instead of 4096-point tiles that hold one or two columns
     NttPlan& pl = c->plan;
     const char* force = getenv("DISTAFF_NTT");
-    const bool three = (c->log_n >= 22 && !(force && (!strcmp(force, "reg") || !strcmp(force, "lds")))) || (force && !strcmp(force, "3pass") && c->log_n >= 20);
+    const bool three = (c->log_n >= 21 && !(force && (!strcmp(force, "reg") || !strcmp(force, "lds")))) || (force && !strcmp(force, "3pass") && c->log_n >= 20);
     pl.log_n = c->log_n;
-    if (three) { pl.log_n1 = 8; pl.log_n2 = c->log_n - 8; pl.log_n3 = c->log_n - 16; }
+    if (three) {
+        // shape n1 * nm * n3 with n1 >= nm >= n3 as balanced as possible, at most 2^8 each; DISTAFF_NTT_SHAPE=a,b overrides n1, nm (tests)
+        uint32_t a = (c->log_n + 2) / 3, b = (c->log_n - a + 1) / 2;
+        if (a > 8) { a = 8; b = 8; }
+        if (const char* sh = getenv("DISTAFF_NTT_SHAPE")) { unsigned x = 0, y = 0; if (sscanf(sh, "%u,%u", &x, &y) == 2 && x >= 4 && y >= 4 && x <= 8 && y <= 8 && x + y + 4 <= c->log_n && c->log_n - x - y <= 8) { a = x; b = y; } }
+        pl.log_n1 = a; pl.log_n2 = c->log_n - a; pl.log_n3 = c->log_n - a - b;
+    }
     else { pl.log_n1 = (c->log_n + 1) / 2; pl.log_n2 = c->log_n / 2; pl.log_n3 = 0; }
     auto tile_for = [](uint32_t log_len, uint32_t other_len_log, uint32_t cap) {
         uint32_t t = cap;
@@ -119,7 +125,8 @@ static int ctx_init(dst_ctx* c) {
         return t;
     };
     pl.tile_a = tile_for(pl.log_n1, pl.log_n2, three ? 16 : 4);
-    pl.tile_b = three ? tile_for(pl.log_n3, 8, 16) : tile_for(pl.log_n2, pl.log_n1, 4);
+    pl.tile_b = three ? tile_for(pl.log_n3, pl.log_n1, 16) : tile_for(pl.log_n2, pl.log_n1, 4);
+    pl.tile_m = three ? tile_for(pl.log_n2 - pl.log_n3, pl.log_n3, 16) : 1;
     // kernel choice per pass (measured): the LDS radix-2 kernels win while a tile holds >= 2 columns in 64 KiB of LDS; the
     // register-radix kernels take over for 4096-point tiles.  DISTAFF_NTT=reg|lds forces one two-pass family (tests run both).
     {
@@ -143,7 +150,7 @@ static int ctx_init(dst_ctx* c) {
     if ((r = dev_upload(c, &c->tw_hi, h_powers(h_pow(wN, (u128)1 << c->tw_lo_bits), (size_t)1 << hi_bits)))) return r;
     if ((r = dev_upload(c, &c->itw_lo, h_powers(wN_inv, (size_t)1 << c->tw_lo_bits)))) return r;
     if ((r = dev_upload(c, &c->itw_hi, h_powers(h_pow(wN_inv, (u128)1 << c->tw_lo_bits), (size_t)1 << hi_bits)))) return r;
-    const uint32_t log_second = pl.log_n3 ? 8 : pl.log_n2;        // three-pass: w2* serve the middle pass (length 2^8)
+    const uint32_t log_second = pl.log_n3 ? pl.log_n2 - pl.log_n3 : pl.log_n2;        // three-pass: w2* serve the middle pass
     fe w1 = h_root_of_unity(pl.log_n1), w2 = h_root_of_unity(log_second);
     if ((r = dev_upload(c, &c->w1f, h_powers(w1, (size_t)1 << (pl.log_n1 - 1))))) return r;
     if ((r = dev_upload(c, &c->w2f, h_powers(w2, (size_t)1 << (log_second - 1))))) return r;

@@ -48,6 +48,7 @@ struct NttPlan {
     uint32_t log_n = 0, log_n1 = 0, log_n2 = 0;      // n = n1 * n2: first pass length, rest
     uint32_t log_n3 = 0;                             // 0: two passes (second pass length n2); else three passes n = n1 * (n2/n3) * n3
     uint32_t tile_a = 1, tile_b = 1;                 // columns per workgroup tile in pass A / pass B
+    uint32_t tile_m = 1;                             // three-pass plans: columns per tile of the middle pass
     bool reg_a = false, reg_b = false;               // per pass: register-radix kernel (tile lengths 2^6 .. 2^12) instead of the LDS radix-2 one
 };
 

@@ -452,8 +452,8 @@ static void launch_pass_lds(dst_ctx* c, bool pass_b, const fe* src, size_t src_c
     }
 }
 
-// n = 2^8 * 2^8 * n3 in three HBM passes with 16-column tiles, all on the LDS-family kernels:
-//   pass 1 (ntt_pass_a, shape 2^8 x n/2^8): as the first pass of a two-pass plan (coset pre-scale, twiddle w_N^(m'*(B*k1+j)));
+// n = n1 * nm * n3 (each <= 2^8) in three HBM passes with 16-column tiles, all on the LDS-family kernels:
+//   pass 1 (ntt_pass_a, shape n1 x n/n1): as the first pass of a two-pass plan (coset pre-scale, twiddle w_N^(m'*(B*k1+j)));
 //   pass 2 (ntt_pass_a, shape 2^8 x n3 on each of the cosets*2^8 rows of n/2^8 points): twiddle w_{n/2^8}^(k2*m3);
 //   pass 3 (ntt_pass_b, n3 points, tile = 16 adjacent k1, one batch per k2): natural-order store at k1 + 2^8*(k2 + 2^8*k3).
 static void launch_three_pass(dst_ctx* c, const fe* src, size_t src_col_stride, size_t src_coset_stride,
@@ -490,17 +490,17 @@ static void launch_three_pass(dst_ctx* c, const fe* src, size_t src_col_stride, 
         hipLaunchKernelGGL(ntt_pass_a, g, dim3(NTT_THREADS), lds, c->stream, a, a.src, a.dst);
     }
     // pass 2: tmp -> tmp2, every (coset, k1) row of nrow points is an array of shape 2^log_mid x n3
-    a.log_n1 = log_mid; a.log_n2 = p.log_n3; a.tile = (uint32_t)__builtin_ctz(p.tile_b);
+    a.log_n1 = log_mid; a.log_n2 = p.log_n3; a.tile = (uint32_t)__builtin_ctz(p.tile_m);
     a.j0 = 0; a.coset_twiddle = 0; a.prescale = nullptr;
     a.tw4 = inverse ? c->tw4_row_inv : c->tw4_row_fwd; a.tw4_coset_stride = 0;
     a.stage_tw = inverse ? c->w2i : c->w2f;
     a.src = c->tmp; a.src_col_stride = n * cosets; a.src_coset_stride = nrow;
     a.dst = c->tmp2; a.dst_col_stride = n * cosets; a.dst_coset_stride = nrow;
     {
-        const uint32_t tiles = (uint32_t)(n3 / p.tile_b);
+        const uint32_t tiles = (uint32_t)(n3 / p.tile_m);
         const size_t rows = cosets * n1;
         a.tiles_per_block = ntt_tiles_per_block(tiles, rows * cols);
-        const size_t lds = (((size_t)1 << log_mid) * p.tile_b + ((size_t)1 << log_mid) / 2) * sizeof(fe);
+        const size_t lds = (((size_t)1 << log_mid) * p.tile_m + ((size_t)1 << log_mid) / 2) * sizeof(fe);
         dim3 g((unsigned)(tiles / a.tiles_per_block), (unsigned)rows, (unsigned)cols);
         KScope ks_(c, "ntt_pass_mid", 32.0 * n * cols * cosets);
         hipLaunchKernelGGL(ntt_pass_a, g, dim3(NTT_THREADS), lds, c->stream, a, a.src, a.dst);

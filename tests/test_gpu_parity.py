@@ -268,7 +268,7 @@ def _random_columns(W, n, seed):
 
 @pytest.mark.parametrize("family,log_n,log_blowup", [("reg", 13, 5), ("reg", 14, 5), ("reg", 15, 4), ("reg", 16, 5), ("reg", 17, 4), ("reg", 18, 4),
                                                       ("reg", 19, 4), ("reg", 20, 4), ("reg", 21, 4), ("reg", 22, 4), ("reg", 23, 4), ("reg", 24, 4),
-                                                      ("lds", 13, 5), ("lds", 16, 5), ("lds", 19, 4), ("lds", 22, 4), ("auto", 22, 4), ("auto", 23, 4), ("auto", 24, 4), ("3pass", 20, 5)])
+                                                      ("lds", 13, 5), ("lds", 16, 5), ("lds", 19, 4), ("lds", 22, 4), ("auto", 21, 4), ("auto", 22, 4), ("auto", 23, 4), ("auto", 24, 4), ("3pass", 20, 5)])
 def test_lde_every_tile_length(oracle, monkeypatch, family, log_n, log_blowup):
     """Both NTT kernel families (register-radix: every tile length 2^6 .. 2^12 in both passes; LDS radix-2) and the default per-pass
     choice at the largest size, through size-independent properties that pin the
