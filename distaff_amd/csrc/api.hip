@@ -298,6 +298,63 @@ void dst_internal_transition_coefficients(const dst_ctx* c, const fe* draws344, 
             if (deg[k] == d) { tc[k] = cc[2 * i]; tc[nc + k] = cc[2 * i + 1]; i++; }
 }
 
+// The two boundary combinations (evaluator.rs:181-326) in COEFFICIENT form.  With v_k(x) = T_k(x) - const_k for the constrained
+// registers k, the reference evaluates I(x) = sum_k v_k(x) * (cc_k + cc'_k * x^p), p = 6n + 2, on the 8n-point domain and interpolates
+// it again (constraint_table.rs:54-62).  I has degree < 7n + 2 < 8n, so the interpolant is I itself, and its coefficients are two
+// linear combinations of the trace polynomials: A = sum_k cc_k v_k at [0, n) and A' = sum_k cc'_k v_k at [p, p + n).  Nothing is
+// evaluated and nothing is interpolated: ip / fp (8n coefficients each, before the divisions) are written directly.
+// DISTAFF_BOUNDARY=eval keeps the evaluate-and-interpolate route (the tests compare its evaluation vectors with the oracle's).
+bool dst_internal_boundary_by_evaluation() { const char* e = getenv("DISTAFF_BOUNDARY"); return e && !strcmp(e, "eval"); }
+int dst_internal_boundary_polys(dst_ctx* c, const fe* draws344, fe* ip, fe* fp) {
+    const size_t n = c->n, D = 8 * n, W = c->W, p = 6 * n + 2;
+    const uint32_t ctx_depth = c->prm.ctx_depth, loop_depth = c->prm.loop_depth;
+    const size_t sd = c->stack_depth;
+    const size_t cl = ctx_depth > 1 ? ctx_depth : 1, ll = loop_depth > 1 ? loop_depth : 1;
+    // host: weights per trace register (plain, degree-adjusted) and the constant terms, for the first-step and last-step combinations
+    std::vector<u128> w(4 * W, 0);                       // [pass][adj][register]
+    u128 g[4] = {0, 0, 0, 0};                            // [pass][adj]
+    const u128 one = 1;
+    for (int pass = 0; pass < 2; pass++) {
+        const fe* cc = draws344 + pass * 94;
+        auto term = [&](int col, u128 constant, size_t idx) {       // value = T_col(x) - constant (col < 0: no register, value = -constant)
+            for (int adj = 0; adj < 2; adj++) {
+                const u128 k = fe_to_u128(cc[idx + adj]);
+                if (col >= 0) w[(pass * 2 + adj) * W + col] = hf_add(w[(pass * 2 + adj) * W + col], k);
+                if (constant != 0) g[pass * 2 + adj] = hf_add(g[pass * 2 + adj], hf_mul(k, constant));
+            }
+        };
+        term(0, pass ? (u128)c->op_count : 0, 0);
+        if (pass == 0) { for (int i = 0; i < 4; i++) term(1 + i, 0, 2 + 2 * i); }
+        else { for (int i = 0; i < 2; i++) term(1 + i, fe_to_u128(c->program_hash[i]), 2 + 2 * i); }
+        for (int i = 0; i < 3; i++) term(5 + i, pass ? one : 0, 10 + 2 * i);
+        for (int i = 0; i < 5; i++) term(8 + i, pass ? one : 0, 16 + 2 * i);
+        for (int i = 0; i < 2; i++) term(13 + i, pass ? one : 0, 26 + 2 * i);
+        for (size_t i = 0; i < cl; i++) if (i < ctx_depth) term(15 + (int)i, 0, 30 + 2 * i);
+        for (size_t i = 0; i < ll; i++) if (i < loop_depth) term(15 + (int)ctx_depth + (int)i, 0, 62 + 2 * i);
+        const uint32_t nio = pass ? c->pub.num_outputs : c->pub.num_inputs;
+        for (uint32_t i = 0; i < nio && i < 8; i++) {
+            u128 v; memcpy(&v, pass ? c->pub.outputs[i] : c->pub.inputs[i], 16);
+            term(i < sd ? 15 + (int)ctx_depth + (int)loop_depth + (int)i : -1, v, 78 + 2 * i);
+        }
+    }
+    std::vector<fe> up(4 * W + 4);
+    for (size_t i = 0; i < 4 * W; i++) up[i] = fe_from_u128(w[i]);
+    for (int i = 0; i < 4; i++) up[4 * W + i] = fe_from_u128(g[i]);
+    fe* d_w = (fe*)c->d_stage;                           // staging area is free until the openings
+    HIP_TRY(c, hipMemcpyAsync(d_w, up.data(), up.size() * sizeof(fe), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemsetAsync(ip, 0, D * sizeof(fe), c->stream));
+    HIP_TRY(c, hipMemsetAsync(fp, 0, D * sizeof(fe), c->stream));
+    fe* outs[2] = {ip, fp};
+    for (int pass = 0; pass < 2; pass++)
+        for (int adj = 0; adj < 2; adj++) {
+            fe* dst = outs[pass] + (adj ? p : 0);
+            k_lincomb(c, c->polys, W, n, d_w + (pass * 2 + adj) * W, dst);
+            k_sub_at0(c, dst, d_w + 4 * W + pass * 2 + adj);
+        }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));         // `up` leaves scope
+    return DST_OK;
+}
+
 int dst_eval_constraints(dst_ctx* c, const dst_public* pub, const uint8_t* coeffs, uint8_t constraint_root[32], int64_t* bad_step) {
     if (!c || !pub || !coeffs || !constraint_root) return DST_ERR_ARG;
     if (!c->committed) { c->err = "dst_eval_constraints: trace not committed"; return DST_ERR_STATE; }
@@ -319,9 +376,11 @@ int dst_eval_constraints(dst_ctx* c, const dst_public* pub, const uint8_t* coeff
     // combine_polys (constraint_table.rs:54-88)
     const size_t n = c->n, D = 8 * n;
     fe* ip = c->cwork; fe* fp = c->cwork + D; fe* tp = c->cwork + 2 * D; fe* work = c->cwork + 3 * D;
-    k_intt8_cosets(c, c->ceval, ip, work);
+    if (dst_internal_boundary_by_evaluation()) {
+        k_intt8_cosets(c, c->ceval, ip, work);
+        k_intt8_cosets(c, c->ceval + D, fp, work);
+    } else if ((r = dst_internal_boundary_polys(c, draws.data(), ip, fp))) return r;
     k_syn_div(c, ip, D, fe_one());
-    k_intt8_cosets(c, c->ceval + D, fp, work);
     k_syn_div(c, fp, D, c->x_last);
     k_intt8_cosets(c, c->ceval + 2 * D, tp, work);
     k_syn_div_expanded(c, tp, c->cpoly, D, n, c->x_last);

@@ -64,6 +64,7 @@ struct dst_ctx {
     size_t Bc = 0, j0 = 0;              // local cosets
     size_t stack_depth = 0;
     NttPlan plan;
+    std::vector<fe> shard_draws;       // shard.hip: the 344 constraint coefficients of the current proof
     std::shared_ptr<void> open_plan;   // shard.hip: plan of the last dst_shard_open, reused by dst_shard_assemble for the same positions
     std::vector<uint64_t> open_plan_positions;
     bool sharded_layout = false;        // FRI layers >= 1 coset-major with per-rank tree heaps (dst_shard_* phases) instead of natural order / full heaps
@@ -152,6 +153,8 @@ struct KScope {
 
 // ---- kernel launchers (kernels_*.hip) ------------------------------------------------------------------------------------
 // NTT / LDE
+extern "C" bool dst_internal_boundary_by_evaluation();                                  // api.hip: DISTAFF_BOUNDARY=eval
+extern "C" int dst_internal_boundary_polys(dst_ctx* c, const fe* draws344, fe* ip, fe* fp);   // api.hip: boundary combinations in coefficient form
 int k_build_twiddle_tables(dst_ctx* c);                                                 // fills tw4_lde / tw4_fwd / tw4_inv (context creation)
 void k_intt_columns(dst_ctx* c, const fe* src, fe* dst, size_t ncols);                  // size-n inverse NTT of ncols contiguous columns
 void k_lde_columns(dst_ctx* c, const fe* polys, fe* lde, size_t ncols);                 // n coefficients -> coset-major [Bc][n] per column

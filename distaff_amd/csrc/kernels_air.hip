@@ -6,7 +6,7 @@ void air_launch_generic(dst_ctx* c, const AirArgs& a, uint32_t Q) {
     // any shape the VM can produce (up to 16 context, 8 loop and 32 stack registers, known at run time), per-operation formulation,
     // cut into the same section launches as the specialised instances
     launch_air<16, 8, 0, 32, 2, true, false>(c, a, Q);     // op bits
-    launch_air<16, 8, 0, 32, 1, false, false>(c, a, Q);    // boundary
+    if (dst_internal_boundary_by_evaluation()) launch_air<16, 8, 0, 32, 1, false, false>(c, a, Q);    // boundary (normally in coefficient form, api.hip)
     launch_air<16, 8, 0, 32, 4, false, false>(c, a, Q);    // sponge, loop image, context / loop stacks
     launch_air<16, 8, 0, 32, 8, false, false>(c, a, Q);    // stack: low-degree ops that move items
     launch_air<16, 8, 0, 32, 32, false, false>(c, a, Q);   // stack: low-degree arithmetic / selection ops

@@ -77,6 +77,7 @@ int dst_shard_eval_constraints(dst_ctx* c, const dst_public* pub, const uint8_t*
     c->pub = *pub;
     std::vector<fe> draws(344), tc;
     memcpy(draws.data(), coeffs, 344 * 16);
+    c->shard_draws = draws;                                  // dst_shard_combine builds the boundary polynomials from them
     dst_internal_transition_coefficients(c, draws.data(), tc);
     fe* d_coef = c->scratch + c->scratch_elems - 1024;
     fe* d_tc = d_coef + 344;
@@ -94,9 +95,14 @@ int dst_shard_combine(dst_ctx* c) {
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t n = c->n, D = 8 * n;
     fe* ip = c->cwork; fe* fp = c->cwork + D; fe* tp = c->cwork + 2 * D; fe* work = c->cwork + 3 * D;
-    k_intt8_cosets(c, c->ceval, ip, work);
+    if (dst_internal_boundary_by_evaluation()) {
+        k_intt8_cosets(c, c->ceval, ip, work);
+        k_intt8_cosets(c, c->ceval + D, fp, work);
+    } else {
+        int rb = dst_internal_boundary_polys(c, c->shard_draws.data(), ip, fp);
+        if (rb) return rb;
+    }
     k_syn_div(c, ip, D, fe_one());
-    k_intt8_cosets(c, c->ceval + D, fp, work);
     k_syn_div(c, fp, D, c->x_last);
     k_intt8_cosets(c, c->ceval + 2 * D, tp, work);
     k_syn_div_expanded(c, tp, c->cpoly, D, n, c->x_last);
@@ -144,7 +150,7 @@ int dst_shard_export_size(dst_ctx* c, uint32_t what, uint32_t arg, size_t* bytes
     switch (what) {
         case SH_TRACE_TREE: case SH_CONSTRAINT_TREE: *bytes = c->n * 32; return DST_OK;
         case SH_FRI_TREE: if ((int)arg >= c->num_fri_layers) return DST_ERR_ARG; *bytes = fri_nd(c, arg) / 4 * 32; return DST_OK;
-        case SH_CEVAL: *bytes = 3 * (c->Bc / (c->B / 8)) * c->n * 16; return DST_OK;
+        case SH_CEVAL: *bytes = (dst_internal_boundary_by_evaluation() ? 3 : 1) * (c->Bc / (c->B / 8)) * c->n * 16; return DST_OK;   // [i, f,] t
         case SH_FRI_LAST: *bytes = c->Bc * fri_nd(c, c->num_fri_layers - 1) * 16; return DST_OK;
     }
     return DST_ERR_ARG;
@@ -159,7 +165,7 @@ int dst_shard_export(dst_ctx* c, uint32_t what, uint32_t arg, void* dst, int dst
         case SH_TRACE_TREE: src = c->trace_nodes + c->n; break;
         case SH_CONSTRAINT_TREE: src = c->cnodes + c->n; break;
         case SH_FRI_TREE: src = c->fri_nodes[arg] + fri_nd(c, arg) / 4; break;
-        case SH_CEVAL: src = c->ceval; break;
+        case SH_CEVAL: src = dst_internal_boundary_by_evaluation() ? c->ceval : c->ceval + 2 * (c->Bc / (c->B / 8)) * c->n; break;   // local layout [3][Q][n]
         case SH_FRI_LAST: src = c->fri_e[c->num_fri_layers - 1]; break;
     }
     return copy_out(c, dst, src, bytes, dst_is_device);
@@ -176,11 +182,12 @@ int dst_shard_import(dst_ctx* c, uint32_t what, uint32_t arg, const void* src, i
     if (total > c->gather_bytes) { c->err = "dst_shard_import: gather buffer too small"; return DST_ERR_ARG; }
     if ((r = copy_in(c, c->gather_buf, src, total, src_is_device))) return r;
     if (what == SH_CEVAL) {
-        const size_t Q = c->Bc / (c->B / 8), blk = Q * c->n;        // gathered [G][3][Q][n] -> ceval [3][8][n]
+        const size_t Q = c->Bc / (c->B / 8), blk = Q * c->n;        // gathered [G][V][Q][n] -> ceval [3][8][n], V = 3 (i, f, t) or 1 (t)
+        const size_t V = dst_internal_boundary_by_evaluation() ? 3 : 1;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         for (size_t g = 0; g < G; g++)
-            for (size_t v = 0; v < 3; v++)
-                HIP_TRY(c, hipMemcpyAsync(c->ceval + (v * 8 + g * Q) * c->n, (const fe*)c->gather_buf + (g * 3 + v) * blk, blk * 16, hipMemcpyDeviceToDevice, c->stream));
+            for (size_t v = 0; v < V; v++)
+                HIP_TRY(c, hipMemcpyAsync(c->ceval + ((V == 3 ? v : 2) * 8 + g * Q) * c->n, (const fe*)c->gather_buf + (g * V + v) * blk, blk * 16, hipMemcpyDeviceToDevice, c->stream));
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         return DST_OK;
     }

@@ -32,7 +32,10 @@ def _check_all_phases(O, D, trace, num_outputs=1, log_blowup=5, num_queries=50, 
 
     # steps 3-5 with the oracle's coefficient draws
     croot = ctx.eval_constraints(trace.public_inputs, op.outputs, op.get("constraint_draws"))
-    for name, oname in (("ceval_i", "i_evaluations"), ("ceval_f", "f_evaluations"), ("ceval_t", "t_evaluations")):
+    # the boundary combinations are written in coefficient form (no evaluation vectors) unless DISTAFF_BOUNDARY=eval
+    import os
+    vectors = (("ceval_i", "i_evaluations"), ("ceval_f", "f_evaluations"), ("ceval_t", "t_evaluations"))
+    for name, oname in (vectors if os.environ.get("DISTAFF_BOUNDARY") == "eval" else vectors[2:]):
         assert (ctx.read_elements(name) == op.get(oname)).all(), name
     assert (ctx.read_elements("cpoly") == op.get("constraint_poly")).all(), "constraint poly"
     assert (ctx.read_elements("cevals") == op.get("constraint_evaluations")).all(), "constraint evaluations"
@@ -83,6 +86,19 @@ def _check_all_phases(O, D, trace, num_outputs=1, log_blowup=5, num_queries=50, 
 def test_fibonacci_all_phases(oracle, log_n):
     import distaff_amd as D
     _check_all_phases(oracle, D, oracle.fibonacci_trace(1 << log_n))
+
+
+@pytest.mark.parametrize("instance", ["", "small", "generic"])
+def test_boundary_constraints_by_evaluation(oracle, monkeypatch, instance):
+    """The evaluate-and-interpolate route of the two boundary combinations (the reference's own, constraint_table.rs:54-62): its
+    evaluation vectors equal the oracle's; the default route writes the same polynomials in coefficient form, and every other test
+    compares the constraint polynomial and everything downstream."""
+    import distaff_amd as D
+    monkeypatch.setenv("DISTAFF_BOUNDARY", "eval")
+    if instance:
+        monkeypatch.setenv("DISTAFF_AIR", instance)
+    _check_all_phases(oracle, D, oracle.fibonacci_trace(1 << 8))
+    _check_all_phases(oracle, D, oracle.Trace("begin dup.4 add mul swap.2 add drop drop block push.9 mul end end", [1, 2, 3, 4]), num_outputs=2)
 
 
 def test_other_program_shapes(oracle):
