@@ -344,13 +344,9 @@ int dst_internal_boundary_polys(dst_ctx* c, const fe* draws344, fe* ip, fe* fp) 
     HIP_TRY(c, hipMemcpyAsync(d_w, up.data(), up.size() * sizeof(fe), hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemsetAsync(ip, 0, D * sizeof(fe), c->stream));
     HIP_TRY(c, hipMemsetAsync(fp, 0, D * sizeof(fe), c->stream));
-    fe* outs[2] = {ip, fp};
-    for (int pass = 0; pass < 2; pass++)
-        for (int adj = 0; adj < 2; adj++) {
-            fe* dst = outs[pass] + (adj ? p : 0);
-            k_lincomb(c, c->polys, W, n, d_w + (pass * 2 + adj) * W, dst);
-            k_sub_at0(c, dst, d_w + 4 * W + pass * 2 + adj);
-        }
+    fe* outs[4] = {ip, ip + p, fp, fp + p};               // [pass][adj]
+    k_lincomb4(c, c->polys, W, n, d_w, outs[0], outs[1], outs[2], outs[3]);
+    for (int q = 0; q < 4; q++) k_sub_at0(c, outs[q], d_w + 4 * W + q);
     HIP_TRY(c, hipStreamSynchronize(c->stream));         // `up` leaves scope
     return DST_OK;
 }

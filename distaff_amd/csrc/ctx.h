@@ -174,6 +174,7 @@ void k_syn_div(dst_ctx* c, fe* a, size_t len, fe b);                            
 void k_syn_div_expanded(dst_ctx* c, const fe* a, fe* out, size_t len, size_t degree, fe exception);
 void k_horner(dst_ctx* c, const fe* polys, size_t ncols, size_t len, fe x, fe* out_dev);
 void k_lincomb(dst_ctx* c, const fe* cols, size_t ncols, size_t len, const fe* coeffs_dev, fe* out);
+void k_lincomb4(dst_ctx* c, const fe* cols, size_t ncols, size_t len, const fe* coeffs_dev, fe* out0, fe* out1, fe* out2, fe* out3);   // four combinations, one pass over the columns
 void k_axpy(dst_ctx* c, fe* y, const fe* x, fe a, size_t len);                           // y += a * x
 void k_add(dst_ctx* c, fe* y, const fe* x, size_t len);                                  // y += x
 void k_sub_dot_at0(dst_ctx* c, fe* y, const fe* values_dev, const fe* coeffs_dev, size_t count);   // y[0] -= sum values[k]*coeffs[k]
