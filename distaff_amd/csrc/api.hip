@@ -414,9 +414,8 @@ int dst_compose(dst_ctx* c, const uint8_t* draws_bytes, uint8_t* trace_at_z1, ui
     k_horner(c, c->polys, W, n, z, d_tz1);
     k_horner(c, c->polys, W, n, next_z, d_tz2);
     fe* t1 = c->cwork; fe* t2 = c->cwork + n; fe* cp = c->cwork + D;
-    k_lincomb(c, c->polys, W, n, d_draws + 1, t1);
+    k_lincomb2(c, c->polys, W, n, d_draws + 1, 256, t1, t2);          // both combinations in one pass over the trace polynomials
     k_sub_dot_at0(c, t1, d_tz1, d_draws + 1, W);
-    k_lincomb(c, c->polys, W, n, d_draws + 257, t2);
     k_sub_dot_at0(c, t2, d_tz2, d_draws + 257, W);
     k_syn_div(c, t1, n, z);
     k_syn_div(c, t2, n, next_z);

@@ -174,6 +174,7 @@ void k_syn_div(dst_ctx* c, fe* a, size_t len, fe b);                            
 void k_syn_div_expanded(dst_ctx* c, const fe* a, fe* out, size_t len, size_t degree, fe exception);
 void k_horner(dst_ctx* c, const fe* polys, size_t ncols, size_t len, fe x, fe* out_dev);
 void k_lincomb(dst_ctx* c, const fe* cols, size_t ncols, size_t len, const fe* coeffs_dev, fe* out);
+void k_lincomb2(dst_ctx* c, const fe* cols, size_t ncols, size_t len, const fe* coeffs_dev, size_t coef_stride, fe* out0, fe* out1);
 void k_lincomb4(dst_ctx* c, const fe* cols, size_t ncols, size_t len, const fe* coeffs_dev, fe* out0, fe* out1, fe* out2, fe* out3);   // four combinations, one pass over the columns
 void k_axpy(dst_ctx* c, fe* y, const fe* x, fe a, size_t len);                           // y += a * x
 void k_add(dst_ctx* c, fe* y, const fe* x, size_t len);                                  // y += x

@@ -182,7 +182,7 @@ void k_horner(dst_ctx* c, const fe* polys, size_t ncols, size_t len, fe x, fe* o
 // products with one reduction (fe_acc); coeffs is [NOUT][ncols], outputs are given as pointers (they may be unrelated arrays)
 struct LincombOut { fe* p[4]; };
 template <int NOUT>
-__global__ void lincomb_kernel(const fe* __restrict__ cols, size_t ncols, size_t len, const fe* __restrict__ coeffs, LincombOut out) {
+__global__ void lincomb_kernel(const fe* __restrict__ cols, size_t ncols, size_t len, const fe* __restrict__ coeffs, size_t coef_stride, LincombOut out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= len) return;
     fe_acc acc[NOUT];
@@ -191,18 +191,23 @@ __global__ void lincomb_kernel(const fe* __restrict__ cols, size_t ncols, size_t
     for (size_t k = 0; k < ncols; k++) {
         const fe v = cols[k * len + i];
 #pragma unroll
-        for (int q = 0; q < NOUT; q++) fe_acc_mac(acc[q], v, coeffs[q * ncols + k]);
+        for (int q = 0; q < NOUT; q++) fe_acc_mac(acc[q], v, coeffs[q * coef_stride + k]);
     }
 #pragma unroll
     for (int q = 0; q < NOUT; q++) out.p[q][i] = fe_acc_reduce(acc[q]);
 }
 void k_lincomb(dst_ctx* c, const fe* cols, size_t ncols, size_t len, const fe* coeffs_dev, fe* out) {
     LincombOut o{{out, nullptr, nullptr, nullptr}};
-    { KScope ks_(c, "lincomb_kernel", 16.0 * len * (ncols + 1)); hipLaunchKernelGGL(lincomb_kernel<1>, dim3((unsigned)((len + PT - 1) / PT)), dim3(PT), 0, c->stream, cols, ncols, len, coeffs_dev, o); }
+    { KScope ks_(c, "lincomb_kernel", 16.0 * len * (ncols + 1)); hipLaunchKernelGGL(lincomb_kernel<1>, dim3((unsigned)((len + PT - 1) / PT)), dim3(PT), 0, c->stream, cols, ncols, len, coeffs_dev, ncols, o); }
 }
 void k_lincomb4(dst_ctx* c, const fe* cols, size_t ncols, size_t len, const fe* coeffs_dev, fe* out0, fe* out1, fe* out2, fe* out3) {
     LincombOut o{{out0, out1, out2, out3}};
-    { KScope ks_(c, "lincomb_kernel", 16.0 * len * (ncols + 4)); hipLaunchKernelGGL(lincomb_kernel<4>, dim3((unsigned)((len + PT - 1) / PT)), dim3(PT), 0, c->stream, cols, ncols, len, coeffs_dev, o); }
+    { KScope ks_(c, "lincomb_kernel", 16.0 * len * (ncols + 4)); hipLaunchKernelGGL(lincomb_kernel<4>, dim3((unsigned)((len + PT - 1) / PT)), dim3(PT), 0, c->stream, cols, ncols, len, coeffs_dev, ncols, o); }
+}
+// two combinations whose coefficient vectors are coef_stride elements apart
+void k_lincomb2(dst_ctx* c, const fe* cols, size_t ncols, size_t len, const fe* coeffs_dev, size_t coef_stride, fe* out0, fe* out1) {
+    LincombOut o{{out0, out1, nullptr, nullptr}};
+    { KScope ks_(c, "lincomb_kernel", 16.0 * len * (ncols + 2)); hipLaunchKernelGGL(lincomb_kernel<2>, dim3((unsigned)((len + PT - 1) / PT)), dim3(PT), 0, c->stream, cols, ncols, len, coeffs_dev, coef_stride, o); }
 }
 __global__ void axpy_kernel(fe* y, const fe* x, fe a, size_t len) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
