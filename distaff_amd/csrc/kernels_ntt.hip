@@ -35,6 +35,7 @@ struct NttArgs {
     // middle frequency k2 (batch index = low bits of blockIdx.x): source rows (k1, k2, .) and destination k1 + n1 * (k2 + n2' * k3)
     size_t src_row_stride, dst_k_stride, src_batch_stride, dst_batch_stride;
     uint32_t batch_log;
+    uint32_t dit;              // pass A of an extension: coset DIT (pre-scale folded into the stage twiddles, taken from `prescale`)
     fe scale;
 };
 
@@ -94,6 +95,41 @@ __device__ __forceinline__ void lds_ntt_dif(fe* L, const fe* W, uint32_t log_len
     }
 }
 
+// in-LDS DIT over the first index of L[len][T] for a COSET transform: X[k] = sum_m x[m] * g^m * w_len^(m*k).  The input sits in
+// bit-reversed order (position brev(m) holds x[m]), the output is in natural order.  The sub-transforms over the even and
+// odd indices are coset transforms with g^2, so the stage that merges blocks of size B multiplies by g^(len/B) * w_B^k: the
+// pre-scale by g^m costs nothing -- it is part of twiddles that had to be applied anyway.  W holds them per stage at offset
+// B/2 - 1 (len - 1 entries for the workgroup's coset).  Two stages per LDS round trip, as in lds_ntt_dif.
+__device__ __forceinline__ void lds_ntt_dit(fe* L, const fe* W, uint32_t log_len, uint32_t log_t) {
+    const uint32_t T = 1u << log_t;
+    uint32_t s = 1;
+    for (; s + 1 <= log_len; s += 2) {
+        const uint32_t B = 1u << s, half = B >> 1;                     // first stage merges blocks of size B / 2 into B, second B into 2B
+        for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 2) * T; w += NTT_THREADS) {
+            const uint32_t t = w & (T - 1), q = w >> log_t;
+            const uint32_t k = q & (half - 1), base = (q >> (s - 1)) << (s + 1);
+            fe* p0 = L + (((base + k) << log_t) + t); fe* p1 = p0 + (half << log_t); fe* p2 = p0 + (B << log_t); fe* p3 = p2 + (half << log_t);
+            const fe tb = W[half - 1 + k];
+            const fe x0 = *p0, x1 = fe_mul(*p1, tb), x2 = *p2, x3 = fe_mul(*p3, tb);
+            const fe a0 = fe_add(x0, x1), a1 = fe_sub(x0, x1);
+            const fe a2 = fe_mul(fe_add(x2, x3), W[B - 1 + k]), a3 = fe_mul(fe_sub(x2, x3), W[B - 1 + k + half]);
+            *p0 = fe_add(a0, a2); *p2 = fe_sub(a0, a2);
+            *p1 = fe_add(a1, a3); *p3 = fe_sub(a1, a3);
+        }
+        __syncthreads();
+    }
+    if (s == log_len) {                              // last single stage: blocks of len / 2 into len
+        const uint32_t half = 1u << (log_len - 1);
+        for (uint32_t w = threadIdx.x; w < half * T; w += NTT_THREADS) {
+            const uint32_t t = w & (T - 1), k = w >> log_t;
+            fe* p0 = L + ((k << log_t) + t); fe* p1 = p0 + (half << log_t);
+            const fe u = *p0, v = fe_mul(*p1, W[half - 1 + k]);
+            *p0 = fe_add(u, v); *p1 = fe_sub(u, v);
+        }
+        __syncthreads();
+    }
+}
+
 extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
 
 // Both passes are persistent over `tiles_per_block` adjacent tiles: the tile's elements for the NEXT iteration are fetched from HBM
@@ -112,8 +148,15 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_a(NttArgs a, const fe
     fe* __restrict__ dst = dst_base + (size_t)blockIdx.z * a.dst_col_stride + (size_t)jl * a.dst_coset_stride;
     const uint32_t pmask = (1u << (a.log_b + a.log_n1)) - 1u;
     const uint64_t nmask = (1ull << a.log_N) - 1ull;
+    if (a.dit) {
+        // stage twiddles of this coset: g^(n1/B) * w_B^k = w_{B_lde*n1}^((j + B_lde*k) * n1/B) straight from the pre-scale table
+        for (uint32_t i = threadIdx.x; i + 1 < n1; i += NTT_THREADS) {
+            const uint32_t lb = 31u - (uint32_t)__clz(i + 1), k = i + 1 - (1u << lb);         // entry i: block size B = 2^(lb+1), index k
+            TW[i] = a.prescale[((jg + (k << a.log_b)) << (a.log_n1 - lb - 1)) & pmask];
+        }
+    } else
     for (uint32_t i = threadIdx.x; i < n1 / 2; i += NTT_THREADS) TW[i] = a.stage_tw[i];
-    const bool scaled = a.prescale != nullptr && jg != 0 && !(a.debug & 1u);
+    const bool scaled = !a.dit && a.prescale != nullptr && jg != 0 && !(a.debug & 1u);
     fe pre0 = fe_zero(), pre1 = fe_zero(), pre2 = fe_zero(), pre3 = fe_zero(), pre4 = fe_zero(), pre5 = fe_zero(), pre6 = fe_zero(), pre7 = fe_zero();
     const uint32_t count = n1 * T;
 #define NTT_FETCH_A1(e, var, m2_0) { uint32_t idx = threadIdx.x + (e) * NTT_THREADS; idx = idx < count ? idx : 0u; /* branch-free: a lane past the tile re-reads element 0 */ var = src[((size_t)(idx >> log_t) << a.log_n2) + (m2_0) + (idx & (T - 1))]; }
@@ -127,12 +170,12 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_a(NttArgs a, const fe
         const uint32_t m2_0 = (tile0 + it) * T;
         __syncthreads();                                   // the previous tile has left LDS (and TW is complete)
         // the coset pre-scale depends on the row m1 of an element only; the table is small and stays in L2
-#define NTT_PUT_A(e, var) { const uint32_t idx = threadIdx.x + (e) * NTT_THREADS; if (idx < count) L[idx] = scaled ? fe_mul(var, a.prescale[(jg * (idx >> log_t)) & pmask]) : var; }
+#define NTT_PUT_A(e, var) { const uint32_t idx = threadIdx.x + (e) * NTT_THREADS; if (idx < count) { if (a.dit) L[((__brev(idx >> log_t) >> (32 - a.log_n1)) << log_t) + (idx & (T - 1))] = var; else L[idx] = scaled ? fe_mul(var, a.prescale[(jg * (idx >> log_t)) & pmask]) : var; } }
         NTT_PUT_A(0, pre0) NTT_PUT_A(1, pre1) NTT_PUT_A(2, pre2) NTT_PUT_A(3, pre3) NTT_PUT_A(4, pre4) NTT_PUT_A(5, pre5) NTT_PUT_A(6, pre6) NTT_PUT_A(7, pre7)
 #undef NTT_PUT_A
         __syncthreads();
         if (it + 1 < a.tiles_per_block) NTT_FETCH_A(tile0 + it + 1)
-        lds_ntt_dif(L, TW, a.log_n1, log_t);
+        if (a.dit) lds_ntt_dit(L, TW, a.log_n1, log_t); else lds_ntt_dif(L, TW, a.log_n1, log_t);
         // read-out in batches of four elements per lane: the four twiddle loads are in flight together
         for (uint32_t base = 0; base < count; base += 4 * NTT_THREADS) {
             fe v[4], w[4]; uint32_t k1s[4], m2s[4]; bool ok[4], scale[4];
@@ -142,7 +185,7 @@ __global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_a(NttArgs a, const fe
                 ok[q] = idx < count;
                 idx = ok[q] ? idx : 0u;
                 const uint32_t t = idx & (T - 1), r = idx >> log_t;
-                k1s[q] = __brev(r) >> (32 - a.log_n1);
+                k1s[q] = a.dit ? r : __brev(r) >> (32 - a.log_n1);        // DIT leaves the tile in natural order
                 m2s[q] = m2_0 + t;
                 v[q] = L[idx];
                 if (a.debug & 2u) { scale[q] = false; w[q] = fe_one(); }
@@ -434,7 +477,8 @@ static void launch_pass_lds(dst_ctx* c, bool pass_b, const fe* src, size_t src_c
     if (!pass_b) {
         a.tw4 = lde ? c->tw4_lde + (size_t)skip * c->n : (inverse ? c->tw4_inv : c->tw4_fwd); a.tw4_coset_stride = lde ? c->n : 0;
         a.stage_tw = inverse ? c->w1i : c->w1f; a.tile = (uint32_t)__builtin_ctz(p.tile_a);
-        size_t lds_a = (((size_t)1 << p.log_n1) * p.tile_a + ((size_t)1 << p.log_n1) / 2) * sizeof(fe);
+        a.dit = (lde && getenv("DISTAFF_NTT_DIF") == nullptr) ? 1u : 0u;
+        size_t lds_a = (((size_t)1 << p.log_n1) * p.tile_a + (a.dit ? ((size_t)1 << p.log_n1) : ((size_t)1 << p.log_n1) / 2)) * sizeof(fe);
         const uint32_t tiles = (1u << p.log_n2) / p.tile_a;
         a.tiles_per_block = ntt_tiles_per_block(tiles, cosets * cols);
         dim3 ga((unsigned)(tiles / a.tiles_per_block), (unsigned)cosets, (unsigned)cols);
@@ -479,19 +523,20 @@ static void launch_three_pass(dst_ctx* c, const fe* src, size_t src_col_stride, 
     a.prescale = lde ? c->prescale : nullptr; a.has_scale = 0;
     a.tw4 = lde ? c->tw4_lde + (size_t)skip * n : (inverse ? c->tw4_inv : c->tw4_fwd); a.tw4_coset_stride = lde ? n : 0;
     a.stage_tw = inverse ? c->w1i : c->w1f;
+    a.dit = (lde && getenv("DISTAFF_NTT_DIF") == nullptr) ? 1u : 0u;
     a.src = src; a.src_col_stride = src_col_stride; a.src_coset_stride = src_coset_stride;
     a.dst = c->tmp; a.dst_col_stride = n * cosets; a.dst_coset_stride = n;
     {
         const uint32_t tiles = (uint32_t)(nrow / p.tile_a);
         a.tiles_per_block = ntt_tiles_per_block(tiles, cosets * cols);
-        const size_t lds = (n1 * p.tile_a + n1 / 2) * sizeof(fe);
+        const size_t lds = (n1 * p.tile_a + (a.dit ? n1 : n1 / 2)) * sizeof(fe);
         dim3 g((unsigned)(tiles / a.tiles_per_block), (unsigned)cosets, (unsigned)cols);
         KScope ks_(c, "ntt_pass_a", 16.0 * n * cols * (lde ? (1 + cosets) : 2 * cosets));
         hipLaunchKernelGGL(ntt_pass_a, g, dim3(NTT_THREADS), lds, c->stream, a, a.src, a.dst);
     }
     // pass 2: tmp -> tmp2, every (coset, k1) row of nrow points is an array of shape 2^log_mid x n3
     a.log_n1 = log_mid; a.log_n2 = p.log_n3; a.tile = (uint32_t)__builtin_ctz(p.tile_m);
-    a.j0 = 0; a.coset_twiddle = 0; a.prescale = nullptr;
+    a.j0 = 0; a.coset_twiddle = 0; a.prescale = nullptr; a.dit = 0;
     a.tw4 = inverse ? c->tw4_row_inv : c->tw4_row_fwd; a.tw4_coset_stride = 0;
     a.stage_tw = inverse ? c->w2i : c->w2f;
     a.src = c->tmp; a.src_col_stride = n * cosets; a.src_coset_stride = nrow;
