@@ -675,7 +675,7 @@ static void launch_air(dst_ctx* c, const AirArgs& a, uint32_t Q) {
     dim3 g((unsigned)((c->n + AIR_THREADS - 1) / AIR_THREADS), Q);
     static char name[48];          // one name per instantiation, matching the template arguments rocprofv3 prints
     if (!name[0]) snprintf(name, sizeof(name), "air_kernel<%d,%d,%d,%d,%d,%d,%d>", CL, LL, SD, SLCAP, SECT, (int)FIRST, (int)LAST);
-    { KScope ks_(c, name, 16.0 * c->n * Q * (c->W + (FIRST ? 0 : 7) + (LAST ? 1 : 7) + ((SECT & 1) ? 2 : 0))); hipLaunchKernelGGL((air_kernel<CL, LL, SD, SLCAP, SECT, FIRST, LAST>), g, dim3(AIR_THREADS), 0, c->stream, a); }
+    { KScope ks_(c, name, 16.0 * c->n * Q * (c->W + (FIRST ? 0 : 7) + (LAST ? 1 : 7) + ((SECT & 1) ? 2 : 0)), true); hipLaunchKernelGGL((air_kernel<CL, LL, SD, SLCAP, SECT, FIRST, LAST>), g, dim3(AIR_THREADS), 0, c->stream, a); }
 }
 // instances live in their own translation units (compile time): Fibonacci shape, small stacks, fully generic
 void air_launch_sd4(dst_ctx* c, const AirArgs& a, uint32_t Q);      // cl <= 2, ll <= 1, stack_depth == 4

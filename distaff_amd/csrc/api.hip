@@ -72,6 +72,8 @@ static void free_all(dst_ctx* c) {
     void* ptrs[] = {c->tw_lo, c->tw_hi, c->itw_lo, c->itw_hi, c->w1f, c->w2f, c->w1i, c->w2i, c->prescale, c->tw4_lde, c->tw4_fwd, c->tw4_inv, c->tw4_row_fwd, c->tw4_row_inv, c->w3f, c->w3i, c->tmp2, c->periodic, c->trace, c->polys, c->lde, c->tmp,
                     c->trace_leaves, c->trace_nodes, c->air_consts, c->ceval, c->cwork, c->cpoly, c->cevals, c->cnodes, c->comp_poly, c->comp, c->scratch, c->d_u64, c->d_stage};
     for (void* p : ptrs) if (p) hipFree(p);
+    for (auto& e : c->kpending) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
+    for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
     if (c->gather_buf) hipFree(c->gather_buf);
     if (c->trace_upper) hipFree(c->trace_upper);
     if (c->c_upper) hipFree(c->c_upper);
@@ -622,7 +624,7 @@ int dst_field_op(dst_ctx* c, int op, const uint8_t* a, const uint8_t* b, uint8_t
     HIP_TRY(c, hipSetDevice(c->device));
     return k_field_op(c, op, a, b, out, count);
 }
-int dst_set_profiling(dst_ctx* c, int enabled) { if (!c) return DST_ERR_ARG; c->profile = enabled != 0; return DST_OK; }
+int dst_set_profiling(dst_ctx* c, int level) { if (!c || level < 0 || level > 2) return DST_ERR_ARG; c->profile = level; return DST_OK; }
 int dst_kernel_stats(dst_ctx* c, char* json_out, size_t cap, int reset) {
     if (!c || !json_out) return DST_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -630,7 +632,7 @@ int dst_kernel_stats(dst_ctx* c, char* json_out, size_t cap, int reset) {
     for (auto& e : c->kpending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, e.e0, e.e1) == hipSuccess) { auto& st = c->kstats[e.name]; st.launches++; st.ms += ms; st.bytes += e.bytes; }
-        hipEventDestroy(e.e0); hipEventDestroy(e.e1);
+        c->event_pool.push_back(e.e0); c->event_pool.push_back(e.e1);
     }
     c->kpending.clear();
     std::string js = "{";

@@ -122,9 +122,10 @@ struct dst_ctx {
     double phase_ms[9] = {0};
 
     // optional per-kernel timing with HIP events recorded on `stream` (dst_set_profiling / dst_kernel_stats)
-    bool profile = false;
+    int profile = 0;                       // dst_set_profiling: 0 off, 1 every kernel launch, 2 only the heavy kernels (NTT passes, constraint kernel, leaf hashing)
     struct KEvent { hipEvent_t e0, e1; std::string name; double bytes; };
     std::vector<KEvent> kpending;
+    std::vector<hipEvent_t> event_pool;    // recycled profiling events
     struct KStat { uint64_t launches = 0; double ms = 0, bytes = 0; };
     std::map<std::string, KStat> kstats;
 };
@@ -133,10 +134,12 @@ struct dst_ctx {
 struct KScope {
     dst_ctx* c; bool on;
     dst_ctx::KEvent ev;
-    KScope(dst_ctx* ctx, const char* name, double bytes) : c(ctx), on(ctx->profile) {
+    KScope(dst_ctx* ctx, const char* name, double bytes, bool heavy = false) : c(ctx), on(ctx->profile == 1 || (ctx->profile == 2 && heavy)) {
         if (!on) return;
         ev.name = name; ev.bytes = bytes;
-        if (hipEventCreate(&ev.e0) != hipSuccess || hipEventCreate(&ev.e1) != hipSuccess) { on = false; return; }
+        // events come from a pool that dst_kernel_stats refills: creating two per launch would be host time inside the timed region
+        if (c->event_pool.size() >= 2) { ev.e0 = c->event_pool.back(); c->event_pool.pop_back(); ev.e1 = c->event_pool.back(); c->event_pool.pop_back(); }
+        else if (hipEventCreate(&ev.e0) != hipSuccess || hipEventCreate(&ev.e1) != hipSuccess) { on = false; return; }
         (void)hipEventRecord(ev.e0, c->stream);
     }
     ~KScope() { if (on) { (void)hipEventRecord(ev.e1, c->stream); c->kpending.push_back(ev); } }

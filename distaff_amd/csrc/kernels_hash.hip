@@ -79,7 +79,7 @@ void k_trace_leaves(dst_ctx* c) {
     while ((1u << log_jt) < jt) log_jt++;
     uint32_t KT = HASH_THREADS >> log_jt;
     dim3 g((unsigned)(c->n / KT), (unsigned)(c->Bc >> log_jt));
-    { KScope ks_(c, "trace_leaves_kernel", (16.0 * c->W + 32.0) * c->Bc * c->n); hipLaunchKernelGGL(trace_leaves_kernel, g, dim3(HASH_THREADS), 0, c->stream, (const fe*)c->lde, c->trace_leaves, (uint32_t)c->W, c->n, (uint32_t)c->Bc, log_jt); }
+    { KScope ks_(c, "trace_leaves_kernel", (16.0 * c->W + 32.0) * c->Bc * c->n, true); hipLaunchKernelGGL(trace_leaves_kernel, g, dim3(HASH_THREADS), 0, c->stream, (const fe*)c->lde, c->trace_leaves, (uint32_t)c->W, c->n, (uint32_t)c->Bc, log_jt); }
 }
 
 // ---- generic Merkle levels: out[i] = H(children[2i] || children[2i+1]) -------------------------------------------------------

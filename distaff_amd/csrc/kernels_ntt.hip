@@ -407,7 +407,7 @@ template <int LOGL>
 static void launch_ntt_reg(dst_ctx* c, const NttRegArgs& a, size_t tiles, size_t cosets, size_t cols, const char* name, double bytes) {
     constexpr int NT = (1 << (LOGL + NttDigits<LOGL>::log_t)) / 16;
     dim3 g((unsigned)(tiles >> NttDigits<LOGL>::log_t), (unsigned)cosets, (unsigned)cols);
-    KScope ks_(c, name, bytes);
+    KScope ks_(c, name, bytes, true);
     hipLaunchKernelGGL(ntt_reg_kernel<LOGL>, g, dim3(NT), 0, c->stream, a);
 }
 static void dispatch_ntt_reg(dst_ctx* c, uint32_t log_len, const NttRegArgs& a, size_t tiles, size_t cosets, size_t cols, const char* name, double bytes) {
@@ -482,7 +482,7 @@ static void launch_pass_lds(dst_ctx* c, bool pass_b, const fe* src, size_t src_c
         const uint32_t tiles = (1u << p.log_n2) / p.tile_a;
         a.tiles_per_block = ntt_tiles_per_block(tiles, cosets * cols);
         dim3 ga((unsigned)(tiles / a.tiles_per_block), (unsigned)cosets, (unsigned)cols);
-        KScope ks_(c, "ntt_pass_a", 16.0 * c->n * cols * (lde ? (1 + cosets) : 2 * cosets));
+        KScope ks_(c, "ntt_pass_a", 16.0 * c->n * cols * (lde ? (1 + cosets) : 2 * cosets), true);
         hipLaunchKernelGGL(ntt_pass_a, ga, dim3(NTT_THREADS), lds_a, c->stream, a, a.src, a.dst);
     } else {
         a.stage_tw = inverse ? c->w2i : c->w2f; a.tile = (uint32_t)__builtin_ctz(p.tile_b);
@@ -491,7 +491,7 @@ static void launch_pass_lds(dst_ctx* c, bool pass_b, const fe* src, size_t src_c
         const uint32_t tiles = (1u << p.log_n1) / p.tile_b;
         a.tiles_per_block = ntt_tiles_per_block(tiles, cosets * cols);
         dim3 gb((unsigned)(tiles / a.tiles_per_block), (unsigned)cosets, (unsigned)cols);
-        KScope ks_(c, "ntt_pass_b", 32.0 * c->n * cols * cosets);
+        KScope ks_(c, "ntt_pass_b", 32.0 * c->n * cols * cosets, true);
         hipLaunchKernelGGL(ntt_pass_b, gb, dim3(NTT_THREADS), lds_b, c->stream, a, a.src, a.dst);
     }
 }
@@ -531,7 +531,7 @@ static void launch_three_pass(dst_ctx* c, const fe* src, size_t src_col_stride, 
         a.tiles_per_block = ntt_tiles_per_block(tiles, cosets * cols);
         const size_t lds = (n1 * p.tile_a + (a.dit ? n1 : n1 / 2)) * sizeof(fe);
         dim3 g((unsigned)(tiles / a.tiles_per_block), (unsigned)cosets, (unsigned)cols);
-        KScope ks_(c, "ntt_pass_a", 16.0 * n * cols * (lde ? (1 + cosets) : 2 * cosets));
+        KScope ks_(c, "ntt_pass_a", 16.0 * n * cols * (lde ? (1 + cosets) : 2 * cosets), true);
         hipLaunchKernelGGL(ntt_pass_a, g, dim3(NTT_THREADS), lds, c->stream, a, a.src, a.dst);
     }
     // pass 2: tmp -> tmp2, every (coset, k1) row of nrow points is an array of shape 2^log_mid x n3
@@ -547,7 +547,7 @@ static void launch_three_pass(dst_ctx* c, const fe* src, size_t src_col_stride, 
         a.tiles_per_block = ntt_tiles_per_block(tiles, rows * cols);
         const size_t lds = (((size_t)1 << log_mid) * p.tile_m + ((size_t)1 << log_mid) / 2) * sizeof(fe);
         dim3 g((unsigned)(tiles / a.tiles_per_block), (unsigned)rows, (unsigned)cols);
-        KScope ks_(c, "ntt_pass_mid", 32.0 * n * cols * cosets);
+        KScope ks_(c, "ntt_pass_mid", 32.0 * n * cols * cosets, true);
         hipLaunchKernelGGL(ntt_pass_a, g, dim3(NTT_THREADS), lds, c->stream, a, a.src, a.dst);
     }
     // pass 3: tmp2 -> dst
@@ -563,7 +563,7 @@ static void launch_three_pass(dst_ctx* c, const fe* src, size_t src_col_stride, 
         a.tiles_per_block = ntt_tiles_per_block(tiles, ((size_t)cosets << log_mid) * cols);
         const size_t lds = (n3 * p.tile_b + n3 / 2) * sizeof(fe);
         dim3 g((unsigned)((tiles / a.tiles_per_block) << log_mid), (unsigned)cosets, (unsigned)cols);
-        KScope ks_(c, "ntt_pass_b", 32.0 * n * cols * cosets);
+        KScope ks_(c, "ntt_pass_b", 32.0 * n * cols * cosets, true);
         hipLaunchKernelGGL(ntt_pass_b, g, dim3(NTT_THREADS), lds, c->stream, a, a.src, a.dst);
     }
 }

@@ -329,8 +329,9 @@ class Context:
         self._check(self.lib.dst_shard_info(self._h, ctypes.byref(op), ctypes.byref(layers), ctypes.byref(sd)))
         return op.value, layers.value, sd.value
 
-    def set_profiling(self, enabled=True):
-        self._check(self.lib.dst_set_profiling(self._h, int(enabled)))
+    def set_profiling(self, level=1):
+        """0 / False: off, 1 / True: every kernel launch, 2: heavy kernels only (see include/distaff_hip.h)"""
+        self._check(self.lib.dst_set_profiling(self._h, int(level)))
 
     def kernel_stats(self, reset=True):
         import json

@@ -150,9 +150,11 @@ int dst_read_buffer(dst_ctx* ctx, uint32_t what, uint32_t arg, uint8_t* out, siz
 int dst_bench_mulmod(dst_ctx* ctx, uint64_t lanes, uint32_t iters, double* ms);
 /* element-wise device field arithmetic on caller data (tests): op 0 add, 1 sub, 2 mul, 3 mul (portable formulation), 4 inv(a), 5 a^b */
 int dst_field_op(dst_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t count);
-/* per-kernel timing: when enabled every kernel launch is bracketed by HIP events on the context's stream;
- * dst_kernel_stats drains them and writes a JSON object {"kernel": {"launches": k, "ms": total, "bytes": algorithmic}, ...}. */
-int dst_set_profiling(dst_ctx* ctx, int enabled);
+/* per-kernel timing with HIP events on the context's stream.  level 0: off; 1: every kernel launch is bracketed (costs ~5 % of a
+ * proof: ~300 launches lose their back-to-back issue); 2: only the heavy kernels (NTT passes, constraint kernel, leaf hashing:
+ * ~35 launches, ~90 % of the device time, no measurable cost).  dst_kernel_stats drains the events and writes a JSON object
+ * {"kernel": {"launches": k, "ms": total, "bytes": algorithmic}, ...}. */
+int dst_set_profiling(dst_ctx* ctx, int level);
 int dst_kernel_stats(dst_ctx* ctx, char* json_out, size_t cap, int reset);
 
 #ifdef __cplusplus
