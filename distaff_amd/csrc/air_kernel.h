@@ -183,8 +183,38 @@ __device__ __forceinline__ fe st_term(const StackRows& s) {
 }
 
 // slot I of the low-degree part: the three nested sums
+// The operations selected by the high-degree bits and the flow flags join the outermost sum of a slot (one more product each,
+// no separate multiplication and modular addition): PUSH (input.rs:6), CMP (comparison.rs:64-105), RESCR (hash.rs:9-35; its six
+// differences are computed once by the caller), BEGIN / NOOP (stack untouched).
+struct StackHigh { fe push, cmp, rescr, keep; fe resc[6]; bool on; };       // the four flags; on = false: low-degree part only
+
 template <int I>
-__device__ __forceinline__ fe st_low_degree(const StackRows& s, const fe* lo2, const fe* mid, const fe* top) {
+__device__ __forceinline__ void st_high_degree(fe_acc& outer, const StackRows& s, const StackHigh& h) {
+    if constexpr (I < 8) {
+        const fe* o = s.o; const fe* nw = s.nw;
+        if constexpr (I >= 1) fe_acc_mac(outer, h.push, fe_sub(o[I - 1 < 0 ? 0 : I - 1], nw[I]));
+        {
+            const fe x_bit = nw[1], y_bit = nw[2], not_set = nw[3];
+            fe v;
+            if constexpr (I == 0) v = is_bin(x_bit);
+            else if constexpr (I == 1) v = is_bin(y_bit);
+            else if constexpr (I == 2) v = fe_sub(nw[4], fe_add(o[4], fe_mul(fe_mul(x_bit, bnot(y_bit)), not_set)));
+            else if constexpr (I == 3) v = fe_sub(nw[5], fe_add(o[5], fe_mul(fe_mul(y_bit, bnot(x_bit)), not_set)));
+            else if constexpr (I == 4) v = fe_sub(nw[6], fe_add(o[6], fe_mul(y_bit, o[0])));
+            else if constexpr (I == 5) v = fe_sub(nw[7], fe_add(o[7], fe_mul(x_bit, o[0])));
+            else if constexpr (I == 6) v = fe_sub(not_set, fe_mul(bnot(o[5]), bnot(o[4])));
+            else v = fe_sub(fe_double(nw[0]), o[0]);
+            fe_acc_mac(outer, h.cmp, v);
+        }
+        const fe keep = fe_sub(o[I < 8 ? I : 0], nw[I < 8 ? I : 0]);
+        if constexpr (I < 6) fe_acc_mac(outer, h.rescr, h.resc[I < 6 ? I : 0]); else fe_acc_mac(outer, h.rescr, keep);
+        fe_acc_mac(outer, h.keep, keep);
+    }
+}
+
+// slot I of the stack constraints: the three nested sums of the low-degree part, plus the high-degree / flow operations
+template <int I>
+__device__ __forceinline__ fe st_low_degree(const StackRows& s, const fe* lo2, const fe* mid, const fe* top, const StackHigh& h) {
     fe_acc outer; fe_acc_zero(outer);
     static_for_air<0, 2>([&](auto c_) {
         constexpr int c = decltype(c_)::value;
@@ -204,6 +234,7 @@ __device__ __forceinline__ fe st_low_degree(const StackRows& s, const fe* lo2, c
         });
         fe_acc_mac(outer, top[c], fe_acc_reduce(middle));
     });
+    if (h.on) st_high_degree<I>(outer, s, h);
     return fe_acc_reduce(outer);
 }
 
@@ -467,24 +498,39 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
         };
         fe f;
         constexpr bool NESTED = SD == 4 || (SD == 0 && SLCAP == 8);      // depth 4 exactly, or any depth <= 8 (all 8 slots, `sd` of them emitted)
+        constexpr bool HD_FUSED = NESTED && (SECT & 88) == 88;             // the whole stack in one launch: high-degree ops join the nested sums
         if constexpr (NESTED && (SECT & 8) != 0) {
             // all low-degree operations (both halves) as nested sums, see st_low_degree
             StackRows rows;
 #pragma unroll
             for (int i = 0; i < 8; i++) { rows.o[i] = o[i]; rows.nw[i] = nw[i]; }
             rows.hd0 = hd[0];
-            ev[0] = st_low_degree<0>(rows, lo2, mid, top);
-            ev[1] = st_low_degree<1>(rows, lo2, mid, top);
-            ev[2] = st_low_degree<2>(rows, lo2, mid, top);
-            ev[3] = st_low_degree<3>(rows, lo2, mid, top);
-            if constexpr (SD != 4) {
-                ev[4] = st_low_degree<4>(rows, lo2, mid, top);
-                ev[5] = st_low_degree<5>(rows, lo2, mid, top);
-                ev[6] = st_low_degree<6>(rows, lo2, mid, top);
-                ev[7] = st_low_degree<7>(rows, lo2, mid, top);
+            StackHigh high;
+            high.on = HD_FUSED;
+            if constexpr (HD_FUSED) {
+                high.push = hdf[0]; high.cmp = hdf[1]; high.rescr = hdf[2]; high.keep = fe_add(begin_flag, noop_flag);
+                fe os[6], ns[6];
+#pragma unroll
+                for (int i = 0; i < 6; i++) os[i] = fe_cube(fe_add(o[i], per[8 + i]));
+                matmul<6>(os, c_hasher_mds);
+#pragma unroll
+                for (int i = 0; i < 6; i++) ns[i] = nw[i];
+                matmul<6>(ns, c_hasher_inv_mds);
+#pragma unroll
+                for (int i = 0; i < 6; i++) high.resc[i] = fe_sub(fe_sub(fe_cube(ns[i]), per[14 + i]), os[i]);
             }
-            aux0 = st_low_degree<ST_AUX0>(rows, lo2, mid, top);
-            aux1 = st_low_degree<ST_AUX1>(rows, lo2, mid, top);
+            ev[0] = st_low_degree<0>(rows, lo2, mid, top, high);
+            ev[1] = st_low_degree<1>(rows, lo2, mid, top, high);
+            ev[2] = st_low_degree<2>(rows, lo2, mid, top, high);
+            ev[3] = st_low_degree<3>(rows, lo2, mid, top, high);
+            if constexpr (SD != 4) {
+                ev[4] = st_low_degree<4>(rows, lo2, mid, top, high);
+                ev[5] = st_low_degree<5>(rows, lo2, mid, top, high);
+                ev[6] = st_low_degree<6>(rows, lo2, mid, top, high);
+                ev[7] = st_low_degree<7>(rows, lo2, mid, top, high);
+            }
+            aux0 = st_low_degree<ST_AUX0>(rows, lo2, mid, top, high);
+            aux1 = st_low_degree<ST_AUX1>(rows, lo2, mid, top, high);
         }
         if constexpr (!NESTED && (SECT & 8) != 0) {
         // flags that only shift / copy are merged before the multiplications
@@ -584,7 +630,7 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
             aux0 = fe_add(aux0, fe_mul(f, binc));
         }
         }   // low-degree arithmetic / selection ops
-        if constexpr ((SECT & 16) != 0) {
+        if constexpr (!HD_FUSED && (SECT & 16) != 0) {
         rshift(1, hdf[0]);                                             // PUSH (input.rs:6)
         // CMP (hd 1) (comparison.rs:64-105)
         {
@@ -603,7 +649,7 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
         // BEGIN and NOOP leave the stack untouched
         copy_from(0, fe_add(begin_flag, noop_flag));
         }   // PUSH, CMP, BEGIN / NOOP
-        if constexpr ((SECT & 64) != 0) {
+        if constexpr (!HD_FUSED && (SECT & 64) != 0) {
         // RESCR (hd 2) (hash.rs:9-35)
         {
             f = hdf[2];
