@@ -406,9 +406,11 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
 
     // ---- decoder: sponge, loop image, context and loop stacks (decoder/sponge.rs, decoder/flow_ops.rs) -----------------------
     if constexpr ((SECT & 4) != 0) {
-        fe sp[4] = {fe_zero(), fe_zero(), fe_zero(), fe_zero()};
-        // HACC (sponge.rs:10-43)
+        fe sp[4];
+        const fe f_begin = cff[1], f_tend = cff[2], f_fend = cff[3], f_loop = cff[4], f_wrap = cff[5], f_break = cff[6], f_void = cff[7];
         {
+            // every sponge constraint is a sum of four flag * value products, reduced once (fe_acc):
+            //   HACC (sponge.rs:10-43) | cleared by BEGIN, LOOP, WRAP | copied by BREAK, VOID | TEND / FEND merge hashes
             fe os[4], ns[4];
 #pragma unroll
             for (int i = 0; i < 4; i++) os[i] = fe_cube(fe_add(c_sp[i], per[i]));
@@ -427,24 +429,20 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
             matmul<4>(ns, c_sponge_inv_mds);
 #pragma unroll
             for (int i = 0; i < 4; i++) ns[i] = fe_sub(fe_cube(ns[i]), per[4 + i]);
-#pragma unroll
-            for (int i = 0; i < 4; i++) sp[i] = fe_mul(cff[0], fe_sub(os[i], ns[i]));
-        }
-        const fe f_begin = cff[1], f_tend = cff[2], f_fend = cff[3], f_loop = cff[4], f_wrap = cff[5], f_break = cff[6], f_void = cff[7];
-        // sponge cleared by BEGIN, LOOP, WRAP; copied by BREAK, VOID; TEND / FEND merge hashes
-        {
-            fe clr = fe_add(fe_add(f_begin, f_loop), f_wrap);
-            fe cpy = fe_add(f_break, f_void);
+            const fe clr = fe_add(fe_add(f_begin, f_loop), f_wrap);
+            const fe cpy = fe_add(f_break, f_void);
+            const fe tf = fe_add(f_tend, f_fend);
+            const fe xf[4] = {tf, f_tend, f_fend, tf};
+            const fe xv[4] = {fe_sub(c_ctx[0], n_sp[0]), fe_sub(c_sp[0], n_sp[1]), fe_sub(c_sp[0], n_sp[2]), n_sp[3]};
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                sp[i] = fe_add(sp[i], fe_mul(clr, n_sp[i]));
-                sp[i] = fe_add(sp[i], fe_mul(cpy, fe_sub(c_sp[i], n_sp[i])));
+                fe_acc A; fe_acc_zero(A);
+                fe_acc_mac(A, cff[0], fe_sub(os[i], ns[i]));
+                fe_acc_mac(A, clr, n_sp[i]);
+                fe_acc_mac(A, cpy, fe_sub(c_sp[i], n_sp[i]));
+                fe_acc_mac(A, xf[i], xv[i]);
+                sp[i] = fe_acc_reduce(A);
             }
-            fe tf = fe_add(f_tend, f_fend);
-            sp[0] = fe_add(sp[0], fe_mul(tf, fe_sub(c_ctx[0], n_sp[0])));
-            sp[1] = fe_add(sp[1], fe_mul(f_tend, fe_sub(c_sp[0], n_sp[1])));
-            sp[2] = fe_add(sp[2], fe_mul(f_fend, fe_sub(c_sp[0], n_sp[2])));
-            sp[3] = fe_add(sp[3], fe_mul(tf, n_sp[3]));
         }
         acc.emit(15, 3, sp[0]); acc.emit(16, 4, sp[1]); acc.emit(17, 3, sp[2]); acc.emit(18, 3, sp[3]);
         // loop image (WRAP, BREAK)
@@ -455,9 +453,11 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
 #pragma unroll
             for (int i = 0; i < CL; i++) {
                 if (i >= cl) break;
-                fe v = fe_mul(push, fe_sub(i == 0 ? c_sp[0] : c_ctx[i - 1 < 0 ? 0 : i - 1], n_ctx[i]));
-                v = fe_add(v, fe_mul(pop, i + 1 < cl ? fe_sub(c_ctx[i + 1 < CL ? i + 1 : 0], n_ctx[i]) : n_ctx[i]));
-                v = fe_add(v, fe_mul(cpy, fe_sub(c_ctx[i], n_ctx[i])));
+                fe_acc A; fe_acc_zero(A);
+                fe_acc_mac(A, push, fe_sub(i == 0 ? c_sp[0] : c_ctx[i - 1 < 0 ? 0 : i - 1], n_ctx[i]));
+                fe_acc_mac(A, pop, i + 1 < cl ? fe_sub(c_ctx[i + 1 < CL ? i + 1 : 0], n_ctx[i]) : n_ctx[i]);
+                fe_acc_mac(A, cpy, fe_sub(c_ctx[i], n_ctx[i]));
+                const fe v = fe_acc_reduce(A);
                 acc.emit(20 + i, 2, v);
             }
         }
