@@ -239,18 +239,19 @@ __device__ __forceinline__ fe st_low_degree(const StackRows& s, const fe* lo2, c
 }
 
 // degree-group slots: 2->0 3->1 4->2 6->3 7->4 8->5
-// ADJ_ACC: the degree-group sums are fe_acc accumulators too (launches that emit into few groups; an accumulator is 21 registers)
-template <bool ADJ_ACC>
+// ACC_MASK: the degree-group sums (bit = slot) that are fe_acc accumulators too; an accumulator is 21 registers, so launches that
+// emit into many groups keep the rarely used ones as plain field elements
+template <uint32_t ACC_MASK>
 struct Acc {
     fe_acc res_acc;        // sum over all constraints of value * coefficient: one reduction at the end of the launch (fe_acc)
-    fe_acc adj_acc[ADJ_ACC ? 6 : 1];
+    fe_acc adj_acc[6];     // only the entries selected by ACC_MASK are ever touched (the others are eliminated)
     fe res, adj[6];
     bool nonzero;
     const fe* tc; uint32_t nc;
     __device__ __forceinline__ void emit(uint32_t cidx, int slot, const fe& d) {
         nonzero |= !fe_is_zero(d);
         fe_acc_mac(res_acc, d, tc[cidx]);
-        if constexpr (ADJ_ACC) fe_acc_mac(adj_acc[slot], d, tc[nc + cidx]);
+        if ((ACC_MASK >> slot) & 1u) fe_acc_mac(adj_acc[slot], d, tc[nc + cidx]);
         else adj[slot] = fe_add(adj[slot], fe_mul(d, tc[nc + cidx]));
     }
 };
@@ -368,12 +369,12 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
     }
 
     const fe* per = a.periodic + (size_t)(step & 127u) * 23;
-    constexpr bool ADJ_ACC = (SECT & 2) == 0 && (SD != 0 || SLCAP == 8);      // op bits emit into five groups: too many accumulators
-    Acc<ADJ_ACC> acc;
-    if constexpr (ADJ_ACC) {
+    // specialised instances: every group a launch without op bits emits into; with op bits (five groups) only degree 2, which
+    // takes ten of its fifteen constraints
+    constexpr uint32_t ACC_MASK = !(SD != 0 || SLCAP == 8) ? 0u : ((SECT & 2) ? 0x01u : 0x3Fu);
+    Acc<ACC_MASK> acc;
 #pragma unroll
-        for (int i = 0; i < 6; i++) fe_acc_zero(acc.adj_acc[i]);
-    }
+    for (int i = 0; i < 6; i++) if ((ACC_MASK >> i) & 1u) fe_acc_zero(acc.adj_acc[i]);
     fe_acc_zero(acc.res_acc); acc.res = fe_zero(); acc.nonzero = false; acc.tc = a.tc; acc.nc = 20 + cl + ll + 2 + sd;
 #pragma unroll
     for (int i = 0; i < 6; i++) acc.adj[i] = fe_zero();
@@ -682,10 +683,8 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
     // degree-group sums its sections emit into: op bits {2,3,4,6,8}, sponge / context / loop {4,6,7}, stack {7}
     acc.res = fe_acc_reduce(acc.res_acc);
     constexpr uint32_t USED = ((SECT & 2) ? 0x2Fu : 0u) | ((SECT & 4) ? 0x1Cu : 0u) | ((SECT & 120) ? 0x10u : 0u);
-    if constexpr (ADJ_ACC) {
 #pragma unroll
-        for (int i = 0; i < 6; i++) if ((USED >> i) & 1u) acc.adj[i] = fe_acc_reduce(acc.adj_acc[i]);
-    }
+    for (int i = 0; i < 6; i++) if (((ACC_MASK & USED) >> i) & 1u) acc.adj[i] = fe_add(acc.adj[i], fe_acc_reduce(acc.adj_acc[i]));
     if constexpr (!FIRST) {
         acc.res = fe_add(acc.res, a.partial[pidx]);
 #pragma unroll
