@@ -10,7 +10,7 @@
 //   * Uniform<T>::sample (UniformInt, "widening multiply" rejection): range = high - low,
 //     zone = MAX - ((MAX - range + 1) % range); loop { v = gen(); (hi, lo) = widening_mul(v, range);
 //     if lo <= zone { return low + hi } }.
-// PARITY STATUS: the ChaCha20 block function is pinned against OpenSSL's chacha20 keystream (tests/golden);
+// PARITY STATUS -- "parity unpinned" for the two rules named below: the ChaCha20 block function is pinned against OpenSSL's chacha20 keystream (tests/golden);
 // the word-consumption order and the Uniform rule are restated from the crates' published sources and are
 // UNPINNED (no Rust toolchain and no reference fixture with concrete draws exists -- SURVEY.md section 8c).
 #pragma once
