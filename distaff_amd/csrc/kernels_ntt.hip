@@ -635,31 +635,38 @@ void k_lde_columns(dst_ctx* c, const fe* polys, fe* lde, size_t ncols) {
 
 // ---- 8n coefficients -> coset-major evaluations -------------------------------------------------------------------------
 // d_j[m0] = w_N^(j*m0) * sum_{m1<8} c[m0 + n*m1] * w_B^(j*m1); followed by a plain size-n NTT per coset.
-__global__ void fold8_kernel(const fe* __restrict__ poly, fe* __restrict__ out, const fe* tw_lo, const fe* tw_hi, uint32_t lo_bits,
-                             uint32_t log_n, uint32_t log_N, uint32_t j0) {
-    // the eight factors w_B^(j*m1) depend on the coset only: one lane each forms them, the workgroup reads them from LDS
-    __shared__ fe cj[8];
+// one lane per m0 walks through all local cosets: the eight coefficients are read once, the factors w_B^(j*m1) of every coset come
+// from LDS, and w_N^(j*m0) advances by one multiplication per coset
+__global__ void __launch_bounds__(256) fold8_kernel(const fe* __restrict__ poly, fe* __restrict__ out, const fe* tw_lo, const fe* tw_hi, uint32_t lo_bits,
+                                                    uint32_t log_n, uint32_t log_N, uint32_t j0, uint32_t cosets) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char fold_smem[];
+    fe* cj = reinterpret_cast<fe*>(fold_smem);                      // [cosets][8]
     const size_t n = (size_t)1 << log_n;
     const uint64_t nmask = ((uint64_t)1 << log_N) - 1;
-    const uint32_t jg = j0 + blockIdx.y;
-    if (threadIdx.x < 8) cj[threadIdx.x] = dom_pow(tw_lo, tw_hi, lo_bits, ((uint64_t)jg * threadIdx.x << log_n) & nmask);
+    for (uint32_t i = threadIdx.x; i < cosets * 8; i += blockDim.x)
+        cj[i] = dom_pow(tw_lo, tw_hi, lo_bits, ((uint64_t)(j0 + (i >> 3)) * (i & 7) << log_n) & nmask);
     __syncthreads();
-    size_t m0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t m0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (m0 >= n) return;
-    fe_acc A; fe_acc_zero(A);                        // eight products, one reduction
-    fe_acc_add(A, poly[m0]);
+    fe c[8];
 #pragma unroll
-    for (uint32_t m1 = 1; m1 < 8; m1++) fe_acc_mac(A, poly[m0 + n * m1], cj[m1]);
-    fe acc = fe_acc_reduce(A);
-    uint64_t e0 = ((uint64_t)jg * m0) & nmask;
-    if (e0) acc = fe_mul(acc, dom_pow(tw_lo, tw_hi, lo_bits, e0));
-    out[(size_t)blockIdx.y * n + m0] = acc;
+    for (int m1 = 0; m1 < 8; m1++) c[m1] = poly[m0 + n * m1];
+    const fe step = dom_pow(tw_lo, tw_hi, lo_bits, m0 & nmask);                         // w_N^m0
+    fe t = dom_pow(tw_lo, tw_hi, lo_bits, ((uint64_t)j0 * m0) & nmask);                 // w_N^(j*m0) for the first local coset
+    for (uint32_t jl = 0; jl < cosets; jl++) {
+        fe_acc A; fe_acc_zero(A);                        // eight products, one reduction
+        fe_acc_add(A, c[0]);
+#pragma unroll
+        for (int m1 = 1; m1 < 8; m1++) fe_acc_mac(A, c[m1], cj[jl * 8 + m1]);
+        out[(size_t)jl * n + m0] = fe_mul(fe_acc_reduce(A), t);
+        t = fe_mul(t, step);
+    }
 }
 
 void k_lde_fold8(dst_ctx* c, const fe* poly8n, fe* out) {
     // stage the folded inputs in `out` itself, then transform each coset in place (pass A reads out, pass B writes out)
-    dim3 g((unsigned)((c->n + 255) / 256), (unsigned)c->Bc);
-    { KScope ks_(c, "fold8_kernel", 16.0 * c->n * (8 + c->Bc)); hipLaunchKernelGGL(fold8_kernel, g, dim3(256), 0, c->stream, poly8n, out, c->tw_lo, c->tw_hi, c->tw_lo_bits, c->log_n, c->log_N, (uint32_t)c->j0); }
+    dim3 g((unsigned)((c->n + 255) / 256));
+    { KScope ks_(c, "fold8_kernel", 16.0 * c->n * (8 + c->Bc)); hipLaunchKernelGGL(fold8_kernel, g, dim3(256), c->Bc * 8 * sizeof(fe), c->stream, poly8n, out, c->tw_lo, c->tw_hi, c->tw_lo_bits, c->log_n, c->log_N, (uint32_t)c->j0, (uint32_t)c->Bc); }
     launch_two_pass(c, out, 0, c->n, out, 0, c->n, c->Bc, 1, false, false);
 }
 
