@@ -294,7 +294,7 @@ struct Geometry {                      // distaff_amd/sharded.py TreeGeometry: l
         uint64_t t = heap - level, span = L / level;
         if (span >= Bct) { g = -1; idx = heap; return; }
         uint64_t local_leaf; leaf(t * span, g, local_leaf);
-        idx = K * Bct / span + local_leaf / span;
+        idx = L / (G * span) + local_leaf / span;                              // nodes of this level held by one rank = L / (G * span), also when L < Bt
     }
 };
 

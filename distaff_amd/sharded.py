@@ -96,7 +96,7 @@ class TreeGeometry:
         if span >= self.Bct:
             return None, heap_index
         g, local_leaf = self.leaf(t * span)
-        local_count = self.K * self.Bct // span
+        local_count = self.L // (self.G * span)
         return g, local_count + local_leaf // span
 
 

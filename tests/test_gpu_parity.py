@@ -480,3 +480,12 @@ def test_bench_line_contract(tmp_path):
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and "sample" in c and c["unit"] == d["unit"]
+
+
+@pytest.mark.parametrize("steps,log_blowup", [(128, 7), (256, 8)])
+def test_blowup_128_and_256(oracle, steps, log_blowup):
+    """The largest extension factors the C-ABI accepts, on trace lengths for which the reference's own FRI parameters verify (with a
+    256-element remainder bound the reference rejects its own proofs for many (length, extension) pairs beyond 64, e.g. 512 x 256).
+    Includes FRI layers with fewer leaves than the extension factor (tree geometry of the batched openings)."""
+    import distaff_amd as D
+    _check_all_phases(oracle, D, oracle.fibonacci_trace(steps), log_blowup=log_blowup, num_queries=20)
