@@ -3,14 +3,20 @@
 // Replaces the recursive radix-2 `fft_in_place` (+ `permute`) of /root/reference/src/math/fft.rs:16-108 as it is used by
 // TraceTable::extend (src/stark/trace/trace_table.rs:143-169), ConstraintTable::combine_polys (constraint_table.rs:54-88),
 // ConstraintPoly::eval (constraint_poly.rs:28-37) and the composition evaluation (prover.rs:98-101).  Field results are
-// unique, so the algorithm is free: every transform here is a size-n = n1*n2 "four-step" NTT run as two HBM passes,
-//   pass A: for a tile of T adjacent columns m2, the n1-point NTT over the stride-n2 dimension, in LDS (radix-2 DIF),
-//           fused with the coset pre-scale w_N^(j*n2*m1) on load and the four-step twiddle w_N^(m2*(B*k1+j)) on store;
-//   pass B: for a tile of T adjacent rows k1, the n2-point NTT over the contiguous dimension, in LDS, stored as
-//           X[k1 + n1*k2] so that the output is in natural order.
+// unique, so the algorithm is free: every transform here is a "four-step" NTT in HBM passes over LDS tiles,
+//   two passes (n = n1*n2, n < 2^21):
+//     pass A: for a tile of T adjacent columns m2, the n1-point NTT over the stride-n2 dimension, in LDS, with the four-step
+//             twiddle w_N^(m2*(B*k1+j)) on store (streamed from a table).  For an extension the transform is a coset DIT whose
+//             stage twiddles carry the coset pre-scale w_N^(j*n2*m1); otherwise a DIF; two radix-2 stages per LDS round trip;
+//     pass B: for a tile of T adjacent rows k1, the n2-point NTT over the contiguous dimension, in LDS, stored as
+//             X[k1 + n1*k2] so that the output is in natural order;
+//   three passes (n = n1*nm*n3, n >= 2^21): pass A, pass A again on every row of n/n1 points, pass B with tiles of adjacent k1.
+// Workgroups are persistent over adjacent tiles and prefetch the next tile into registers while the current one is in LDS.
 // The low-degree extension never materialises the zero-padded size-N input of the reference: the N = B*n evaluations
-// are B coset transforms of size n (coset j holds the reference's indices B*k + j), stored coset-major.
-// Loads/stores are T*16-byte segments (T = 4: 64 B); the working set of one workgroup is 2^log * T * 16 B of LDS.
+// are B coset transforms of size n (coset j holds the reference's indices B*k + j), stored coset-major; coset 0 of the trace
+// extension is the trace itself and is copied.  HBM accesses are T*16-byte segments (T = 4 for 1024-point tiles, 16 for the
+// 256-point tiles of three-pass plans).  A second, register-radix kernel family (ntt_reg_kernel) is kept as an independent
+// implementation that the tests run at every tile length.
 #include "ctx.h"
 #include <type_traits>
 
