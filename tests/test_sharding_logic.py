@@ -54,6 +54,19 @@ def test_tree_geometry_partitions_the_tree():
             assert len(local_nodes[g]) == (L // Bt) * (Bt // G - 2)           # levels strictly below the boundary level
 
 
+def test_tree_geometry_single_rank_is_the_plain_heap():
+    """One rank: every node's local index is its heap index -- also for trees with fewer leaves than columns (FRI layers of fewer
+    rows than the extension factor, e.g. 128 rows at extension 256), where the column count does not divide the leaf count."""
+    from distaff_amd.sharded import TreeGeometry
+    for L, Bt in ((1 << 8, 32), (1 << 7, 256), (1 << 5, 64), (4, 256)):
+        geom = TreeGeometry(L, Bt, 1)
+        for i in range(L):
+            assert geom.leaf(i) == (0, i)
+        for heap in range(1, L):
+            g, hi = geom.node(heap)
+            assert hi == heap and g in (None, 0)
+
+
 def test_sharded_tree_equals_full_tree(oracle):
     """Model of the tree exchange on the CPU: local sub-heaps per rank + all-gathered boundary nodes give the reference's root and nodes."""
     from distaff_amd.sharded import TreeGeometry
