@@ -150,3 +150,114 @@ def test_library_exports_every_declared_symbol():
     missing = [s for s in sorted(declared) if not hasattr(lib, s)]
     assert not missing, missing
     assert declared == set(D.EXPORTS), declared ^ set(D.EXPORTS)
+
+
+# ---- the whole sharded orchestration on the CPU: ShardedProver over a mock rank-local context (tests/mock_shard.py) -------------
+def _mock_world(oracle, world, trace, prover, comms, **options):
+    import threading
+    from mock_shard import MockShardContext
+    from distaff_amd.sharded import ShardedProver
+    results, errors = [None] * world, [None] * world
+
+    def run(rank):
+        try:
+            ctx = MockShardContext(oracle, prover, trace, rank, world, **options)
+            results[rank] = ShardedProver(ctx, comms[rank], python_openings=True).prove(trace.public_inputs, prover.outputs)
+        except BaseException as e:      # noqa: BLE001
+            errors[rank] = e
+            comms[rank].shared.barrier.abort()
+
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    first = next((e for e in errors if e is not None and not isinstance(e, threading.BrokenBarrierError)), None)
+    if first is not None:
+        raise first
+    return results
+
+
+@pytest.mark.parametrize("world", [1, 2, 4, 8])
+def test_sharded_orchestration_reproduces_the_oracle_proof(oracle, world):
+    """every rank of ShardedProver.prove (exchanges, Fiat-Shamir, opening plan, ownership, wire format) assembles the oracle's
+    proof byte for byte when the rank-local buffers hold the oracle's values in the sharded layouts"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from distaff_amd.sharded import LocalComm
+    O = oracle
+    t = O.fibonacci_trace(128)
+    p = O.Prover.from_trace(t, 1, grinding=8)
+    proof = p.prove()
+    results = _mock_world(O, world, t, p, LocalComm.create(world), grinding=8)
+    assert all(r == proof for r in results)
+    assert O.verify(results[-1], t.program_hash, t.public_inputs, p.outputs) == (True, "")
+
+
+def test_sharded_orchestration_other_options_and_program(oracle):
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from distaff_amd.sharded import LocalComm
+    O = oracle
+    t = O.fibonacci_trace(256)
+    p = O.Prover.from_trace(t, 1, ext=16, num_queries=100, grinding=10)          # config 5's options at a small size
+    proof = p.prove()
+    for world in (2, 4):
+        assert all(r == proof for r in _mock_world(O, world, t, p, LocalComm.create(world), log_blowup=4, num_queries=100, grinding=10))
+    t = O.Trace("begin add block push.5 mul push.7 end end", [1, 2])             # context register, two outputs
+    p = O.Prover.from_trace(t, 2, grinding=8)
+    proof = p.prove()
+    assert all(r == proof for r in _mock_world(O, 2, t, p, LocalComm.create(2), grinding=8))
+
+
+def test_mock_detects_a_gather_in_the_wrong_rank_order(oracle):
+    """the mock is a real check of the collective layer: pieces delivered in another order are refused"""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from distaff_amd.sharded import LocalComm
+    O = oracle
+    t = O.fibonacci_trace(128)
+    p = O.Prover.from_trace(t, 1, grinding=8)
+    p.prove()
+
+    class Reversed(LocalComm):
+        def all_gather_object(self, obj):
+            return super().all_gather_object(obj)[::-1]
+
+    shared = LocalComm._Shared(2)
+    with pytest.raises(AssertionError, match="rank order"):
+        _mock_world(O, 2, t, p, [Reversed(shared, r) for r in range(2)], grinding=8)
+
+
+MOCK_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, os.path.join(%(root)r, "tests"))
+import torch.distributed as dist
+import oracle as O
+from mock_shard import MockShardContext
+from distaff_amd.sharded import ShardedProver, TorchComm
+dist.init_process_group("gloo")
+comm = TorchComm(dist)
+t = O.fibonacci_trace(128)
+p = O.Prover.from_trace(t, 1, grinding=8)
+proof = p.prove()
+ctx = MockShardContext(O, p, t, comm.rank, comm.world, grinding=8)
+prover = ShardedProver(ctx, comm, python_openings=True)
+got = prover.prove(t.public_inputs, p.outputs)
+assert got == proof, "rank %%d: proof differs from the oracle's" %% comm.rank
+assert set(prover.stage_ms) >= {"trace_tree_exchange", "ceval_exchange", "fri", "openings"}
+comm.barrier()
+dist.destroy_process_group()
+print("ok", comm.rank, len(got))
+'''
+
+
+def test_sharded_orchestration_gloo_world2(oracle, tmp_path):
+    """two processes over torch.distributed (gloo): the N > 1 path of bench.py / INTEGRATION.md minus the device"""
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    script = tmp_path / "mock_worker.py"
+    script.write_text(MOCK_WORKER % {"root": ROOT})
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)
