@@ -81,7 +81,7 @@ __device__ __forceinline__ void static_for_air(F&& f) {
 // the 32 flags are never formed and every level is a sum of products with one reduction (fe_acc): ~13k instructions per point
 // instead of ~21k for flag products + per-term multiply-adds.  st_term states, per operation and slot, exactly what the
 // per-operation code below passes to agg(): slots 0..3 are the stack constraints, 4 and 5 the two auxiliary constraints.
-struct StackRows { fe o[8], nw[8], hd0; };
+struct StackRows { fe o[12], nw[8], hd0; int sl; };       // o[8..11] and sl only matter to the deep instance (slice longer than 8)
 #define ST_AUX0 8
 #define ST_AUX1 9
 
@@ -106,8 +106,12 @@ template <int OP, int I>
 __device__ __forceinline__ fe st_term(const StackRows& s) {
     const fe* o = s.o; const fe* nw = s.nw;
     constexpr int i = I < 8 ? I : 0;
-    // the shift helpers of constraints/stack/mod.rs on an 8-item slice: a left shift by num zero-fills the last num slots
-    auto L = [&](int num) { return i + num < 8 ? fe_sub(o[i + num < 8 ? i + num : 0], nw[i]) : nw[i]; };
+    // the shift helpers of constraints/stack/mod.rs on a slice of s.sl >= 8 items (8 unless the stack is deeper): a left shift by
+    // num zero-fills the last num slots
+    auto L = [&](int num) {
+        if (i + num < 8) return fe_sub(o[i + num < 8 ? i + num : 0], nw[i]);
+        return i + num < s.sl ? fe_sub(o[i + num < 12 ? i + num : 0], nw[i]) : nw[i];
+    };
     auto R = [&](int num) { return fe_sub(o[i - num < 0 ? 0 : i - num], nw[i]); };   // right shift by num (callers: i >= num)
     auto C = [&]() { return fe_sub(o[i], nw[i]); };                       // copy
     auto sel = [&](const fe& c, const fe& x, const fe& y) { return fe_add(y, fe_mul(c, fe_sub(x, y))); };   // c*x + (1-c)*y with one multiplication
@@ -266,6 +270,9 @@ struct Acc {
 template <int CL, int LL, int SD, int SLCAP, int SECT, bool FIRST, bool LAST>
 __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(AirArgs a) {
     constexpr int SL = SD ? (SD > 8 ? SD : 8) : SLCAP;
+    // SLCAP == 12 is the deep instance: any stack depth; slots 0..7 as nested sums from 12 register-resident items of the current
+    // row, slots 8.. from memory as seven flag sums times shifted differences (see the stack section)
+    constexpr bool DEEP = SD == 0 && SLCAP == 12;
     const int cl = (int)a.cl, ll = (int)a.ll;
     const int sl = SD ? SL : (int)a.sl;
     const int sd = SD ? SD : (int)a.stack_depth;
@@ -371,7 +378,7 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
     const fe* per = a.periodic + (size_t)(step & 127u) * 23;
     // specialised instances: every group a launch without op bits emits into; with op bits (five groups) only degree 2, which
     // takes ten of its fifteen constraints
-    constexpr uint32_t ACC_MASK = !(SD != 0 || SLCAP == 8) ? 0u : ((SECT & 2) ? 0x01u : 0x3Fu);
+    constexpr uint32_t ACC_MASK = !(SD != 0 || SLCAP == 8 || DEEP) ? 0u : ((SECT & 2) ? 0x01u : 0x3Fu);
     Acc<ACC_MASK> acc;
 #pragma unroll
     for (int i = 0; i < 6; i++) if ((ACC_MASK >> i) & 1u) fe_acc_zero(acc.adj_acc[i]);
@@ -478,34 +485,38 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
 
     // ---- stack constraints (constraints/stack/mod.rs:117-195) ---------------------------------------------------------------
     if constexpr ((SECT & 120) != 0) {
-        fe ev[SL], aux0 = fe_zero(), aux1 = fe_zero();
+        constexpr int SLR = DEEP ? 8 : SL;                  // slots whose constraints are formed in registers
+        fe ev[SLR], aux0 = fe_zero(), aux1 = fe_zero();
 #pragma unroll
-        for (int i = 0; i < SL; i++) ev[i] = fe_zero();
+        for (int i = 0; i < SLR; i++) ev[i] = fe_zero();
         auto agg = [&](int i, const fe& f, const fe& v) { if (i < sd) ev[i] = fe_add(ev[i], fe_mul(f, v)); };
         auto copy_from = [&](int from, const fe& f) {
 #pragma unroll
-            for (int i = 0; i < SL; i++) if (i >= from && i < sl) agg(i, f, fe_sub(o[i], nw[i]));
+            for (int i = 0; i < SLR; i++) if (i >= from && i < sl) agg(i, f, fe_sub(o[i], nw[i]));
         };
         auto rshift = [&](int num, const fe& f) {
 #pragma unroll
-            for (int i = 0; i < SL; i++) if (i >= num && i < sl) agg(i, f, fe_sub(o[i - num < 0 ? 0 : i - num], nw[i]));
+            for (int i = 0; i < SLR; i++) if (i >= num && i < sl) agg(i, f, fe_sub(o[i - num < 0 ? 0 : i - num], nw[i]));
         };
         auto lshift = [&](int from, int num, const fe& f) {
 #pragma unroll
-            for (int i = 0; i < SL; i++) {
+            for (int i = 0; i < SLR; i++) {
                 if (i >= from - num && i < sl - num) agg(i, f, fe_sub(o[i + num < SL ? i + num : 0], nw[i]));
                 else if (i >= sl - num && i < sl) agg(i, f, nw[i]);
             }
         };
         fe f;
-        constexpr bool NESTED = SD == 4 || (SD == 0 && SLCAP == 8);      // depth 4 exactly, or any depth <= 8 (all 8 slots, `sd` of them emitted)
+        constexpr bool NESTED = SD == 4 || (SD == 0 && SLCAP == 8) || DEEP;      // depth 4 exactly, any depth <= 8 (all 8 slots, `sd` of them emitted), or the first 8 slots of a deeper stack
         constexpr bool HD_FUSED = NESTED && (SECT & 88) == 88;             // the whole stack in one launch: high-degree ops join the nested sums
         if constexpr (NESTED && (SECT & 8) != 0) {
             // all low-degree operations (both halves) as nested sums, see st_low_degree
             StackRows rows;
 #pragma unroll
             for (int i = 0; i < 8; i++) { rows.o[i] = o[i]; rows.nw[i] = nw[i]; }
+#pragma unroll
+            for (int i = 8; i < 12; i++) rows.o[i] = DEEP ? o[i < SL ? i : 0] : fe_zero();
             rows.hd0 = hd[0];
+            rows.sl = DEEP ? sl : 8;
             StackHigh high;
             high.on = HD_FUSED;
             if constexpr (HD_FUSED) {
@@ -672,7 +683,41 @@ __global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(Ai
         const uint32_t sbase = 20 + cl + ll;
         if constexpr ((SECT & 40) != 0) { acc.emit(sbase, 4, aux0); acc.emit(sbase + 1, 4, aux1); }    // only low-degree ops touch the aux constraints
 #pragma unroll
-        for (int i = 0; i < SL; i++) if (i < sd) acc.emit(sbase + 2 + i, 4, ev[i]);
+        for (int i = 0; i < SLR; i++) if (i < sd) acc.emit(sbase + 2 + i, 4, ev[i]);
+        if constexpr (DEEP && (SECT & 16) != 0) {
+            // Slots 8 .. sd-1 of a deep stack.  No operation computes anything there: a slot is copied, or takes the item 1, 2 or 4
+            // places to its left or right (left shifts zero-fill the end of the slice), constraints/stack/mod.rs:117-195 with the
+            // shift helpers :199-262.  So the constraint is a sum of seven products, flag sum * (shifted old item - new item), and
+            // the seven flag sums are formed once per point from the three small tables (never the 32 flags):
+            //   left by 1: ASSERT DROP ADD MUL AND OR | by 2: ASSERTEQ EQ CHOOSE CSWAP2 | by 4: DROP4 CHOOSE2
+            //   right by 1: READ DUP PUSH | by 2: READ2 DUP2 PAD2 | by 4: DUP4
+            //   copy: INV NEG NOT SWAP SWAP2 SWAP4 ROLL4 ROLL8 BINACC CMP RESCR BEGIN NOOP
+            const fe lo_all = fe_add(fe_add(lo2[0], lo2[1]), fe_add(lo2[2], lo2[3]));
+            fe fl1, fl2, fl4, fr1, fr2, fr4, fcp;
+            { fe_acc A; fe_acc_zero(A); fe_acc_mac(A, mid[0], lo2[3]); fe_acc_mac(A, mid[2], lo_all); fl1 = fe_add(fe_mul(top[0], fe_acc_reduce(A)), assert_flag); }
+            { fe_acc A; fe_acc_zero(A); fe_acc_mac(A, mid[0], fe_add(lo2[1], lo2[2])); fe_acc_mac(A, mid[1], fe_add(lo2[1], lo2[3])); fl2 = fe_mul(top[0], fe_acc_reduce(A)); }
+            fl4 = fe_mul(top[0], fe_mul(mid[1], fe_add(lo2[0], lo2[2])));
+            fr1 = fe_add(fe_mul(top[1], fe_mul(mid[0], fe_add(lo2[0], lo2[2]))), hdf[0]);
+            { fe_acc A; fe_acc_zero(A); fe_acc_mac(A, mid[0], fe_add(lo2[1], lo2[3])); fe_acc_mac(A, mid[1], lo2[1]); fr2 = fe_mul(top[1], fe_acc_reduce(A)); }
+            fr4 = fe_mul(top[1], fe_mul(mid[1], lo2[0]));
+            {
+                fe_acc A; fe_acc_zero(A); fe_acc_mac(A, mid[2], lo_all); fe_acc_mac(A, mid[3], fe_add(lo2[0], lo2[1]));
+                fe_acc B; fe_acc_zero(B); fe_acc_mac(B, top[1], fe_acc_reduce(A)); fe_acc_mac(B, top[0], fe_mul(mid[3], fe_add(fe_add(lo2[0], lo2[1]), lo2[2])));
+                fcp = fe_add(fe_add(fe_acc_reduce(B), fe_add(hdf[1], hdf[2])), fe_add(begin_flag, noop_flag));
+            }
+            const uint32_t scol = 15 + a.ctx_depth + a.loop_depth;
+#pragma unroll 1
+            for (int i = 8; i < sd; i++) {
+                const fe ni = NXT(scol + i);
+                auto item = [&](int j) { return CUR(scol + j); };              // j in [4, sd) here
+                auto left = [&](int num) { return i + num < sl ? fe_sub(item(i + num), ni) : ni; };
+                fe_acc A; fe_acc_zero(A);
+                fe_acc_mac(A, fcp, fe_sub(item(i), ni));
+                fe_acc_mac(A, fr1, fe_sub(item(i - 1), ni)); fe_acc_mac(A, fr2, fe_sub(item(i - 2), ni)); fe_acc_mac(A, fr4, fe_sub(item(i - 4), ni));
+                fe_acc_mac(A, fl1, left(1)); fe_acc_mac(A, fl2, left(2)); fe_acc_mac(A, fl4, left(4));
+                acc.emit(sbase + 2 + i, 4, fe_acc_reduce(A));
+            }
+        }
     }
 
     // ---- combination (evaluator.rs:139-162, 335-358) ---------------------------------------------------------------------------
@@ -725,4 +770,5 @@ static void launch_air(dst_ctx* c, const AirArgs& a, uint32_t Q) {
 // instances live in their own translation units (compile time): Fibonacci shape, small stacks, fully generic
 void air_launch_sd4(dst_ctx* c, const AirArgs& a, uint32_t Q);      // cl <= 2, ll <= 1, stack_depth == 4
 void air_launch_small(dst_ctx* c, const AirArgs& a, uint32_t Q);    // cl <= 2, ll <= 1, stack_depth <= 8
-void air_launch_generic(dst_ctx* c, const AirArgs& a, uint32_t Q);  // anything the VM can produce
+void air_launch_deep(dst_ctx* c, const AirArgs& a, uint32_t Q);     // anything the VM can produce, nested sums + flag sums for slots >= 8
+void air_launch_generic(dst_ctx* c, const AirArgs& a, uint32_t Q);  // anything the VM can produce, per-operation formulation (DISTAFF_AIR=generic)

@@ -41,11 +41,13 @@ int k_eval_constraints(dst_ctx* c, const fe* coeffs_dev, const fe* tc_dev, int64
     HIP_TRY(c, hipMemcpyAsync(c->d_u64, &init, 8, hipMemcpyHostToDevice, c->stream));
     const uint32_t cd = c->prm.ctx_depth, lp = c->prm.loop_depth, sd = (uint32_t)c->stack_depth;
     a.cl = cd > 1 ? cd : 1; a.ll = lp > 1 ? lp : 1; a.sl = sd > 8 ? sd : 8;
-    // DISTAFF_AIR=generic|small forces a more general instance than the shape needs (tests run the same trace through all of them)
+    // DISTAFF_AIR=generic|deep|small forces a more general instance than the shape needs (tests run the same trace through all of them)
     const char* force = getenv("DISTAFF_AIR");
-    const bool want_generic = force && !strcmp(force, "generic"), want_small = force && !strcmp(force, "small");
-    if (a.cl <= 2 && a.ll <= 1 && sd == 4 && !want_generic && !want_small) air_launch_sd4(c, a, Q);
-    else if (a.cl <= 2 && a.ll <= 1 && sd <= 8 && !want_generic) air_launch_small(c, a, Q);
+    const bool want_generic = force && !strcmp(force, "generic"), want_small = force && !strcmp(force, "small"), want_deep = force && !strcmp(force, "deep");
+    const bool general = want_generic || want_deep;
+    if (a.cl <= 2 && a.ll <= 1 && sd == 4 && !general && !want_small) air_launch_sd4(c, a, Q);
+    else if (a.cl <= 2 && a.ll <= 1 && sd <= 8 && !general) air_launch_small(c, a, Q);
+    else if (!want_generic) air_launch_deep(c, a, Q);
     else air_launch_generic(c, a, Q);
     unsigned long long res = 0;
     HIP_TRY(c, hipMemcpyAsync(&res, c->d_u64, 8, hipMemcpyDeviceToHost, c->stream));

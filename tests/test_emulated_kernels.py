@@ -31,7 +31,10 @@ SELECTION = [
     "test_sharded_prover_equals_single_gpu[2]",
     "test_sharded_prover_equals_single_gpu[8]",
     "test_sharded_prover_reports_invalid_trace",
+    "test_deep_stacks_and_nested_blocks[]",
+    "test_deep_stacks_and_nested_blocks[generic]",
     "test_general_constraint_instances_on_the_fibonacci_trace[small]",
+    "test_general_constraint_instances_on_the_fibonacci_trace[deep]",
     "test_general_constraint_instances_on_the_fibonacci_trace[generic]",
     "test_lde_every_tile_length[reg-13-5]",
     "test_lde_every_tile_length[lds-13-5]",

@@ -88,7 +88,7 @@ def test_fibonacci_all_phases(oracle, log_n):
     _check_all_phases(oracle, D, oracle.fibonacci_trace(1 << log_n))
 
 
-@pytest.mark.parametrize("instance", ["", "small", "generic"])
+@pytest.mark.parametrize("instance", ["", "small", "deep", "generic"])
 def test_boundary_constraints_by_evaluation(oracle, monkeypatch, instance):
     """The evaluate-and-interpolate route of the two boundary combinations (the reference's own, constraint_table.rs:54-62): its
     evaluation vectors equal the oracle's; the default route writes the same polynomials in coefficient form, and every other test
@@ -108,6 +108,26 @@ def test_other_program_shapes(oracle):
     _check_all_phases(O, D, O.Trace("begin add block push.5 mul push.7 end end", [1, 2]), num_outputs=2)  # W = 18
     _check_all_phases(O, D, O.Trace("begin push.3 push.4 push.5 push.6 push.7 push.8 push.9 push.10 push.11 mul add block swap.2 dup.2 drop add end mul end", [1, 2]),
                       num_outputs=3)                                                                      # stack deeper than 8
+
+
+DEEP_PROGRAMS = [   # (source, inputs, outputs): stack deeper than 8 and / or more than two context registers -> the any-shape instances
+    ("begin push.3 push.4 push.5 push.6 push.7 push.8 push.9 push.10 push.11 mul add block swap.2 dup.2 drop add end mul end", [1, 2], 3),     # depth 11
+    ("begin push.3 push.4 push.5 push.6 push.7 push.8 push.9 push.10 push.11 push.12 push.13 push.14 dup.4 dup.4 dup.2 swap.2 mul add block swap.2 dup.2 drop add "
+     "block dup.1 mul swap.1 drop.4 block add mul end end end drop.4 mul add end", [1, 2, 3], 4),                                                # depth 25, 3 context registers
+    ("begin add block push.5 mul block dup.2 add block mul push.7 end end end add end", [1, 2, 3, 4], 2),                                         # depth 6, 3 context registers
+]
+
+
+@pytest.mark.parametrize("instance", ["", "generic"])
+def test_deep_stacks_and_nested_blocks(oracle, monkeypatch, instance):
+    """Shapes outside the specialised instances: by default the nested-sum instance whose slots 8.. are seven flag sums times shifted
+    differences, and the per-operation formulation (DISTAFF_AIR=generic) as an independent statement of the same constraints; both
+    must reproduce the oracle's evaluations on the whole 8n domain (where every operation's flag is non-zero), and the proof."""
+    import distaff_amd as D
+    if instance:
+        monkeypatch.setenv("DISTAFF_AIR", instance)
+    for src, inputs, num_outputs in DEEP_PROGRAMS:
+        _check_all_phases(oracle, D, oracle.Trace(src, inputs), num_outputs=num_outputs)
 
 
 def test_program_shapes_with_stack_depth_5_to_8(oracle):
@@ -448,9 +468,9 @@ def test_sharded_prover_two_processes_over_gloo(tmp_path):
         assert (tmp_path / ("proof_%d.bin" % r)).read_bytes() == expected
 
 
-@pytest.mark.parametrize("instance", ["small", "generic"])
+@pytest.mark.parametrize("instance", ["small", "deep", "generic"])
 def test_general_constraint_instances_on_the_fibonacci_trace(oracle, monkeypatch, instance):
-    """The depth <= 8 and the any-shape instances of the constraint kernel, forced onto a trace the depth-4 instance would take:
+    """The depth <= 8 and the two any-shape instances of the constraint kernel, forced onto a trace the depth-4 instance would take:
     same evaluations, same proof (DISTAFF_AIR is read by the library at every evaluation)."""
     import distaff_amd as D
     monkeypatch.setenv("DISTAFF_AIR", instance)
