@@ -19,6 +19,6 @@ t0 = time.perf_counter()
 for _ in range(runs):
     proof = ctx.prove([1, 0], [result])
 ms = (time.perf_counter() - t0) / runs * 1e3
-print("2^%d steps: %.2f ms per proof, %.3e trace-cells/s, %d proof bytes, phases %s" % (
-    log_n, ms, (1 << log_n) * 20 / (ms * 1e-3), len(proof), [round(v, 2) for v in ctx.phase_ms()]))
+print("2^%d steps: %.2f ms per proof, %.3e trace-cells/s, %d proof bytes (blake3 %s), phases %s" % (
+    log_n, ms, (1 << log_n) * 20 / (ms * 1e-3), len(proof), D.blake3(proof).hex()[:16], [round(v, 2) for v in ctx.phase_ms()]))
 ctx.close()
