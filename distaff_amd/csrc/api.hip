@@ -78,6 +78,7 @@ static void free_all(dst_ctx* c) {
     if (c->trace_upper) hipFree(c->trace_upper);
     if (c->c_upper) hipFree(c->c_upper);
     for (int d = 0; d < DST_MAX_FRI_LAYERS; d++) if (c->fri_upper[d]) hipFree(c->fri_upper[d]);
+    if (c->fri_nat0) hipFree(c->fri_nat0);
     for (int d = 0; d < DST_MAX_FRI_LAYERS; d++) {
         if (d > 0 && c->fri_e[d]) hipFree(c->fri_e[d]);
         if (c->fri_leaves[d]) hipFree(c->fri_leaves[d]);
@@ -442,7 +443,7 @@ int dst_compose(dst_ctx* c, const uint8_t* draws_bytes, uint8_t* trace_at_z1, ui
     memcpy(trace_at_z1, c->deep_z1.data(), W * 16);
     memcpy(trace_at_z2, c->deep_z2.data(), W * 16);
     c->phase_ms[5] = wall_ms() - t0;
-    c->composed = true; c->fri_committed = 0; c->fri_folded = 0; c->fri_roots.clear();
+    c->composed = true; c->fri_committed = 0; c->fri_folded = 0; c->fri_roots.clear(); c->fri_tail_pending = false;
     return DST_OK;
 }
 

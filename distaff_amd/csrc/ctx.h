@@ -67,6 +67,9 @@ struct dst_ctx {
     std::vector<fe> shard_draws;       // shard.hip: the 344 constraint coefficients of the current proof
     std::shared_ptr<void> open_plan;   // shard.hip: plan of the last dst_shard_open, reused by dst_shard_assemble for the same positions
     std::vector<uint64_t> open_plan_positions;
+    int fri_rep_from = 0;               // sharded phases: FRI layers >= this one are replicated (natural order, full heaps on every rank), see shard.hip
+    bool fri_tail_pending = false;      // dst_shard_fri_begin exported the evaluations of layer fri_rep_from; dst_shard_fri_end finishes the commit phase
+    fe* fri_nat0 = nullptr;             // natural-order layer 0 when fri_rep_from == 0 (fri_e[0] is the rank's coset-major piece)
     bool sharded_layout = false;        // FRI layers >= 1 coset-major with per-rank tree heaps (dst_shard_* phases) instead of natural order / full heaps
 
     // tables (device)
@@ -164,6 +167,9 @@ void k_lde_columns(dst_ctx* c, const fe* polys, fe* lde, size_t ncols);         
 void k_lde_fold8(dst_ctx* c, const fe* poly8n, fe* out);                                // 8n coefficients -> coset-major [Bc][n]
 void k_intt8_cosets(dst_ctx* c, fe* vals /* [8][n] coset-major, in place scratch */, fe* out8n, fe* work);
 void k_coset_to_natural(dst_ctx* c, const fe* src, size_t cosets, fe* dst);             // [cosets][n] -> natural [n*cosets]
+void k_coset_to_natural_len(dst_ctx* c, const fe* src, size_t cosets, size_t len, fe* dst);
+void k_fri_leaves_at(dst_ctx* c, const fe* e, digest* leaves, size_t R);
+void k_fri_fold_at(dst_ctx* c, const fe* e, fe* out, size_t R, int layer, fe special_x);
 // hashing
 void k_trace_leaves(dst_ctx* c);
 void k_merkle_levels(dst_ctx* c, const digest* leaves, digest* nodes, size_t num_leaves);

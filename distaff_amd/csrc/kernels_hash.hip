@@ -215,11 +215,11 @@ __global__ void __launch_bounds__(HASH_THREADS) fri_leaves_kernel(const fe* __re
     store_digest(leaves + r, h);
 }
 
-void k_fri_leaves(dst_ctx* c, int layer) {
-    size_t R = c->fri_size[layer] / 4;
+void k_fri_leaves_at(dst_ctx* c, const fe* e, digest* leaves, size_t R) {        // natural-order layer of 4R evaluations
     { KScope ks_(c, "fri_leaves_kernel", 96.0 * R); hipLaunchKernelGGL(fri_leaves_kernel, dim3((unsigned)((R + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream,
-                       (const fe*)c->fri_e[layer], c->fri_leaves[layer], R); }
+                       e, leaves, R); }
 }
+void k_fri_leaves(dst_ctx* c, int layer) { k_fri_leaves_at(c, c->fri_e[layer], c->fri_leaves[layer], c->fri_size[layer] / 4); }
 
 // ---- coset-sharded trees (world > 1): a rank owns leaves B*k + j for its cosets j and keeps them as local index k*Bc + jl, so the
 //      lowest log2(Bc) levels of every tree are rank-local.  `k_merkle_levels_to` builds the local heap down to `stop_count`

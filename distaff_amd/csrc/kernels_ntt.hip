@@ -719,14 +719,15 @@ void k_intt8_cosets(dst_ctx* c, fe* vals, fe* out8n, fe* work) {
                        c->itw_lo, c->itw_hi, c->tw_lo_bits, c->log_n, c->log_N, c->log_b, c->eight_inv); }
 }
 
-// ---- layout conversion (inspection only) ------------------------------------------------------------------------------------
+// ---- layout conversion (inspection; replicated FRI tail of the sharded path) ------------------------------------------------------------------------------------
 __global__ void coset_to_natural_kernel(const fe* __restrict__ src, fe* __restrict__ dst, size_t n, size_t cosets) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n * cosets) return;
     size_t k = i / cosets, j = i % cosets;
     dst[i] = src[j * n + k];
 }
-void k_coset_to_natural(dst_ctx* c, const fe* src, size_t cosets, fe* dst) {
-    size_t total = c->n * cosets;
-    { KScope ks_(c, "coset_to_natural_kernel", 32.0 * total); hipLaunchKernelGGL(coset_to_natural_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, src, dst, c->n, cosets); }
+void k_coset_to_natural_len(dst_ctx* c, const fe* src, size_t cosets, size_t len, fe* dst) {      // [cosets][len] -> natural [len * cosets]
+    size_t total = len * cosets;
+    { KScope ks_(c, "coset_to_natural_kernel", 32.0 * total); hipLaunchKernelGGL(coset_to_natural_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, c->stream, src, dst, len, cosets); }
 }
+void k_coset_to_natural(dst_ctx* c, const fe* src, size_t cosets, fe* dst) { k_coset_to_natural_len(c, src, cosets, c->n, dst); }

@@ -12,15 +12,36 @@ using namespace dsth;
 
 extern "C" void dst_internal_transition_coefficients(const dst_ctx* c, const fe* draws344, std::vector<fe>& tc);   // api.hip
 
-enum { SH_TRACE_TREE = 0, SH_CONSTRAINT_TREE = 1, SH_FRI_TREE = 2, SH_CEVAL = 3, SH_FRI_LAST = 4 };
+enum { SH_TRACE_TREE = 0, SH_CONSTRAINT_TREE = 1, SH_FRI_TREE = 2, SH_CEVAL = 3, SH_FRI_LAST = 4, SH_FRI_SEND_CAP = 5 };
 enum { RD_TRACE_LEAF = 0, RD_TRACE_NODE = 1, RD_TRACE_UPPER = 2, RD_CEVAL = 3, RD_C_NODE = 4, RD_C_UPPER = 5, RD_FRI_E = 6, RD_FRI_LEAF = 7,
        RD_FRI_NODE = 8, RD_FRI_UPPER = 9, RD_LDE_ROW = 10 };
+
+static size_t fri_nd(const dst_ctx* c, int d) { return c->fri_size[d] / c->B; }     // elements per coset in layer d
+
+// FRI across ranks.  The large layers stay sharded: coset-major evaluations, rank-local leaves and tree levels, one all-gather
+// of boundary nodes per layer.  From the first layer that is small (at most 2^17 elements, 2 MiB) or has fewer than one
+// 4-element row per coset, the ranks all-gather the layer's EVALUATIONS once and every rank finishes the commit phase on its
+// own in natural order (same kernels as the single-GPU path): no further exchanges, and no limit on the blowup factor.  The
+// remainder layer always qualifies, so the tail is never empty.
+static int fri_replicated_from(const dst_ctx* c) {
+    const char* e = getenv("DISTAFF_FRI_REPLICATE_LOG");                      // tests lower the limit to get sharded layers at small sizes
+    int log_limit = e ? atoi(e) : 17;
+    log_limit = log_limit < 0 ? 0 : (log_limit > 40 ? 40 : log_limit);
+    for (int d = 0; d < c->num_fri_layers; d++)
+        if (c->fri_size[d] <= ((size_t)1 << log_limit) || fri_nd(c, d) < 4) return d;
+    return c->num_fri_layers - 1;
+}
+static const fe* fri_layer_natural(const dst_ctx* c, int d) { return (d == 0 && c->fri_rep_from == 0) ? c->fri_nat0 : c->fri_e[d]; }
+static bool fri_layer_replicated(const dst_ctx* c, int d) { return c->sharded_layout && d >= c->fri_rep_from; }
 
 static int ensure_shard_buffers(dst_ctx* c) {
     if (c->gather_buf) return DST_OK;
     const size_t n = c->n, G = c->prm.world;
+    c->fri_rep_from = fri_replicated_from(c);
     size_t need = 32 * n * G;
     if (384 * n > need) need = 384 * n;
+    if (c->fri_size[c->fri_rep_from] * 16 > need) need = c->fri_size[c->fri_rep_from] * 16;      // the gathered evaluations of the first replicated layer
+    if (c->fri_rep_from == 0) HIP_TRY(c, hipMalloc((void**)&c->fri_nat0, c->fri_size[0] * sizeof(fe)));
     HIP_TRY(c, hipMalloc((void**)&c->gather_buf, need));
     c->gather_bytes = need;
     HIP_TRY(c, hipMalloc((void**)&c->trace_upper, 2 * n * G * sizeof(digest)));
@@ -31,8 +52,6 @@ static int ensure_shard_buffers(dst_ctx* c) {
     }
     return DST_OK;
 }
-static size_t fri_nd(const dst_ctx* c, int d) { return c->fri_size[d] / c->B; }     // elements per coset in layer d
-
 static int copy_in(dst_ctx* c, void* dst, const void* src, size_t bytes, int src_is_device) {
     if (src_is_device) k_copy(c, dst, src, bytes);
     else HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
@@ -123,9 +142,9 @@ int dst_shard_fri_layer(dst_ctx* c, int* more) {
     if (!c->composed) { c->err = "dst_shard_fri_layer: composition not built"; return DST_ERR_STATE; }
     int d = c->fri_committed;
     if (d >= c->num_fri_layers || d != c->fri_folded) { c->err = "dst_shard_fri_layer: fold the previous layer first"; return DST_ERR_STATE; }
+    if (d >= c->fri_rep_from) { c->err = "dst_shard_fri_layer: this layer is part of the replicated tail (dst_shard_fri_begin / dst_shard_fri_end)"; return DST_ERR_STATE; }
     HIP_TRY(c, hipSetDevice(c->device));
     size_t nd = fri_nd(c, d), nb = nd / 4;
-    if (nb == 0) { c->err = "dst_shard_fri_layer: layer too small for this blowup (sharded mode needs blowup <= 32)"; return DST_ERR_ARG; }
     k_fri_leaves_cm(c, c->fri_e[d], c->fri_leaves[d], nd);
     k_merkle_levels_to(c, c->fri_leaves[d], c->fri_nodes[d], nb * c->Bc, nb);
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -151,7 +170,13 @@ int dst_shard_export_size(dst_ctx* c, uint32_t what, uint32_t arg, size_t* bytes
         case SH_TRACE_TREE: case SH_CONSTRAINT_TREE: *bytes = c->n * 32; return DST_OK;
         case SH_FRI_TREE: if ((int)arg >= c->num_fri_layers) return DST_ERR_ARG; *bytes = fri_nd(c, arg) / 4 * 32; return DST_OK;
         case SH_CEVAL: *bytes = (dst_internal_boundary_by_evaluation() ? 3 : 1) * (c->Bc / (c->B / 8)) * c->n * 16; return DST_OK;   // [i, f,] t
-        case SH_FRI_LAST: *bytes = c->Bc * fri_nd(c, c->num_fri_layers - 1) * 16; return DST_OK;
+        case SH_FRI_LAST: *bytes = c->fri_size[c->num_fri_layers - 1] * 16; return DST_OK;       // the whole remainder, natural order (replicated)
+        case SH_FRI_SEND_CAP: {                                  // the largest item dst_shard_fri_begin hands out
+            const int t = fri_replicated_from(c);
+            size_t m = c->Bc * fri_nd(c, t) * 16;
+            for (int d = 0; d < t; d++) if (fri_nd(c, d) / 4 * 32 > m) m = fri_nd(c, d) / 4 * 32;
+            *bytes = m; return DST_OK;
+        }
     }
     return DST_ERR_ARG;
 }
@@ -166,7 +191,10 @@ int dst_shard_export(dst_ctx* c, uint32_t what, uint32_t arg, void* dst, int dst
         case SH_CONSTRAINT_TREE: src = c->cnodes + c->n; break;
         case SH_FRI_TREE: src = c->fri_nodes[arg] + fri_nd(c, arg) / 4; break;
         case SH_CEVAL: src = dst_internal_boundary_by_evaluation() ? c->ceval : c->ceval + 2 * (c->Bc / (c->B / 8)) * c->n; break;   // local layout [3][Q][n]
-        case SH_FRI_LAST: src = c->fri_e[c->num_fri_layers - 1]; break;
+        case SH_FRI_LAST:
+            if (c->fri_committed != c->num_fri_layers) { c->err = "dst_shard_export: FRI commit phase not finished"; return DST_ERR_STATE; }
+            src = fri_layer_natural(c, c->num_fri_layers - 1); break;
+        default: c->err = "dst_shard_export: bad item"; return DST_ERR_ARG;
     }
     return copy_out(c, dst, src, bytes, dst_is_device);
 }
@@ -223,10 +251,10 @@ int dst_shard_read(dst_ctx* c, uint32_t buffer, uint32_t arg, const uint64_t* id
         case RD_CEVAL: src = c->cevals; item = 16; break;
         case RD_C_NODE: src = c->cnodes; break;
         case RD_C_UPPER: src = c->c_upper; break;
-        case RD_FRI_E: if ((int)arg >= c->num_fri_layers) return DST_ERR_ARG; src = c->fri_e[arg]; item = 16; break;
+        case RD_FRI_E: if ((int)arg >= c->num_fri_layers) return DST_ERR_ARG; src = fri_layer_replicated(c, (int)arg) ? fri_layer_natural(c, (int)arg) : c->fri_e[arg]; item = 16; break;
         case RD_FRI_LEAF: if ((int)arg >= c->num_fri_layers) return DST_ERR_ARG; src = c->fri_leaves[arg]; break;
         case RD_FRI_NODE: if ((int)arg >= c->num_fri_layers) return DST_ERR_ARG; src = c->fri_nodes[arg]; break;
-        case RD_FRI_UPPER: if ((int)arg >= c->num_fri_layers) return DST_ERR_ARG; src = c->fri_upper[arg]; break;
+        case RD_FRI_UPPER: if ((int)arg >= c->num_fri_layers) return DST_ERR_ARG; src = fri_layer_replicated(c, (int)arg) ? c->fri_nodes[arg] : c->fri_upper[arg]; break;
         case RD_LDE_ROW: break;
         default: c->err = "dst_shard_read: unknown buffer"; return DST_ERR_ARG;
     }
@@ -254,26 +282,82 @@ int dst_shard_read(dst_ctx* c, uint32_t buffer, uint32_t arg, const uint64_t* id
 // layer follows, the Fiat-Shamir draw from that root (field::prng) and the fold.
 int dst_shard_fri_begin(dst_ctx* c, void* send, int send_is_device, size_t cap, size_t* bytes, int* more) {
     if (!c || !send || !bytes || !more) return DST_ERR_ARG;
-    int r = dst_shard_fri_layer(c, more);
+    int r = ensure_shard_buffers(c);
     if (r) return r;
+    if (c->fri_tail_pending) { c->err = "dst_shard_fri_begin: finish the pending exchange with dst_shard_fri_end first"; return DST_ERR_STATE; }
+    if (c->fri_committed == c->fri_rep_from) {
+        // first replicated layer: hand out this rank's cosets of its evaluations; dst_shard_fri_end finishes the commit phase
+        if (!c->composed) { c->err = "dst_shard_fri_begin: composition not built"; return DST_ERR_STATE; }
+        const int d = c->fri_rep_from;
+        if (d != c->fri_folded) { c->err = "dst_shard_fri_begin: fold the previous layer first"; return DST_ERR_STATE; }
+        HIP_TRY(c, hipSetDevice(c->device));
+        *bytes = c->Bc * fri_nd(c, d) * 16;
+        if (*bytes > cap) { c->err = "dst_shard_fri_begin: send buffer too small"; return DST_ERR_ARG; }
+        *more = 0;
+        c->fri_tail_pending = true;
+        return copy_out(c, send, c->fri_e[d], *bytes, send_is_device);
+    }
+    r = dst_shard_fri_layer(c, more);
+    if (r) return r;
+    *more = 1;                                                  // the replicated tail follows every sharded layer
     const uint32_t d = (uint32_t)c->fri_committed - 1;
     if ((r = dst_shard_export_size(c, SH_FRI_TREE, d, bytes))) return r;
     if (*bytes > cap) { c->err = "dst_shard_fri_begin: send buffer too small"; return DST_ERR_ARG; }
     return dst_shard_export(c, SH_FRI_TREE, d, send, send_is_device);
 }
+// commit phase of the replicated tail (fri/prover.rs:11-53 from layer d0 on): every rank on its own, natural order
+static int fri_replicated_tail(dst_ctx* c, const void* gathered, int src_is_device, uint8_t root_out[32]) {
+    const int d0 = c->fri_rep_from, L = c->num_fri_layers;
+    const size_t size0 = c->fri_size[d0];
+    int r = copy_in(c, c->gather_buf, gathered, size0 * 16, src_is_device);            // rank-major pieces = coset-major [B][nd]
+    if (r) return r;
+    fe* nat0 = d0 == 0 ? c->fri_nat0 : c->fri_e[d0];
+    k_coset_to_natural_len(c, (const fe*)c->gather_buf, c->B, fri_nd(c, d0), nat0);
+    if (c->fri_roots.size() < (size_t)L) c->fri_roots.resize(L);
+    for (int d = d0; d < L; d++) {
+        const size_t R = c->fri_size[d] / 4;
+        const fe* e = fri_layer_natural(c, d);
+        k_fri_leaves_at(c, e, c->fri_leaves[d], R);
+        k_merkle_levels(c, c->fri_leaves[d], c->fri_nodes[d], R);
+        uint8_t root[32];
+        HIP_TRY(c, hipMemcpyAsync(root, c->fri_nodes[d] + 1, 32, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipGetLastError());
+        c->fri_roots[d].assign(root, root + 32);
+        if (d == d0 && root_out) memcpy(root_out, root, 32);
+        if (d + 1 < L) {
+            fe x;
+            prng_vector(root, 1, &x);                          // fri/prover.rs:40 field::prng(root)
+            k_fri_fold_at(c, e, c->fri_e[d + 1], R, d, x);
+        }
+    }
+    c->fri_committed = L; c->fri_folded = L - 1;
+    c->fri_tail_pending = false;
+    return DST_OK;
+}
 int dst_shard_fri_end(dst_ctx* c, const void* gathered, int src_is_device, uint8_t root_out[32]) {
     if (!c || !gathered || !root_out) return DST_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (c->fri_tail_pending) return fri_replicated_tail(c, gathered, src_is_device, root_out);
     if (c->fri_committed == 0) { c->err = "dst_shard_fri_end: no layer in flight"; return DST_ERR_STATE; }
     const uint32_t d = (uint32_t)c->fri_committed - 1;
     int r = dst_shard_import(c, SH_FRI_TREE, d, gathered, src_is_device, root_out);
     if (r) return r;
-    if ((int)d + 1 < c->num_fri_layers) {
-        fe x;
-        prng_vector(root_out, 1, &x);                          // fri/prover.rs:40 field::prng(root)
-        uint8_t xb[16]; memcpy(xb, &x, 16);
-        r = dst_shard_fri_fold(c, xb);
-    }
-    return r;
+    fe x;
+    prng_vector(root_out, 1, &x);                              // fri/prover.rs:40 field::prng(root)
+    uint8_t xb[16]; memcpy(xb, &x, 16);
+    return dst_shard_fri_fold(c, xb);                          // a sharded layer is never the last one
+}
+// roots of all FRI layers once the commit phase is over (the layers of the replicated tail are committed inside dst_shard_fri_end)
+int dst_shard_fri_roots(dst_ctx* c, uint8_t* roots, size_t cap, uint32_t* num_layers, uint32_t* replicated_from) {
+    if (!c || !num_layers) return DST_ERR_ARG;
+    *num_layers = (uint32_t)c->num_fri_layers;
+    if (replicated_from) *replicated_from = (uint32_t)fri_replicated_from(c);
+    if (!roots) return DST_OK;
+    if (c->fri_committed != c->num_fri_layers || (int)c->fri_roots.size() < c->num_fri_layers) { c->err = "dst_shard_fri_roots: FRI commit phase not finished"; return DST_ERR_STATE; }
+    if (cap < (size_t)32 * c->num_fri_layers) { c->err = "dst_shard_fri_roots: buffer too small"; return DST_ERR_ARG; }
+    for (int d = 0; d < c->num_fri_layers; d++) memcpy(roots + 32 * d, c->fri_roots[d].data(), 32);
+    return DST_OK;
 }
 
 // ---- step 9 across ranks -------------------------------------------------------------------------------------------------------------
@@ -306,6 +390,7 @@ void plan_item(OpenPlan& p, int owner, uint32_t buffer, uint32_t arg, uint64_t i
 // element at natural position pos of a coset-major [B][nd] array
 void plan_element(const dst_ctx* c, OpenPlan& p, uint32_t buffer, uint32_t arg, uint64_t pos, uint64_t nd) {
     if (buffer == RD_FRI_E && arg > 0 && !c->sharded_layout) { plan_item(p, 0, buffer, arg, pos, 16); return; }     // single-GPU phases keep layers >= 1 in natural order
+    if (buffer == RD_FRI_E && fri_layer_replicated(c, (int)arg)) { plan_item(p, -1, buffer, arg, pos, 16); return; }   // replicated tail of the sharded phases: natural order, served by rank 0
     uint64_t k = pos / c->B, j = pos % c->B, g = j / c->Bc;
     plan_item(p, (int)g, buffer, arg, (j - g * c->Bc) * nd + k, 16);
 }
@@ -361,7 +446,7 @@ int build_open_plan(dst_ctx* c, const uint64_t* positions_in, uint32_t num_posit
         w.raw(c->fri_roots[d].data(), 32);
         w.u64(pos.size());
         for (uint64_t r : pos) for (uint64_t s4 = 0; s4 < 4; s4++) plan_element(c, p, RD_FRI_E, (uint32_t)d, r + s4 * R, nd);
-        plan_tree_nodes(c, p, fp, Geometry(R, B, G), RD_FRI_LEAF, RD_FRI_NODE, RD_FRI_UPPER, (uint32_t)d, false);
+        plan_tree_nodes(c, p, fp, Geometry(R, B, fri_layer_replicated(c, d) ? 1 : G), RD_FRI_LEAF, RD_FRI_NODE, RD_FRI_UPPER, (uint32_t)d, false);
         w.u8(fp.depth);
     }
     w.raw(c->fri_roots[L - 1].data(), 32);
@@ -381,10 +466,10 @@ const void* read_source(dst_ctx* c, uint32_t buffer, uint32_t arg) {
         case RD_CEVAL: return c->cevals;
         case RD_C_NODE: return c->cnodes;
         case RD_C_UPPER: return c->sharded_layout ? c->c_upper : c->cnodes;
-        case RD_FRI_E: return (int)arg < c->num_fri_layers ? c->fri_e[arg] : nullptr;
+        case RD_FRI_E: return (int)arg < c->num_fri_layers ? (fri_layer_replicated(c, (int)arg) ? (const void*)fri_layer_natural(c, (int)arg) : (const void*)c->fri_e[arg]) : nullptr;
         case RD_FRI_LEAF: return (int)arg < c->num_fri_layers ? c->fri_leaves[arg] : nullptr;
         case RD_FRI_NODE: return (int)arg < c->num_fri_layers ? c->fri_nodes[arg] : nullptr;
-        case RD_FRI_UPPER: return (int)arg < c->num_fri_layers ? (c->sharded_layout ? c->fri_upper[arg] : c->fri_nodes[arg]) : nullptr;
+        case RD_FRI_UPPER: return (int)arg < c->num_fri_layers ? (c->sharded_layout && !fri_layer_replicated(c, (int)arg) ? c->fri_upper[arg] : c->fri_nodes[arg]) : nullptr;
     }
     return nullptr;
 }

@@ -23,7 +23,7 @@ EXPORTS = ["dst_ctx_create", "dst_ctx_destroy", "dst_last_error", "dst_phase_ms"
            "dst_build_proof", "dst_prove", "dst_prng_vector", "dst_query_positions", "dst_blake3", "dst_fibonacci_trace",
            "dst_read_buffer", "dst_bench_mulmod", "dst_set_profiling", "dst_kernel_stats", "dst_field_op",
            "dst_shard_commit_trace", "dst_shard_eval_constraints", "dst_shard_combine", "dst_shard_fri_layer", "dst_shard_fri_fold",
-           "dst_shard_export_size", "dst_shard_export", "dst_shard_import", "dst_shard_read", "dst_shard_fri_begin", "dst_shard_fri_end", "dst_shard_open", "dst_shard_assemble", "dst_shard_info"]
+           "dst_shard_export_size", "dst_shard_export", "dst_shard_import", "dst_shard_read", "dst_shard_fri_begin", "dst_shard_fri_end", "dst_shard_fri_roots", "dst_shard_open", "dst_shard_assemble", "dst_shard_info"]
 
 
 class DistaffError(RuntimeError):
@@ -301,6 +301,14 @@ class Context:
         root = ctypes.create_string_buffer(32)
         self._check(self.lib.dst_shard_fri_end(self._h, ctypes.c_void_p(gathered_ptr), ctypes.c_int(1 if is_device else 0), root))
         return root.raw
+
+    def shard_fri_roots(self):
+        """-> (roots of all FRI layers after the commit phase, first layer of the replicated tail)"""
+        layers, rep = ctypes.c_uint32(0), ctypes.c_uint32(0)
+        self._check(self.lib.dst_shard_fri_roots(self._h, None, ctypes.c_size_t(0), ctypes.byref(layers), ctypes.byref(rep)))
+        buf = ctypes.create_string_buffer(32 * layers.value)
+        self._check(self.lib.dst_shard_fri_roots(self._h, buf, ctypes.c_size_t(32 * layers.value), ctypes.byref(layers), ctypes.byref(rep)))
+        return [buf.raw[32 * d:32 * d + 32] for d in range(layers.value)], rep.value
 
     def shard_open(self, positions):
         """-> (this rank's blob of openings, [blob length of every rank])"""

@@ -4,6 +4,8 @@ Rank g of G owns the cosets [g*B/G, (g+1)*B/G) of every low-degree extension (DE
 ``stark::prove`` (/root/reference/src/stark/prover.rs:17-168) the ranks exchange
   * the boundary nodes of each Merkle tree (the level at which a node's leaves stop being rank-local) -- all-gather,
   * the combined constraint evaluations before the cross-coset inverse transform -- all-gather,
+  * the evaluations of the first small FRI layer (<= 2^17 elements), after which every rank finishes the FRI commit phase on its
+    own (replicated tail) -- all-gather,
   * the handful of leaves / nodes / rows that the query openings need -- small object gathers,
 and every rank derives the same Fiat-Shamir challenges from the same roots.  There is no all-reduce.
 
@@ -19,7 +21,7 @@ import numpy as np
 
 from . import lib as L
 
-SH_TRACE_TREE, SH_CONSTRAINT_TREE, SH_FRI_TREE, SH_CEVAL, SH_FRI_LAST = 0, 1, 2, 3, 4
+SH_TRACE_TREE, SH_CONSTRAINT_TREE, SH_FRI_TREE, SH_CEVAL, SH_FRI_LAST, SH_FRI_SEND_CAP = 0, 1, 2, 3, 4, 5
 RD_TRACE_LEAF, RD_TRACE_NODE, RD_TRACE_UPPER, RD_CEVAL, RD_C_NODE, RD_C_UPPER, RD_FRI_E, RD_FRI_LEAF, RD_FRI_NODE, RD_FRI_UPPER, RD_LDE_ROW = range(11)
 
 
@@ -278,9 +280,9 @@ class ShardedProver:
         draws = L.prng_vector(constraint_root, 516)
         z1, z2 = ctx.compose(draws)
         self._mark("deep_composition")
-        # step 7: per layer two library calls around one all-gather (leaves + local levels + export | import + draw + fold)
-        fri_roots = []
-        cap = ctx.shard_export_size(SH_FRI_TREE, 0)                    # layer 0 has the most boundary nodes
+        # step 7: per exchange two library calls around one all-gather.  Sharded layers: leaves + local levels + export of the
+        # boundary nodes | upper tree + draw + fold; then once the evaluations of the first small layer | the rest of the commit phase
+        cap = ctx.shard_export_size(SH_FRI_SEND_CAP, 0)
         device_path = getattr(comm, "device_path", False)
         if device_path:
             torch = comm.torch
@@ -294,14 +296,14 @@ class ShardedProver:
                 out = recv_t[:size * G]
                 comm.dist.all_gather_into_tensor(out, send_t[:size])
                 torch.cuda.synchronize(comm.device)
-                root = ctx.shard_fri_end(out.data_ptr(), True)
+                ctx.shard_fri_end(out.data_ptr(), True)
             else:
                 size, more = ctx.shard_fri_begin(send_h.ctypes.data, False, cap)
                 gathered = np.ascontiguousarray(comm.all_gather(send_h[:size]))
-                root = ctx.shard_fri_end(gathered.ctypes.data, False)
-            fri_roots.append(root)
+                ctx.shard_fri_end(gathered.ctypes.data, False)
             if not more:
                 break
+        fri_roots, rep_from = ctx.shard_fri_roots()
         layers = len(fri_roots)
         self._mark("fri")
         # step 8
@@ -354,14 +356,18 @@ class ShardedProver:
             R, nd = size // 4, size // B
             pos = augmented_positions(pos, size)
             fvals, fnodes, fdepth = plan_batch(pos, R)
-            h_vals = ask([(g, RD_FRI_E, dd, li) for r in pos for s in range(4) for g, li in (self._element_request(r + s * R, nd),)])
-            fgeom = TreeGeometry(R, B, G)
+            if dd >= rep_from:          # replicated tail: natural order and full heaps on every rank, rank 0 serves
+                h_vals = ask([(None, RD_FRI_E, dd, r + s * R) for r in pos for s in range(4)])
+                fgeom = TreeGeometry(R, B, 1)
+            else:
+                h_vals = ask([(g, RD_FRI_E, dd, li) for r in pos for s in range(4) for g, li in (self._element_request(r + s * R, nd),)])
+                fgeom = TreeGeometry(R, B, G)
             h_nodes = ask(self._tree_requests(fgeom, [r for lst in fnodes for r in lst], RD_FRI_LEAF, RD_FRI_NODE, RD_FRI_UPPER, dd))
             fri_plan.append((len(pos), h_vals, fnodes, h_nodes, fdepth))
             size //= 4
-        last = np.empty(ctx.shard_export_size(SH_FRI_LAST, 0), dtype=np.uint8)     # this rank's cosets of the remainder
+        last = np.empty(ctx.shard_export_size(SH_FRI_LAST, 0), dtype=np.uint8)     # the remainder (replicated, natural order)
         ctx.shard_export(SH_FRI_LAST, 0, last.ctypes.data, False)
-        got, lasts = self._fetch(reqs, last.tobytes())
+        got, _ = self._fetch(reqs)
 
         def take(h):
             return got[h[0]:h[0] + h[1]]
@@ -390,9 +396,7 @@ class ShardedProver:
             self._write_nodes(w, fnodes, take(h_nodes))
             w.u8(fdepth)
         w.raw(fri_roots[-1])
-        nl = size // B                                         # remainder: natural order from the ranks' coset-major pieces
-        pieces = np.frombuffer(b"".join(lasts), dtype=np.uint64).reshape(G * self.Bc, nl, 2)       # [B][nl]
-        w.u64(size); w.raw(np.ascontiguousarray(pieces.transpose(1, 0, 2)).tobytes())
+        w.u64(size); w.raw(last.tobytes())
         w.u64(nonce)
         w.u8(p.log_blowup); w.u8(p.num_queries); w.u8(p.grinding_factor); w.u8(0)
         self._mark("openings")

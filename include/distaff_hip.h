@@ -110,8 +110,9 @@ int dst_fibonacci_trace(uint32_t log_n, uint8_t* cols, uint8_t program_hash[32],
 
 /* ---- coset-sharded proving on several GPUs (one context per GPU, params.rank / params.world) ----------
  * The phases mirror the single-GPU ones; collectives are issued by the host between them.  `what`: 0 trace-tree boundary
- * nodes, 1 constraint-tree boundary nodes, 2 FRI-tree boundary nodes of layer `arg`, 3 combined constraint evaluations,
- * 4 last FRI layer (remainder).  dst_shard_import takes the all-gathered items of all ranks (rank-major); for trees it
+ * nodes, 1 constraint-tree boundary nodes, 2 FRI-tree boundary nodes of (sharded) layer `arg`, 3 combined constraint evaluations,
+ * 4 last FRI layer (remainder: all of it, natural order, after the commit phase), 5 size query only: the largest item
+ * dst_shard_fri_begin hands out.  dst_shard_import takes the all-gathered items of all ranks (rank-major); for trees it
  * finishes the replicated upper levels and returns the root.  *_is_device: the pointer is device memory (possibly owned
  * by another HIP runtime instance in the process, e.g. a torch tensor) instead of host memory. */
 int dst_shard_commit_trace(dst_ctx* ctx);
@@ -126,11 +127,15 @@ int dst_shard_import(dst_ctx* ctx, uint32_t what, uint32_t arg, const void* src,
  * evaluations (elements), 4 constraint local nodes, 5 constraint upper nodes, 6 FRI layer `arg` evaluations (elements), 7 FRI leaves,
  * 8 FRI local nodes, 9 FRI upper nodes, 10 LDE rows (idx = natural positions owned by this rank, W elements each). */
 int dst_shard_read(dst_ctx* ctx, uint32_t buffer, uint32_t arg, const uint64_t* idx, uint32_t count, uint8_t* out);
-/* One FRI layer (fri/prover.rs:11-53) around its all-gather in two calls: dst_shard_fri_begin = dst_shard_fri_layer + export of the
- * boundary nodes into `send` (*bytes of them, per rank); dst_shard_fri_end = import of the gathered nodes (layer root) and, when
- * another layer follows, the fold at field::prng(root). */
+/* The FRI commit phase (fri/prover.rs:11-53): call dst_shard_fri_begin, all-gather the *bytes it wrote into `send` (same size
+ * on every rank), call dst_shard_fri_end with the gathered bytes (rank-major); repeat while *more.  Large layers stay sharded:
+ * begin = leaves + rank-local tree levels + export of the boundary nodes, end = upper tree, root, fold at field::prng(root).
+ * From the first layer of at most 2^17 elements (or with fewer than one 4-element row per coset) begin hands out the rank's
+ * cosets of the layer's EVALUATIONS instead (*more = 0) and end commits that layer and all following ones on every rank by
+ * itself (replicated tail: no further exchanges).  dst_shard_fri_roots then returns the roots of all layers. */
 int dst_shard_fri_begin(dst_ctx* ctx, void* send, int send_is_device, size_t cap, size_t* bytes, int* more);
 int dst_shard_fri_end(dst_ctx* ctx, const void* gathered, int src_is_device, uint8_t root_out[32]);
+int dst_shard_fri_roots(dst_ctx* ctx, uint8_t* roots /* 32 per layer, or NULL */, size_t cap, uint32_t* num_layers, uint32_t* replicated_from);
 
 /* Step 9 across ranks (prover.rs:143-165; merkle.rs:64-124 prove_batch; fri/prover.rs:55-96 build_proof).  Every rank derives the
  * same ordered list of openings from the query positions.  dst_shard_open returns the items THIS rank owns, concatenated in that

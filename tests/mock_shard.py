@@ -49,7 +49,7 @@ class _Tree:
 
 
 class MockShardContext:
-    def __init__(self, oracle, prover, trace, rank, world, log_blowup=5, num_queries=50, grinding=20):
+    def __init__(self, oracle, prover, trace, rank, world, log_blowup=5, num_queries=50, grinding=20, replicate_log=17):
         O, p = oracle, prover
         self.O, self.p = O, p
         self.B, self.n, self.W = 1 << log_blowup, trace.length, trace.columns.shape[0]
@@ -79,7 +79,13 @@ class MockShardContext:
         self.trace_root, self.constraint_root = roots[:32], roots[32:]
         fr = p.get_bytes("fri_roots")
         self.fri_roots = [fr[32 * d:32 * d + 32] for d in range(self.layers)]
+        # layers >= rep_from are replicated: natural order, full heaps on every rank (shard.hip fri_replicated_from)
+        sizes = [4 * rows.shape[0] for rows in self.fri_rows]
+        self.rep_from = next(d for d in range(self.layers) if sizes[d] <= (1 << replicate_log) or sizes[d] // B < 4 or d == self.layers - 1)
+        for d in range(self.rep_from, self.layers):
+            self.fri_tree[d] = _Tree(self.fri_tree[d].heap, self.fri_tree[d].leaves, B, 1)
         self.fri_d = 0
+        self.tail_pending = False
         self.calls = []
 
     # -- layouts
@@ -101,10 +107,13 @@ class MockShardContext:
             q = np.arange(g * Q, (g + 1) * Q)[:, None]
             k = np.arange(n)[None, :]
             return np.ascontiguousarray(self.t_evals[8 * k + q]).tobytes()
-        if what == S.SH_FRI_LAST:                                                # remainder, coset-major [Bc][nl]
+        if what == S.SH_FRI_LAST:                                                # the whole remainder in natural order (replicated)
             d = self.layers - 1
-            nl = self.fri_rows[d].shape[0] * 4 // B
-            return b"".join(self._fri_element(d, B * k + g * Bc + jl) for jl in range(Bc) for k in range(nl))
+            return b"".join(self._fri_element(d, i) for i in range(4 * self.fri_rows[d].shape[0]))
+        if what == "fri_tail":                                                   # rank g's cosets of the first replicated layer, [Bc][nd]
+            d = self.rep_from
+            nd = self.fri_rows[d].shape[0] * 4 // B
+            return b"".join(self._fri_element(d, B * k + g * Bc + jl) for jl in range(Bc) for k in range(nd))
         raise AssertionError("unknown export %r" % what)
 
     # -- the calls ShardedProver makes
@@ -112,6 +121,8 @@ class MockShardContext:
         self.calls.append("commit_trace")
 
     def shard_export_size(self, what, arg=0):
+        if what == S.SH_FRI_SEND_CAP:
+            return max([len(self._export("fri_tail", 0, self.g))] + [len(self._export(S.SH_FRI_TREE, d, self.g)) for d in range(self.rep_from)])
         return len(self._export(what, arg, self.g))
 
     def shard_export(self, what, arg, dst_ptr, is_device):
@@ -140,16 +151,33 @@ class MockShardContext:
         return self.p.get("trace_at_z1").copy(), self.p.get("trace_at_z2").copy()
 
     def shard_fri_begin(self, send_ptr, is_device, cap):
-        assert not is_device
-        data = self._export(S.SH_FRI_TREE, self.fri_d, self.g)
-        assert len(data) <= cap
+        assert not is_device and not self.tail_pending
+        if self.fri_d == self.rep_from:
+            data, more = self._export("fri_tail", 0, self.g), False
+            self.tail_pending = True
+        else:
+            assert self.fri_d < self.rep_from
+            data, more = self._export(S.SH_FRI_TREE, self.fri_d, self.g), True
+        assert len(data) <= cap, "send buffer smaller than the item (SH_FRI_SEND_CAP)"
         ctypes.memmove(send_ptr, data, len(data))
-        return len(data), self.fri_d + 1 < self.layers
+        return len(data), more
 
     def shard_fri_end(self, gathered_ptr, is_device):
+        assert not is_device
+        if self.tail_pending:
+            expect = b"".join(self._export("fri_tail", 0, g) for g in range(self.G))
+            assert ctypes.string_at(gathered_ptr, len(expect)) == expect, "all-gather of the first replicated FRI layer is not the ranks' pieces in rank order"
+            self.tail_pending = False
+            root = self.fri_roots[self.rep_from]
+            self.fri_d = self.layers
+            return root
         root = self.shard_import(S.SH_FRI_TREE, self.fri_d, gathered_ptr, is_device)
         self.fri_d += 1
         return root
+
+    def shard_fri_roots(self):
+        assert self.fri_d == self.layers, "FRI commit phase not finished"
+        return list(self.fri_roots), self.rep_from
 
     def pow_grind(self, seed, grinding):
         seeds = self.p.get_bytes("query_seeds")
@@ -177,15 +205,17 @@ class MockShardContext:
                 out.append(self.c_tree.local_node(g, i))
             elif buffer == S.RD_C_UPPER:
                 out.append(self.c_tree.heap[i])
+            elif buffer == S.RD_FRI_E and arg >= self.rep_from:                   # replicated layer: natural order
+                out.append(self._fri_element(arg, i))
             elif buffer == S.RD_FRI_E:                                           # coset-major [Bc][nd]
                 nd = self.fri_rows[arg].shape[0] * 4 // B
                 jl, k = divmod(i, nd)
                 out.append(self._fri_element(arg, B * k + g * Bc + jl))
             elif buffer == S.RD_FRI_LEAF:
                 t = self.fri_tree[arg]
-                out.append(t.leaves[t.global_leaf(g, i)])
+                out.append(t.leaves[t.global_leaf(0 if arg >= self.rep_from else g, i)])
             elif buffer == S.RD_FRI_NODE:
-                out.append(self.fri_tree[arg].local_node(g, i))
+                out.append(self.fri_tree[arg].local_node(0 if arg >= self.rep_from else g, i))
             elif buffer == S.RD_FRI_UPPER:
                 out.append(self.fri_tree[arg].heap[i])
             elif buffer == S.RD_LDE_ROW:                                         # natural position owned by this rank

@@ -243,21 +243,27 @@ def test_device_field_arithmetic(oracle):
 
 
 @pytest.mark.parametrize("world", [2, 4, 8])
-def test_sharded_prover_equals_single_gpu(oracle, world):
-    """Coset-sharded proving (distaff_amd/sharded.py) with `world` ranks as threads on one GPU: every rank returns the oracle's proof."""
+def test_sharded_prover_equals_single_gpu(oracle, monkeypatch, world):
+    """Coset-sharded proving (distaff_amd/sharded.py) with `world` ranks as threads on one GPU: every rank returns the oracle's proof.
+    At these sizes the whole FRI commit phase is in the replicated tail (layers of <= 2^17 elements); lowering the limit makes the
+    first one to three layers sharded (coset-major, boundary-node exchanges), which is what a 2^20-step proof does with four."""
     import distaff_amd as D
     from distaff_amd import sharded
     O = oracle
-    for log_n, log_b, nq in ((8, 5, 50), (10, 5, 50), (8, 4, 100)):
+    for log_n, log_b, nq, replicate_log in ((8, 5, 50, None), (10, 5, 50, None), (8, 4, 100, None), (10, 5, 50, 9), (10, 5, 50, 13), (8, 6, 60, 10), (7, 7, 40, 0)):
         if world > min(8, (1 << log_b) // 4):
             continue
+        if replicate_log is None:
+            monkeypatch.delenv("DISTAFF_FRI_REPLICATE_LOG", raising=False)
+        else:
+            monkeypatch.setenv("DISTAFF_FRI_REPLICATE_LOG", str(replicate_log))
         t = O.fibonacci_trace(1 << log_n)
         op = O.Prover.from_trace(t, 1, ext=1 << log_b, num_queries=nq, grinding=10)
         expected = op.prove()
         for python_openings in (False, True):                 # openings planned behind the C-ABI / by the Python statement of the plan
             proofs = sharded.prove_local(t.columns, log_n, t.width, t.ctx_depth, t.loop_depth, t.public_inputs, op.outputs, world,
                                          python_openings=python_openings, log_blowup=log_b, num_queries=nq, grinding=10)
-            assert all(p == expected for p in proofs), (world, log_n, log_b, python_openings)
+            assert all(p == expected for p in proofs), (world, log_n, log_b, replicate_log, python_openings)
 
 
 def test_sharded_prover_reports_invalid_trace(oracle):

@@ -188,8 +188,9 @@ def test_sharded_orchestration_reproduces_the_oracle_proof(oracle, world):
     t = O.fibonacci_trace(128)
     p = O.Prover.from_trace(t, 1, grinding=8)
     proof = p.prove()
-    results = _mock_world(O, world, t, p, LocalComm.create(world), grinding=8)
-    assert all(r == proof for r in results)
+    for replicate_log in (17, 10, 8):        # FRI: everything in the replicated tail | one | two sharded layers before it
+        results = _mock_world(O, world, t, p, LocalComm.create(world), grinding=8, replicate_log=replicate_log)
+        assert all(r == proof for r in results), replicate_log
     assert O.verify(results[-1], t.program_hash, t.public_inputs, p.outputs) == (True, "")
 
 
@@ -201,7 +202,7 @@ def test_sharded_orchestration_other_options_and_program(oracle):
     p = O.Prover.from_trace(t, 1, ext=16, num_queries=100, grinding=10)          # config 5's options at a small size
     proof = p.prove()
     for world in (2, 4):
-        assert all(r == proof for r in _mock_world(O, world, t, p, LocalComm.create(world), log_blowup=4, num_queries=100, grinding=10))
+        assert all(r == proof for r in _mock_world(O, world, t, p, LocalComm.create(world), log_blowup=4, num_queries=100, grinding=10, replicate_log=9))
     t = O.Trace("begin add block push.5 mul push.7 end end", [1, 2])             # context register, two outputs
     p = O.Prover.from_trace(t, 2, grinding=8)
     proof = p.prove()
@@ -238,7 +239,7 @@ comm = TorchComm(dist)
 t = O.fibonacci_trace(128)
 p = O.Prover.from_trace(t, 1, grinding=8)
 proof = p.prove()
-ctx = MockShardContext(O, p, t, comm.rank, comm.world, grinding=8)
+ctx = MockShardContext(O, p, t, comm.rank, comm.world, grinding=8, replicate_log=8)      # two sharded FRI layers, then the replicated tail
 prover = ShardedProver(ctx, comm, python_openings=True)
 got = prover.prove(t.public_inputs, p.outputs)
 assert got == proof, "rank %%d: proof differs from the oracle's" %% comm.rank
