@@ -276,9 +276,11 @@ def test_sharded_prover_reports_invalid_trace(oracle):
         sharded.prove_local(cols, 8, t.width, t.ctx_depth, t.loop_depth, [1, 0], [1], 2, grinding=8)
 
 
-def test_sharded_prover_over_torch_distributed_world1(oracle):
+def test_sharded_prover_over_torch_distributed_world1(oracle, monkeypatch):
     """The torch.distributed (RCCL) transport of the sharded prover on one GPU, both shard-transfer modes: staged through the host and
-    directly between libdistaff_hip.so's buffers and torch tensors on the device."""
+    directly between libdistaff_hip.so's buffers and torch tensors on the device; with the FRI limit lowered so that two layers go
+    through the boundary-node exchange before the replicated tail."""
+    monkeypatch.setenv("DISTAFF_FRI_REPLICATE_LOG", "9")
     import socket
     import torch
     import torch.distributed as dist
