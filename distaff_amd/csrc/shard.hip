@@ -172,7 +172,7 @@ int dst_shard_export_size(dst_ctx* c, uint32_t what, uint32_t arg, size_t* bytes
         case SH_CEVAL: *bytes = (dst_internal_boundary_by_evaluation() ? 3 : 1) * (c->Bc / (c->B / 8)) * c->n * 16; return DST_OK;   // [i, f,] t
         case SH_FRI_LAST: *bytes = c->fri_size[c->num_fri_layers - 1] * 16; return DST_OK;       // the whole remainder, natural order (replicated)
         case SH_FRI_SEND_CAP: {                                  // the largest item dst_shard_fri_begin hands out
-            const int t = fri_replicated_from(c);
+            const int t = c->gather_buf ? c->fri_rep_from : fri_replicated_from(c);    // fixed once the shard buffers exist
             size_t m = c->Bc * fri_nd(c, t) * 16;
             for (int d = 0; d < t; d++) if (fri_nd(c, d) / 4 * 32 > m) m = fri_nd(c, d) / 4 * 32;
             *bytes = m; return DST_OK;
@@ -352,7 +352,7 @@ int dst_shard_fri_end(dst_ctx* c, const void* gathered, int src_is_device, uint8
 int dst_shard_fri_roots(dst_ctx* c, uint8_t* roots, size_t cap, uint32_t* num_layers, uint32_t* replicated_from) {
     if (!c || !num_layers) return DST_ERR_ARG;
     *num_layers = (uint32_t)c->num_fri_layers;
-    if (replicated_from) *replicated_from = (uint32_t)fri_replicated_from(c);
+    if (replicated_from) *replicated_from = (uint32_t)(c->gather_buf ? c->fri_rep_from : fri_replicated_from(c));
     if (!roots) return DST_OK;
     if (c->fri_committed != c->num_fri_layers || (int)c->fri_roots.size() < c->num_fri_layers) { c->err = "dst_shard_fri_roots: FRI commit phase not finished"; return DST_ERR_STATE; }
     if (cap < (size_t)32 * c->num_fri_layers) { c->err = "dst_shard_fri_roots: buffer too small"; return DST_ERR_ARG; }
