@@ -94,9 +94,9 @@ static int ctx_init(dst_ctx* c) {
     if (p.ctx_depth > 16 || p.loop_depth > 8) { c->err = "context / loop depth out of range"; return DST_ERR_ARG; }
     if (p.width >= 128 || p.width <= 15 + p.ctx_depth + p.loop_depth) { c->err = "register count out of range"; return DST_ERR_ARG; }
     if (p.num_queries == 0 || p.num_queries > 128 || p.grinding_factor > 32) { c->err = "invalid proof options"; return DST_ERR_ARG; }
-    if (p.world == 0 || p.rank >= p.world || (p.world & (p.world - 1)) || p.world > 8 || p.world > (1u << p.log_blowup) / 4) {
-        // a rank needs >= 1 of the 8 evaluation cosets and >= 4 LDE cosets (two constraint-tree leaves per row)
-        c->err = "invalid rank / world: world must be a power of two <= min(8, blowup / 4)"; return DST_ERR_ARG;
+    if (p.world == 0 || p.rank >= p.world || (p.world & (p.world - 1)) || p.world > 8 || p.world > (1u << p.log_blowup) / 2) {
+        // a rank needs >= 1 of the 8 evaluation cosets and >= 2 LDE cosets (one constraint-tree leaf = a pair of neighbouring cosets)
+        c->err = "invalid rank / world: world must be a power of two <= min(8, blowup / 2)"; return DST_ERR_ARG;
     }
     if (p.log_trace_length + p.log_blowup > 40) { c->err = "LDE domain exceeds 2^40"; return DST_ERR_ARG; }
     c->log_n = p.log_trace_length; c->log_b = p.log_blowup; c->log_N = c->log_n + c->log_b;

@@ -128,8 +128,10 @@ int dst_shard_combine(dst_ctx* c) {
     k_add(c, c->cpoly, ip, D);
     k_add(c, c->cpoly, fp, D);
     k_lde_fold8(c, c->cpoly, c->cevals);
-    k_constraint_level1(c);
-    k_merkle_local_levels(c, c->cnodes, c->Bc * n / 4, n);
+    if (c->Bc >= 4) {                                   // with two cosets per rank the leaves themselves are the boundary (see dst_shard_export)
+        k_constraint_level1(c);
+        k_merkle_local_levels(c, c->cnodes, c->Bc * n / 4, n);
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     c->constraints_done = true; c->composed = false;
@@ -195,6 +197,13 @@ int dst_shard_export(dst_ctx* c, uint32_t what, uint32_t arg, void* dst, int dst
             if (c->fri_committed != c->num_fri_layers) { c->err = "dst_shard_export: FRI commit phase not finished"; return DST_ERR_STATE; }
             src = fri_layer_natural(c, c->num_fri_layers - 1); break;
         default: c->err = "dst_shard_export: bad item"; return DST_ERR_ARG;
+    }
+    if (what == SH_CONSTRAINT_TREE && c->Bc == 2) {
+        // two cosets per rank: a rank holds exactly one constraint-tree leaf per k, the raw pair (C(x_{B k + 2g}), C(x_{B k + 2g + 1}))
+        // (prover.rs:180-187), and no node below the replicated part: the "boundary nodes" are the leaves, interleaved from the
+        // coset-major evaluations [2][n]
+        k_coset_to_natural_len(c, c->cevals, 2, c->n, (fe*)c->cnodes);      // [2][n] elements -> n pairs; the local heap is unused in this case
+        return copy_out(c, dst, c->cnodes, bytes, dst_is_device);
     }
     return copy_out(c, dst, src, bytes, dst_is_device);
 }

@@ -45,7 +45,7 @@ typedef struct dst_params {
     uint32_t grinding_factor;    /* <= 32 (options.rs:46) */
     int32_t  device;             /* HIP device ordinal */
     /* multi-GPU sharding of the LDE domain by cosets (DESIGN.md "Multi-GPU"): this context owns cosets
-       [rank * B / world, (rank + 1) * B / world); world = 1 means the whole job. */
+       [rank * B / world, (rank + 1) * B / world); world = 1 means the whole job; world is a power of two <= min(8, B / 2). */
     uint32_t rank, world;
 } dst_params;
 

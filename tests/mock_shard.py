@@ -33,6 +33,8 @@ class _Tree:
     def boundary(self, g):
         """the nodes whose leaves are exactly rank g's columns of one row k: level with K*G nodes, offset G*k + g"""
         level = self.K * self.G
+        if level == self.L:              # one leaf column per rank (constraint tree, two cosets per rank): the leaves are the boundary
+            return b"".join(self.leaves[self.G * k + g] for k in range(self.K))
         return b"".join(self.heap[level + self.G * k + g] for k in range(self.K))
 
     def global_leaf(self, g, local):

@@ -251,7 +251,7 @@ def test_sharded_prover_equals_single_gpu(oracle, monkeypatch, world):
     from distaff_amd import sharded
     O = oracle
     for log_n, log_b, nq, replicate_log in ((8, 5, 50, None), (10, 5, 50, None), (8, 4, 100, None), (10, 5, 50, 9), (10, 5, 50, 13), (8, 6, 60, 10), (7, 7, 40, 0)):
-        if world > min(8, (1 << log_b) // 4):
+        if world > min(8, (1 << log_b) // 2):              # two cosets per rank is the minimum (blowup 16 on 8 ranks: BASELINE config 5's shape)
             continue
         if replicate_log is None:
             monkeypatch.delenv("DISTAFF_FRI_REPLICATE_LOG", raising=False)

@@ -201,7 +201,7 @@ def test_sharded_orchestration_other_options_and_program(oracle):
     t = O.fibonacci_trace(256)
     p = O.Prover.from_trace(t, 1, ext=16, num_queries=100, grinding=10)          # config 5's options at a small size
     proof = p.prove()
-    for world in (2, 4):
+    for world in (2, 4, 8):                  # 8 ranks at blowup 16: two cosets per rank, the constraint tree's boundary is its leaf level
         assert all(r == proof for r in _mock_world(O, world, t, p, LocalComm.create(world), log_blowup=4, num_queries=100, grinding=10, replicate_log=9))
     t = O.Trace("begin add block push.5 mul push.7 end end", [1, 2])             # context register, two outputs
     p = O.Prover.from_trace(t, 2, grinding=8)
