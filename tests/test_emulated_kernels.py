@@ -31,6 +31,7 @@ SELECTION = [
     "test_sharded_prover_equals_single_gpu[2]",
     "test_sharded_prover_equals_single_gpu[8]",
     "test_sharded_prover_reports_invalid_trace",
+    "test_sharded_fri_protocol_state_errors",
     "test_deep_stacks_and_nested_blocks[]",
     "test_deep_stacks_and_nested_blocks[generic]",
     "test_general_constraint_instances_on_the_fibonacci_trace[small]",

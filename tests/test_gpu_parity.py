@@ -276,6 +276,55 @@ def test_sharded_prover_reports_invalid_trace(oracle):
         sharded.prove_local(cols, 8, t.width, t.ctx_depth, t.loop_depth, [1, 0], [1], 2, grinding=8)
 
 
+def test_sharded_fri_protocol_state_errors(oracle, monkeypatch):
+    """The begin / end / roots protocol of the FRI commit phase refuses calls out of order with DST_ERR_STATE (one rank, host buffers)."""
+    import ctypes
+    import distaff_amd as D
+    from distaff_amd import sharded
+    monkeypatch.setenv("DISTAFF_FRI_REPLICATE_LOG", "9")                       # 2^13, 2^11 sharded, then the replicated tail
+    t = oracle.fibonacci_trace(256)
+    ctx = D.Context(8, t.width, t.ctx_depth, t.loop_depth, grinding=8)
+    ctx.upload(t.columns)
+    prover = sharded.ShardedProver(ctx, sharded.LocalComm.create(1)[0])
+    expected = prover.prove(t.public_inputs, [3])                               # a complete run first: all buffers exist
+    roots, rep_from = ctx.shard_fri_roots()
+    assert len(roots) == 4 and rep_from == 2
+    cap = ctx.shard_export_size(sharded.SH_FRI_SEND_CAP, 0)
+    buf = np.zeros(cap, dtype=np.uint8)
+
+    def state_error(call):
+        with pytest.raises(D.DistaffError) as e:
+            call()
+        assert e.value.code == D.DST_ERR_STATE, e.value
+
+    # a new proof up to the composition; then FRI calls out of order
+    ctx.shard_commit_trace()
+    root = prover._exchange(sharded.SH_TRACE_TREE)
+    assert ctx.shard_eval_constraints(t.public_inputs, [3], D.lib.prng_vector(root, 344)) == -1
+    prover._exchange(sharded.SH_CEVAL)
+    ctx.shard_combine()
+    croot = prover._exchange(sharded.SH_CONSTRAINT_TREE)
+    state_error(lambda: ctx.shard_fri_begin(buf.ctypes.data, False, cap))      # composition not built
+    ctx.compose(D.lib.prng_vector(croot, 516))
+    state_error(lambda: ctx.shard_fri_roots())                                 # commit phase not finished
+    state_error(lambda: ctx.shard_fri_end(buf.ctypes.data, False))             # nothing in flight
+    size, more = ctx.shard_fri_begin(buf.ctypes.data, False, cap)
+    assert more and size == ctx.shard_export_size(sharded.SH_FRI_TREE, 0)
+    state_error(lambda: ctx.shard_fri_begin(buf.ctypes.data, False, cap))      # layer 0 not folded yet
+    ctx.shard_fri_end(buf.ctypes.data, False)                                  # one rank: what it sent is what the all-gather delivers
+    size, more = ctx.shard_fri_begin(buf.ctypes.data, False, cap)
+    ctx.shard_fri_end(buf.ctypes.data, False)
+    state_error(lambda: ctx.shard_fri_layer())                                 # layer 2 belongs to the replicated tail
+    size, more = ctx.shard_fri_begin(buf.ctypes.data, False, cap)              # the tail: this rank's cosets of layer 2
+    assert not more and size == (1 << 9) * 16
+    state_error(lambda: ctx.shard_fri_begin(buf.ctypes.data, False, cap))      # exchange pending
+    ctx.shard_fri_end(buf.ctypes.data, False)
+    assert ctx.shard_fri_roots() == (roots, rep_from)                          # same trace, same challenges: same commitments
+    state_error(lambda: ctx.shard_fri_begin(buf.ctypes.data, False, cap))      # commit phase over
+    assert prover.prove(t.public_inputs, [3]) == expected
+    ctx.close()
+
+
 def test_sharded_prover_over_torch_distributed_world1(oracle, monkeypatch):
     """The torch.distributed (RCCL) transport of the sharded prover on one GPU, both shard-transfer modes: staged through the host and
     directly between libdistaff_hip.so's buffers and torch tensors on the device; with the FRI limit lowered so that two layers go
