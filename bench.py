@@ -22,11 +22,11 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI35
 W_FIB = 20                     # registers of the Fibonacci trace
 
 
-def cpu_baseline(log_n):
+def cpu_baseline(log_n, blowup=32, queries=50):
     """Times the CPU oracle (single-threaded restatement of the reference algorithm) on a bounded sample of the workload."""
     import oracle as O
     t = O.fibonacci_trace(1 << log_n)
-    p = O.Prover.from_trace(t, 1)
+    p = O.Prover.from_trace(t, 1, ext=blowup, num_queries=queries)
     t0 = time.time()
     p.prove()
     dt = time.time() - t0
@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-n", type=int, default=int(os.environ.get("BENCH_LOG_N", "20")))
     ap.add_argument("--cpu-log-n", type=int, default=int(os.environ.get("BENCH_CPU_LOG_N", "16")))
+    ap.add_argument("--log-blowup", type=int, default=5, help="log2 of the extension factor (default ProofOptions: 5; BASELINE config 5: 4)")
+    ap.add_argument("--queries", type=int, default=50, help="number of queries (default ProofOptions: 50; BASELINE config 5: 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (multi-GPU) code path even with one rank")
     args = ap.parse_args()
@@ -75,8 +77,9 @@ def main():
     n = 1 << log_n
     cols, program_hash, result = D.fibonacci_trace(log_n)          # host: VM trace of `begin repeat.K swap dup.2 drop add end end`
     if world > 8 or (world & (world - 1)):
-        raise SystemExit("--gpus must be 1, 2, 4 or 8 (cosets of the blowup-32 LDE domain are split evenly)")
-    ctx = D.Context(log_n, W_FIB, 1, 0, device=local_rank, rank=rank, world=world)   # default ProofOptions: blowup 32, 50 queries, grinding 20
+        raise SystemExit("--gpus must be 1, 2, 4 or 8 (cosets of the LDE domain are split evenly)")
+    blowup = 1 << args.log_blowup
+    ctx = D.Context(log_n, W_FIB, 1, 0, device=local_rank, rank=rank, world=world, log_blowup=args.log_blowup, num_queries=args.queries)   # defaults = default ProofOptions: blowup 32, 50 queries, grinding 20
     ctx.upload(cols)                                                # inputs resident in HBM before the timed region
 
     if world == 1 and not args.force_sharded:
@@ -165,14 +168,15 @@ def main():
                 if row["kernel"].replace("void ", "").replace(" ", "").startswith(kernel.replace(" ", "")) and row["fetch_bytes_per_launch_x2"] and row["write_bytes_per_launch_raw"]:
                     return int(row["fetch_bytes_per_launch_x2"]) + int(row["write_bytes_per_launch_raw"]), os.path.basename(files[-1])
         return None, None
+    default_workload = log_n == 20 and world == 1 and (blowup, args.queries) == (32, 50)     # what the committed PMC passes were taken on
     if dom[0]:
         name, st = dom
         per_launch_ms = st["ms"] / st["launches"]
         per_launch_bytes = st["bytes"] / st["launches"]
         achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name)[0] if log_n == 20 and world == 1 else None,
-                    "traffic_source": pmc_traffic(name)[1] if log_n == 20 and world == 1 else None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name)[0] if default_workload else None,
+                    "traffic_source": pmc_traffic(name)[1] if default_workload else None,
                     "launches_per_step": st["launches"] / args.steps, "avg_launch_ms": round(per_launch_ms, 4),
                     "algorithmic_bytes_per_launch": per_launch_bytes,
                     "note": "the path is 128-bit modular integer arithmetic on the VALU: see alu_roofline and DESIGN.md"}
@@ -183,9 +187,9 @@ def main():
         "metric": "trace_cells_per_sec", "value": value, "unit": "trace-cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
         "dtype": "u128 (prime field 2^128-45*2^40+1, 4x u32 limbs)", "data": "synthetic",
-        "config": {"workload": "Fibonacci program (src/examples/fibonacci.rs), 2^%d-step trace, W=20 registers, full stark::prove with default "
-                               "ProofOptions (blowup 32, 50 queries, grinding 20, blake3)" % log_n,
-                   "trace_steps": n, "registers": W_FIB, "blowup": 32, "queries": 50, "grinding": 20,
+        "config": {"workload": "Fibonacci program (src/examples/fibonacci.rs), 2^%d-step trace, W=20 registers, full stark::prove with %s"
+                               "ProofOptions (blowup %d, %d queries, grinding 20, blake3)" % (log_n, "default " if (blowup, args.queries) == (32, 50) else "", blowup, args.queries),
+                   "trace_steps": n, "registers": W_FIB, "blowup": blowup, "queries": args.queries, "grinding": 20,
                    "parallelism": "1 GPU" if world == 1 else "one proof sharded over %d GPUs by LDE cosets; RCCL all-gather of Merkle boundary nodes "
                                   "and constraint evaluations; shard hand-off: %s" % (world, transport)},
         "prover_ms": ms_per_step,
@@ -200,7 +204,7 @@ def main():
         "kernels_note": "one extra untimed proof with every launch bracketed by events; the roofline kernel is timed inside the timed region",
     }
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_log_n)
+        out["cpu_baseline"] = cpu_baseline(args.cpu_log_n, blowup, args.queries)
     print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:
