@@ -173,11 +173,16 @@ class TorchComm:
         self.dist.all_gather_into_tensor(out, t)
         return out.cpu().numpy()
 
+    def synchronize(self):
+        """the collective has landed in the tensors before the library (its own stream) reads them"""
+        if self.device is not None and self.device.type == "cuda":
+            self.torch.cuda.synchronize(self.device)
+
     def all_gather_device(self, send):
         """send: uint8 torch tensor on self.device -> gathered tensor (rank-major)"""
         out = self.torch.empty(send.numel() * self.world, dtype=self.torch.uint8, device=send.device)
         self.dist.all_gather_into_tensor(out, send)
-        self.torch.cuda.synchronize(send.device)
+        self.synchronize()
         return out
 
     def barrier(self):
@@ -295,7 +300,7 @@ class ShardedProver:
                 size, more = ctx.shard_fri_begin(send_t.data_ptr(), True, cap)
                 out = recv_t[:size * G]
                 comm.dist.all_gather_into_tensor(out, send_t[:size])
-                torch.cuda.synchronize(comm.device)
+                comm.synchronize()
                 ctx.shard_fri_end(out.data_ptr(), True)
             else:
                 size, more = ctx.shard_fri_begin(send_h.ctypes.data, False, cap)

@@ -71,3 +71,49 @@ def test_emulated_build_is_not_a_product_path():
         if os.path.isfile(f) and not f.endswith((".so", ".pyc", ".o")):
             text = open(f, errors="ignore").read()
             assert "libdistaff_emu" not in text and "tests/emu" not in text, f
+
+
+DEVICE_PATH_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import torch, torch.distributed as dist
+import oracle as O
+import distaff_amd as D
+from distaff_amd.sharded import ShardedProver, TorchComm
+dist.init_process_group("gloo")
+# the hand-off mode bench.py uses on GPUs: the library reads / writes the collective's tensors directly through their data pointers
+comm = TorchComm(dist, torch.device("cpu"), device_path=True)
+assert comm.device_path
+t = O.fibonacci_trace(256)
+p = O.Prover.from_trace(t, 1, grinding=8)
+expected = p.prove()
+ctx = D.Context(8, t.width, t.ctx_depth, t.loop_depth, rank=comm.rank, world=comm.world, grinding=8)
+ctx.upload(t.columns)
+prover = ShardedProver(ctx, comm)
+for _ in range(2):                                   # twice: the buffers of the first proof are reused
+    assert prover.prove(t.public_inputs, p.outputs) == expected, "rank %%d: proof differs from the oracle's" %% comm.rank
+assert ShardedProver(ctx, comm, python_openings=True).prove(t.public_inputs, p.outputs) == expected
+ctx.close()
+comm.barrier()
+dist.destroy_process_group()
+print("ok", comm.rank)
+'''
+
+
+@pytest.mark.parametrize("world,replicate_log", [(2, 9), (4, 17)])
+def test_tensor_hand_off_path_over_gloo(emulated_library, tmp_path, world, replicate_log):
+    """`world` real processes over torch.distributed (gloo), each with its own context of the emulated build, exchanging shards
+    through tensor data pointers (`is_device` = 1 in the C-ABI) -- the branch of ShardedProver that bench.py takes with RCCL on
+    GPUs, which the GPU box of the test run can only exercise with one rank."""
+    import socket
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    script = tmp_path / "device_path_worker.py"
+    script.write_text(DEVICE_PATH_WORKER % {"root": ROOT})
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DISTAFF_HIP_LIB=emulated_library, DISTAFF_HIP_RUNTIME="none", DISTAFF_FRI_REPLICATE_LOG=str(replicate_log), DISTAFF_EMU_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    assert all("ok" in o for o in outs)
