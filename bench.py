@@ -193,7 +193,7 @@ def main():
                    "parallelism": "1 GPU" if world == 1 else "one proof sharded over %d GPUs by LDE cosets; RCCL all-gather of Merkle boundary nodes "
                                   "and constraint evaluations; shard hand-off: %s" % (world, transport)},
         "prover_ms": ms_per_step,
-        "phase_ms": {k: round(v / args.steps, 3) for k, v in zip(
+        "phase_ms": None if transport != "none" else {k: round(v / args.steps, 3) for k, v in zip(
             ["lde", "trace_merkle", "constraint_eval", "combine", "constraint_lde_merkle", "deep_composition", "fri", "pow_queries", "openings"], phase_sum)},
         "proof_bytes": len(proof),
         "shard_stage_ms_rank0": {k: round(v / args.steps, 3) for k, v in stage_sum.items()} or None,

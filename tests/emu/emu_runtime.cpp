@@ -194,7 +194,7 @@ struct emu_event { std::chrono::steady_clock::time_point t; };
 const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "no error" : e == hipErrorOutOfMemory ? "out of memory (emulated)" : "error (emulated)"; }
 hipError_t hipGetLastError() { return hipSuccess; }
 hipError_t hipGetDeviceCount(int* n) { *n = 1; return hipSuccess; }
-hipError_t hipSetDevice(int d) { return d == 0 ? hipSuccess : hipErrorInvalidValue; }
+hipError_t hipSetDevice(int d) { return d >= 0 && d < 64 ? hipSuccess : hipErrorInvalidValue; }    // one host stands in for every ordinal
 hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int) {
     memset(p, 0, sizeof(*p));

@@ -117,3 +117,33 @@ def test_tensor_hand_off_path_over_gloo(emulated_library, tmp_path, world, repli
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert all("ok" in o for o in outs)
+
+
+@pytest.mark.parametrize("ranks", [1, 2])
+def test_bench_control_flow_on_cpu_stand_ins(emulated_library, ranks):
+    """bench.py's own main() launched exactly as the driver launches it for N > 1 (`python -m torch.distributed.run ...`), with gloo,
+    CPU tensors and the emulated build standing in for RCCL, device tensors and the GPU (tests/emu/bench_harness.py): one JSON line
+    from rank 0 with the contract's fields, the sharded prover with the tensor hand-off for N = 2.  The numbers mean nothing here."""
+    import json
+    import socket
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    env = dict(os.environ, DISTAFF_HIP_LIB=emulated_library, DISTAFF_HIP_RUNTIME="none", DISTAFF_EMU_THREADS="2")
+    harness = os.path.join(EMU_DIR, "bench_harness.py")
+    args = ["--gpus", str(ranks), "--steps", "1", "--warmup", "1", "--log-n", "8", "--cpu-log-n", "7"]
+    if ranks == 1:
+        cmd = [sys.executable, harness] + args
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), harness] + args
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [l for l in r.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    out = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in out, key
+    assert out["n_gpus"] == ranks and out["steps"] == 1 and out["vs_baseline"] is None and "workload" in out["config"]
+    assert out["scaling"] == ("weak" if ranks == 1 else "strong")
+    assert ("cpu_baseline" in out) == (ranks == 1)
+    if ranks > 1:
+        assert "hand-off: device" in out["config"]["parallelism"] and out["shard_stage_ms_rank0"]
