@@ -112,7 +112,7 @@ static int ctx_init(dst_ctx* c) {
     // 16-column tiles (256-byte HBM segments) instead of 4096-point tiles that hold one or two columns
     NttPlan& pl = c->plan;
     const char* force = getenv("DISTAFF_NTT");
-    const bool three = (c->log_n >= 21 && !(force && (!strcmp(force, "reg") || !strcmp(force, "lds")))) || (force && !strcmp(force, "3pass") && c->log_n >= 20);
+    const bool three = (c->log_n >= 21 && !(force && (!strcmp(force, "reg") || !strcmp(force, "lds")))) || (force && !strcmp(force, "3pass") && c->log_n >= 12);
     pl.log_n = c->log_n;
     if (three) {
         // shape n1 * nm * n3 with n1 >= nm >= n3 as balanced as possible, at most 2^8 each; DISTAFF_NTT_SHAPE=a,b overrides n1, nm (tests)

@@ -147,3 +147,42 @@ def test_bench_control_flow_on_cpu_stand_ins(emulated_library, ranks):
     assert ("cpu_baseline" in out) == (ranks == 1)
     if ranks > 1:
         assert "hand-off: device" in out["config"]["parallelism"] and out["shard_stage_ms_rank0"]
+
+
+THREE_PASS_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+os.environ["DISTAFF_NTT"] = "3pass"                      # the plan the library takes by itself from 2^21 points on
+import numpy as np
+import oracle as O
+import distaff_amd as D
+for log_n, log_b in ((12, 5), (13, 4), (15, 4)):
+    n, B, W = 1 << log_n, 1 << log_b, 16
+    rng = np.random.default_rng(log_n)
+    cols = rng.integers(0, 2**63, size=(W, n, 2), dtype=np.uint64)
+    ctx = D.Context(log_n, W, 0, 0, log_blowup=log_b)
+    ctx.upload(cols)
+    ctx.commit_trace()
+    for c in (0, 9, 15):
+        poly = ctx.read_elements("polys").reshape(W, n, 2)[c]
+        lde = ctx.read_elements("lde", c)
+        g_n, g_N = O.root_of_unity(n), O.root_of_unity(n * B)
+        for k in (0, 1, n - 1, 77):
+            assert O.poly_eval(poly, O.exp(g_n, k)) == O.to_ints(cols[c, k:k + 1])[0], ("interpolation", log_n, c, k)
+        for i in (1, B - 1, B, n * B - 1, 12345):
+            assert O.poly_eval(poly, O.exp(g_N, i)) == O.to_ints(lde[i:i + 1])[0], ("extension", log_n, c, i)
+        assert (lde[::B] == cols[c]).all()
+    ctx.close()
+print("ok")
+'''
+
+
+def test_three_pass_transform_plan_at_small_sizes(emulated_library, tmp_path):
+    """The three-pass NTT plan (n = n1 * nm * n3, the default from 2^21 points, GPU-tested at 2^20 .. 2^24) forced onto 2^12 .. 2^15
+    points so that its index arithmetic is also checked where there is no GPU: interpolation and extension against Horner
+    evaluations by the oracle."""
+    script = tmp_path / "three_pass_worker.py"
+    script.write_text(THREE_PASS_WORKER % {"root": ROOT})
+    env = dict(os.environ, DISTAFF_HIP_LIB=emulated_library, DISTAFF_HIP_RUNTIME="none")
+    r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0 and b"ok" in r.stdout, r.stdout.decode()[-3000:]
