@@ -31,54 +31,66 @@ FE_HD fe fe_from_u64(uint64_t x) { return fe_make((uint32_t)x, (uint32_t)(x >> 3
 FE_HD bool fe_is_zero(const fe& a) { return (a.v[0] | a.v[1] | a.v[2] | a.v[3]) == 0; }
 FE_HD bool fe_eq(const fe& a, const fe& b) { return ((a.v[0] ^ b.v[0]) | (a.v[1] ^ b.v[1]) | (a.v[2] ^ b.v[2]) | (a.v[3] ^ b.v[3])) == 0; }
 
+// ---- carry primitives ----------------------------------------------------------------------------------------------------------
+// Everything below is written over a handful of primitives with two forms.  On gfx950 each one is a single VALU instruction
+// in inline asm whose carry / borrow is a LANE MASK in an SGPR pair (fe_cf): the compiler allocates the pairs, schedules the
+// instructions of independent chains between each other and pads the VALU-writes-SGPR -> VALU-reads-SGPR wait states; masks are
+// combined on the scalar unit (s_or / s_andn2), never materialised as 0/1 values in vector registers.  On the host (tables, the
+// host-emulated test build) the same functions are plain integer arithmetic, so the limb-level dataflow of every formulation is exercised by the
+// CPU tests as well (tools/felab holds the standalone CPU and GPU checks of this file).
 #if defined(__HIP_DEVICE_COMPILE__)
-__device__ __forceinline__ uint32_t fe_addc(uint32_t a, uint32_t b, uint32_t cin, uint32_t* cout) { return __builtin_addc(a, b, cin, cout); }
-__device__ __forceinline__ uint32_t fe_subb(uint32_t a, uint32_t b, uint32_t bin, uint32_t* bout) { return __builtin_subc(a, b, bin, bout); }
-#endif
-
-FE_HD fe fe_add(const fe& a, const fe& b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t c, cs;
-    uint32_t s0 = fe_addc(a.v[0], b.v[0], 0, &c), s1 = fe_addc(a.v[1], b.v[1], c, &c), s2 = fe_addc(a.v[2], b.v[2], c, &c), s3 = fe_addc(a.v[3], b.v[3], c, &cs);
-    uint32_t z0 = fe_addc(s0, FE_C0, 0, &c), z1 = fe_addc(s1, FE_C1, c, &c), z2 = fe_addc(s2, 0, c, &c), z3 = fe_addc(s3, 0, c, &c);
-    bool ov = (cs | c) != 0;
-    return fe_make(ov ? z0 : s0, ov ? z1 : s1, ov ? z2 : s2, ov ? z3 : s3);
-#else
-    // s = a + b; t = s + C128; a + b >= p  <=>  a + b + C128 >= 2^128
-    uint64_t c = (uint64_t)a.v[0] + b.v[0];               uint32_t s0 = (uint32_t)c;
-    c = (uint64_t)a.v[1] + b.v[1] + (c >> 32);            uint32_t s1 = (uint32_t)c;
-    c = (uint64_t)a.v[2] + b.v[2] + (c >> 32);            uint32_t s2 = (uint32_t)c;
-    c = (uint64_t)a.v[3] + b.v[3] + (c >> 32);            uint32_t s3 = (uint32_t)c;
-    uint32_t cs = (uint32_t)(c >> 32);
-    uint64_t d = (uint64_t)s0 + FE_C0;                    uint32_t t0 = (uint32_t)d;
-    d = (uint64_t)s1 + FE_C1 + (d >> 32);                 uint32_t t1 = (uint32_t)d;
-    d = (uint64_t)s2 + (d >> 32);                         uint32_t t2 = (uint32_t)d;
-    d = (uint64_t)s3 + (d >> 32);                         uint32_t t3 = (uint32_t)d;
-    bool over = (cs | (uint32_t)(d >> 32)) != 0;
-    return over ? fe_make(t0, t1, t2, t3) : fe_make(s0, s1, s2, s3);
-#endif
+typedef uint64_t fe_cf;
+__device__ __forceinline__ uint64_t fe_madc(uint32_t a, uint32_t b, uint64_t c, fe_cf& co) {          // a * b + c, carry out of bit 64
+    uint64_t d; asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(co) : "v"(a), "v"(b), "v"(c)); return d;
 }
-
-FE_HD fe fe_sub(const fe& a, const fe& b) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t bw;
-    uint32_t d0 = fe_subb(a.v[0], b.v[0], 0, &bw), d1 = fe_subb(a.v[1], b.v[1], bw, &bw), d2 = fe_subb(a.v[2], b.v[2], bw, &bw), d3 = fe_subb(a.v[3], b.v[3], bw, &bw);
-    uint32_t m = 0u - bw;                              // all ones when a < b: add p == subtract C128 (mod 2^128)
-    uint32_t e0 = fe_subb(d0, m, 0, &bw), e1 = fe_subb(d1, m & FE_C1, bw, &bw), e2 = fe_subb(d2, 0, bw, &bw), e3 = fe_subb(d3, 0, bw, &bw);
-    return fe_make(e0, e1, e2, e3);
+__device__ __forceinline__ uint32_t fe_cnt0(fe_cf c) { uint32_t r; asm("v_cndmask_b32_e64 %0, 0, 1, %1" : "=v"(r) : "s"(c)); return r; }
+__device__ __forceinline__ uint32_t fe_cnt(uint32_t n, fe_cf c) { uint32_t r; fe_cf o; asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r), "=s"(o) : "v"(n), "s"(c)); return r; }
+__device__ __forceinline__ uint32_t fe_add_co(uint32_t a, uint32_t b, fe_cf& co) { uint32_t r; asm("v_add_co_u32_e64 %0, %1, %2, %3" : "=v"(r), "=s"(co) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint32_t fe_addc_co(uint32_t a, uint32_t b, fe_cf ci, fe_cf& co) { uint32_t r; asm("v_addc_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r), "=s"(co) : "v"(a), "v"(b), "s"(ci)); return r; }
+__device__ __forceinline__ uint32_t fe_addc0_co(uint32_t a, fe_cf ci, fe_cf& co) { uint32_t r; asm("v_addc_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r), "=s"(co) : "v"(a), "s"(ci)); return r; }
+__device__ __forceinline__ uint32_t fe_addm1_co(uint32_t a, fe_cf& co) { uint32_t r; asm("v_add_co_u32_e64 %0, %1, -1, %2" : "=v"(r), "=s"(co) : "v"(a)); return r; }      // a + 0xFFFFFFFF
+__device__ __forceinline__ uint32_t fe_sub_co(uint32_t a, uint32_t b, fe_cf& bo) { uint32_t r; asm("v_sub_co_u32_e64 %0, %1, %2, %3" : "=v"(r), "=s"(bo) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ uint32_t fe_subb_co(uint32_t a, uint32_t b, fe_cf bi, fe_cf& bo) { uint32_t r; asm("v_subb_co_u32_e64 %0, %1, %2, %3, %4" : "=v"(r), "=s"(bo) : "v"(a), "v"(b), "s"(bi)); return r; }
+__device__ __forceinline__ uint32_t fe_subb0_co(uint32_t a, fe_cf bi, fe_cf& bo) { uint32_t r; asm("v_subbrev_co_u32_e64 %0, %1, 0, %2, %3" : "=v"(r), "=s"(bo) : "v"(a), "s"(bi)); return r; }   // a - 0 - borrow
+__device__ __forceinline__ uint32_t fe_sel(fe_cf m, uint32_t a, uint32_t b) { uint32_t r; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(b), "v"(a), "s"(m)); return r; }   // m ? a : b
+__device__ __forceinline__ uint32_t fe_sel0(fe_cf m, uint32_t a) { uint32_t r; asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(a), "s"(m)); return r; }                        // m ? a : 0
+__device__ __forceinline__ uint32_t fe_selm1(fe_cf m) { uint32_t r; asm("v_cndmask_b32_e64 %0, 0, -1, %1" : "=v"(r) : "s"(m)); return r; }                                           // m ? 0xFFFFFFFF : 0
 #else
-    // d = a - b; on borrow add p, i.e. subtract C128 modulo 2^128
-    int64_t c = (int64_t)(uint64_t)a.v[0] - b.v[0];                 uint32_t d0 = (uint32_t)c;
-    c = (int64_t)(uint64_t)a.v[1] - b.v[1] + (c >> 32);             uint32_t d1 = (uint32_t)c;
-    c = (int64_t)(uint64_t)a.v[2] - b.v[2] + (c >> 32);             uint32_t d2 = (uint32_t)c;
-    c = (int64_t)(uint64_t)a.v[3] - b.v[3] + (c >> 32);             uint32_t d3 = (uint32_t)c;
-    bool borrow = (c >> 32) != 0;
-    int64_t e = (int64_t)(uint64_t)d0 - FE_C0;                      uint32_t e0 = (uint32_t)e;
-    e = (int64_t)(uint64_t)d1 - FE_C1 + (e >> 32);                  uint32_t e1 = (uint32_t)e;
-    e = (int64_t)(uint64_t)d2 + (e >> 32);                          uint32_t e2 = (uint32_t)e;
-    e = (int64_t)(uint64_t)d3 + (e >> 32);                          uint32_t e3 = (uint32_t)e;
-    return borrow ? fe_make(e0, e1, e2, e3) : fe_make(d0, d1, d2, d3);
+typedef uint32_t fe_cf;
+FE_HD uint64_t fe_madc(uint32_t a, uint32_t b, uint64_t c, fe_cf& co) { unsigned __int128 t = (unsigned __int128)a * b + c; co = (fe_cf)(t >> 64); return (uint64_t)t; }
+FE_HD uint32_t fe_cnt0(fe_cf c) { return c; }
+FE_HD uint32_t fe_cnt(uint32_t n, fe_cf c) { return n + c; }
+FE_HD uint32_t fe_add_co(uint32_t a, uint32_t b, fe_cf& co) { uint64_t t = (uint64_t)a + b; co = (fe_cf)(t >> 32); return (uint32_t)t; }
+FE_HD uint32_t fe_addc_co(uint32_t a, uint32_t b, fe_cf ci, fe_cf& co) { uint64_t t = (uint64_t)a + b + ci; co = (fe_cf)(t >> 32); return (uint32_t)t; }
+FE_HD uint32_t fe_addc0_co(uint32_t a, fe_cf ci, fe_cf& co) { return fe_addc_co(a, 0u, ci, co); }
+FE_HD uint32_t fe_addm1_co(uint32_t a, fe_cf& co) { return fe_add_co(a, 0xFFFFFFFFu, co); }
+FE_HD uint32_t fe_sub_co(uint32_t a, uint32_t b, fe_cf& bo) { bo = a < b; return a - b; }
+FE_HD uint32_t fe_subb_co(uint32_t a, uint32_t b, fe_cf bi, fe_cf& bo) { uint64_t t = (uint64_t)a - b - bi; bo = (fe_cf)((t >> 32) & 1); return (uint32_t)t; }
+FE_HD uint32_t fe_subb0_co(uint32_t a, fe_cf bi, fe_cf& bo) { return fe_subb_co(a, 0u, bi, bo); }
+FE_HD uint32_t fe_sel(fe_cf m, uint32_t a, uint32_t b) { return m ? a : b; }
+FE_HD uint32_t fe_sel0(fe_cf m, uint32_t a) { return m ? a : 0u; }
+FE_HD uint32_t fe_selm1(fe_cf m) { return m ? 0xFFFFFFFFu : 0u; }
 #endif
+#define FE_LO(x) ((uint32_t)(x))
+#define FE_HI(x) ((uint32_t)((x) >> 32))
+#define FE_PAIR(lo, hi) ((uint64_t)(lo) | ((uint64_t)(hi) << 32))
+FE_HD uint32_t fe_mad24(uint32_t a, uint32_t b, uint32_t c) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu) + c; }      // operands below 2^24: v_mad_u32_u24
+
+// canonical addition: s = a + b, z = s - p (= s + C128 mod 2^128); z is the answer when either addition carries
+FE_HD fe fe_add(const fe& a, const fe& b) {
+    fe_cf c, d;
+    uint32_t s0 = fe_add_co(a.v[0], b.v[0], c), s1 = fe_addc_co(a.v[1], b.v[1], c, c), s2 = fe_addc_co(a.v[2], b.v[2], c, c), s3 = fe_addc_co(a.v[3], b.v[3], c, c);
+    uint32_t z0 = fe_addm1_co(s0, d), z1 = fe_addc_co(s1, FE_C1, d, d), z2 = fe_addc0_co(s2, d, d), z3 = fe_addc0_co(s3, d, d);
+    fe_cf s = c | d;
+    return fe_make(fe_sel(s, z0, s0), fe_sel(s, z1, s1), fe_sel(s, z2, s2), fe_sel(s, z3, s3));
+}
+// canonical subtraction: d = a - b; on borrow add p, i.e. subtract C128 modulo 2^128
+FE_HD fe fe_sub(const fe& a, const fe& b) {
+    fe_cf c, d;
+    uint32_t d0 = fe_sub_co(a.v[0], b.v[0], c), d1 = fe_subb_co(a.v[1], b.v[1], c, c), d2 = fe_subb_co(a.v[2], b.v[2], c, c), d3 = fe_subb_co(a.v[3], b.v[3], c, c);
+    uint32_t k0 = fe_selm1(c), k1 = fe_sel0(c, FE_C1);
+    uint32_t e0 = fe_sub_co(d0, k0, d), e1 = fe_subb_co(d1, k1, d, d), e2 = fe_subb0_co(d2, d, d), e3 = fe_subb0_co(d3, d, d);
+    return fe_make(e0, e1, e2, e3);
 }
 
 FE_HD fe fe_neg(const fe& a) { return fe_sub(fe_zero(), a); }
@@ -155,92 +167,136 @@ FE_HD fe fe_mul_portable(const fe& a, const fe& b) {
     return fe_reduce8(t);
 }
 
-#if defined(__HIP_DEVICE_COMPILE__)
-// ---- gfx950 formulation --------------------------------------------------------------------------------------------------
-// 16 v_mad_u64_u32 for the 256-bit product: partial products with i + j even / odd accumulate in separate 64-bit windows
-// (E0..E3 at limbs 0,2,4,6 and O0..O2 at limbs 1,3,5), the carry-out of each accumulating mad is counted with one
-// v_addc_co_u32, and the windows are merged with two carry chains.  The reduction multiplies the four high limbs by
-// K = 45*2^8 with independent mads (no carry chain between them) and folds with add/sub-with-carry chains.
-__device__ __forceinline__ void fe_mac_c(uint64_t& acc, uint32_t& cnt, uint32_t a, uint32_t b) {
-    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, %1, vcc" : "+v"(acc), "+v"(cnt) : "v"(a), "v"(b) : "vcc");
-}
-// first accumulation into a window: the carry count starts as the carry-out itself (no zero-initialised register)
-__device__ __forceinline__ void fe_mac_c0(uint64_t& acc, uint32_t& cnt, uint32_t a, uint32_t b) {
-    asm("v_mad_u64_u32 %0, vcc, %2, %3, %0\n\tv_addc_co_u32 %1, vcc, 0, 0, vcc" : "+v"(acc), "=v"(cnt) : "v"(a), "v"(b) : "vcc");
-}
-__device__ __forceinline__ fe fe_mul_gfx950(const fe& a, const fe& b) {
-#define FE_LO(x) ((uint32_t)(x))
-#define FE_HI(x) ((uint32_t)((x) >> 32))
-    uint64_t E0 = (uint64_t)a.v[0] * b.v[0];
-    uint64_t E1 = (uint64_t)a.v[0] * b.v[2]; uint32_t ce1; fe_mac_c0(E1, ce1, a.v[1], b.v[1]); fe_mac_c(E1, ce1, a.v[2], b.v[0]);
-    uint64_t E2 = (uint64_t)a.v[1] * b.v[3]; uint32_t ce2; fe_mac_c0(E2, ce2, a.v[2], b.v[2]); fe_mac_c(E2, ce2, a.v[3], b.v[1]);
-    uint64_t E3 = (uint64_t)a.v[3] * b.v[3];
-    uint64_t O0 = (uint64_t)a.v[0] * b.v[1]; uint32_t co0; fe_mac_c0(O0, co0, a.v[1], b.v[0]);
-    uint64_t O1 = (uint64_t)a.v[0] * b.v[3]; uint32_t co1; fe_mac_c0(O1, co1, a.v[1], b.v[2]); fe_mac_c(O1, co1, a.v[2], b.v[1]); fe_mac_c(O1, co1, a.v[3], b.v[0]);
-    uint64_t O2 = (uint64_t)a.v[2] * b.v[3]; uint32_t co2; fe_mac_c0(O2, co2, a.v[3], b.v[2]);
-    uint32_t t0, t1, t2, t3, t4, t5, t6, t7, c, bw;
-    t0 = FE_LO(E0);
-    t1 = fe_addc(FE_HI(E0), FE_LO(O0), 0, &c);
-    t2 = fe_addc(FE_LO(E1), FE_HI(O0), c, &c);
-    t3 = fe_addc(FE_HI(E1), FE_LO(O1), c, &c);
-    t4 = fe_addc(FE_LO(E2), FE_HI(O1), c, &c);
-    t5 = fe_addc(FE_HI(E2), FE_LO(O2), c, &c);
-    t6 = fe_addc(FE_LO(E3), FE_HI(O2), c, &c);
-    t7 = FE_HI(E3) + c;
-    t3 = fe_addc(t3, co0, 0, &c);
-    t4 = fe_addc(t4, ce1, c, &c);
-    t5 = fe_addc(t5, co1, c, &c);
-    t6 = fe_addc(t6, ce2, c, &c);
-    t7 = t7 + co2 + c;
-    // fold 1: v = lo + ((hi * K) << 32) - hi
-    uint64_t P0 = (uint64_t)t4 * FE_K, P1 = (uint64_t)t5 * FE_K, P2 = (uint64_t)t6 * FE_K, P3 = (uint64_t)t7 * FE_K;
-    uint32_t u1, u2, u3, u4, u5;
-    u1 = fe_addc(t1, FE_LO(P0), 0, &c);
-    u2 = fe_addc(t2, FE_LO(P1), c, &c);
-    u3 = fe_addc(t3, FE_LO(P2), c, &c);
-    u4 = fe_addc(FE_LO(P3), 0, c, &c);
-    u5 = c;
-    u2 = fe_addc(u2, FE_HI(P0), 0, &c);
-    u3 = fe_addc(u3, FE_HI(P1), c, &c);
-    u4 = fe_addc(u4, FE_HI(P2), c, &c);
-    u5 = u5 + FE_HI(P3) + c;
-    uint32_t v0, v1, v2, v3, v4, v5;
-    v0 = fe_subb(t0, t4, 0, &bw);
-    v1 = fe_subb(u1, t5, bw, &bw);
-    v2 = fe_subb(u2, t6, bw, &bw);
-    v3 = fe_subb(u3, t7, bw, &bw);
-    v4 = fe_subb(u4, 0, bw, &bw);
-    v5 = u5 - bw;
-    // fold 2: y = v_lo + (((v5:v4) * K) << 32) - (v5:v4)
-    uint64_t w = (uint64_t)v4 * FE_K;
-    uint32_t w0 = FE_LO(w), w1 = FE_HI(w) + v5 * FE_K;
-    uint32_t y0, y1, y2, y3, y4;
-    y1 = fe_addc(v1, w0, 0, &c);
-    y2 = fe_addc(v2, w1, c, &c);
-    y3 = fe_addc(v3, 0, c, &c);
-    y4 = c;
-    y0 = fe_subb(v0, v4, 0, &bw);
-    y1 = fe_subb(y1, v5, bw, &bw);
-    y2 = fe_subb(y2, 0, bw, &bw);
-    y3 = fe_subb(y3, 0, bw, &bw);
-    y4 = y4 - bw;
-    // fold 3 and canonical form in one step.  The value is Y = y + y4 * 2^128 with y4 in {0, 1} and Y < 2p.  z = y + C128 (mod 2^128)
-    // is Y - p whenever Y >= p, and Y >= p <=> y4 = 1 or the addition carries out (when y4 = 1, y < p - C128, so no carry).
-    uint32_t z0, z1, z2, z3;
-    z0 = fe_addc(y0, FE_C0, 0, &c);
-    z1 = fe_addc(y1, FE_C1, c, &c);
-    z2 = fe_addc(y2, 0, c, &c);
-    z3 = fe_addc(y3, 0, c, &c);
-    c |= y4;
-#undef FE_LO
-#undef FE_HI
-    return c ? fe_make(z0, z1, z2, z3) : fe_make(y0, y1, y2, y3);
+// ---- gfx950 formulations -----------------------------------------------------------------------------------------------------------
+// Products are sums of 32x32+64 multiply-adds (v_mad_u64_u32, the widest integer multiplier of the VALU, issued at the rate of an
+// ordinary 32-bit instruction) accumulated in 64-bit windows at limb positions; every accumulating mad hands its carry-out to a one-
+// instruction counter.  The counters of two neighbouring windows are the INITIAL ADDEND (low word, high word) of the window two
+// limbs up, so they cost no separate carry chain.  The windows are merged by one add-with-carry chain, the part above 2^128 is folded
+// with 2^128 = K * 2^32 - 1 (mod p), K = 45 * 2^8, and the last conditional subtraction of p selects with a mask formed on the
+// scalar unit.  VALU instructions: general multiplication 71 (21 of them multiplies), multiplication by a table entry (fe_tw) 55 (18).
+
+// y = r + y4 * 2^128 (y4 a flag) with y < 2p  ->  canonical representative
+FE_HD fe fe_final(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, fe_cf y4) {
+    fe_cf c;
+    uint32_t z0 = fe_addm1_co(r0, c), z1 = fe_addc_co(r1, FE_C1, c, c), z2 = fe_addc0_co(r2, c, c), z3 = fe_addc0_co(r3, c, c);
+    fe_cf s = y4 | c;
+    return fe_make(fe_sel(s, z0, r0), fe_sel(s, z1, r1), fe_sel(s, z2, r2), fe_sel(s, z3, r3));
 }
 
+// reduction of the nine-limb value t0..t8 (t8 < 2^7; the product of two 128-bit values, or a sum of up to 64 of them)
+FE_HD fe fe_fold9(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t t4, uint32_t t5, uint32_t t6, uint32_t t7, uint32_t t8, bool has_t8) {
+    fe_cf c, b;
+    // fold 1: v = lo + ((hi * K) << 32) - hi
+    uint64_t P0 = (uint64_t)t4 * FE_K, P1 = (uint64_t)t5 * FE_K, P2 = (uint64_t)t6 * FE_K, P3 = (uint64_t)t7 * FE_K;
+    uint32_t u1 = fe_add_co(t1, FE_LO(P0), c);
+    uint32_t u2 = fe_addc_co(t2, FE_LO(P1), c, c);
+    uint32_t u3 = fe_addc_co(t3, FE_LO(P2), c, c);
+    uint32_t u4 = fe_addc0_co(FE_LO(P3), c, c);
+    uint32_t u5 = fe_cnt(has_t8 ? fe_mad24(t8, FE_K, FE_HI(P3)) : FE_HI(P3), c);      // t8 * K < 2^21
+    u2 = fe_add_co(u2, FE_HI(P0), c);
+    u3 = fe_addc_co(u3, FE_HI(P1), c, c);
+    u4 = fe_addc_co(u4, FE_HI(P2), c, c);
+    u5 = fe_cnt(u5, c);
+    uint32_t v0 = fe_sub_co(t0, t4, b);
+    uint32_t v1 = fe_subb_co(u1, t5, b, b);
+    uint32_t v2 = fe_subb_co(u2, t6, b, b);
+    uint32_t v3 = fe_subb_co(u3, t7, b, b);
+    uint32_t v4 = has_t8 ? fe_subb_co(u4, t8, b, b) : fe_subb0_co(u4, b, b);
+    uint32_t v5 = fe_subb0_co(u5, b, b);
+    // fold 2: y = v_lo + ((V * K) << 32) - V, V = v5:v4 (< 2^46, < 2^54 with t8)
+    uint64_t w = (uint64_t)v4 * FE_K;
+    uint32_t y1 = fe_add_co(v1, FE_LO(w), c), y2, y3;
+    if (has_t8) { uint64_t x = (uint64_t)v5 * FE_K + FE_HI(w); y2 = fe_addc_co(v2, FE_LO(x), c, c); y3 = fe_addc_co(v3, FE_HI(x), c, c); }
+    else { y2 = fe_addc_co(v2, fe_mad24(v5, FE_K, FE_HI(w)), c, c); y3 = fe_addc0_co(v3, c, c); }
+    uint32_t y0 = fe_sub_co(v0, v4, b);
+    y1 = fe_subb_co(y1, v5, b, b);
+    y2 = fe_subb0_co(y2, b, b);
+    y3 = fe_subb0_co(y3, b, b);
+    return fe_final(y0, y1, y2, y3, c & ~b);        // the value is non-negative: a borrow only ever cancels a carry
+}
+
+// general multiplication; the operands may be ANY 128-bit values (not only canonical ones)
+FE_HD fe fe_mul_wide(const fe& a, const fe& b) {
+    const uint32_t a0 = a.v[0], a1 = a.v[1], a2 = a.v[2], a3 = a.v[3], b0 = b.v[0], b1 = b.v[1], b2 = b.v[2], b3 = b.v[3];
+    fe_cf c;
+    uint64_t E0 = (uint64_t)a0 * b0;
+    uint64_t O0 = (uint64_t)a0 * b1; O0 = fe_madc(a1, b0, O0, c); uint32_t co0 = fe_cnt0(c);
+    uint64_t E1 = (uint64_t)a0 * b2; E1 = fe_madc(a1, b1, E1, c); uint32_t ce1 = fe_cnt0(c); E1 = fe_madc(a2, b0, E1, c); ce1 = fe_cnt(ce1, c);
+    uint64_t O1 = fe_madc(a0, b3, FE_PAIR(co0, ce1), c); uint32_t co1 = fe_cnt0(c);
+    O1 = fe_madc(a1, b2, O1, c); co1 = fe_cnt(co1, c); O1 = fe_madc(a2, b1, O1, c); co1 = fe_cnt(co1, c); O1 = fe_madc(a3, b0, O1, c); co1 = fe_cnt(co1, c);
+    uint64_t E2 = (uint64_t)a1 * b3; E2 = fe_madc(a2, b2, E2, c); uint32_t ce2 = fe_cnt0(c); E2 = fe_madc(a3, b1, E2, c); ce2 = fe_cnt(ce2, c);
+    uint64_t O2 = fe_madc(a2, b3, FE_PAIR(co1, ce2), c); uint32_t co2 = fe_cnt0(c); O2 = fe_madc(a3, b2, O2, c); co2 = fe_cnt(co2, c);
+    uint64_t E3 = (uint64_t)a3 * b3;
+    uint32_t t0 = FE_LO(E0);
+    uint32_t t1 = fe_add_co(FE_HI(E0), FE_LO(O0), c);
+    uint32_t t2 = fe_addc_co(FE_LO(E1), FE_HI(O0), c, c);
+    uint32_t t3 = fe_addc_co(FE_HI(E1), FE_LO(O1), c, c);
+    uint32_t t4 = fe_addc_co(FE_LO(E2), FE_HI(O1), c, c);
+    uint32_t t5 = fe_addc_co(FE_HI(E2), FE_LO(O2), c, c);
+    uint32_t t6 = fe_addc_co(FE_LO(E3), FE_HI(O2), c, c);
+    uint32_t t7 = fe_cnt(FE_HI(E3) + co2, c);
+    return fe_fold9(t0, t1, t2, t3, t4, t5, t6, t7, 0u, false);
+}
+
+// ---- multiplication by a table entry ---------------------------------------------------------------------------------------------------
+// A twiddle w is stored as the pair (P, Q) = (w, w * 2^64 mod p).  Then  a * w = (a0 + a1 X) * P + (a2 + a3 X) * Q  (X = 2^32) is a sum
+// below 2^193 for ANY 128-bit a: five product columns in windows W0..W4, one merge chain, ONE fold of the 65 bits above 2^128.
+struct __attribute__((aligned(16))) fe_tw { fe p, q; };
+FE_HD fe fe_mul_tw(const fe& a, const fe& P, const fe& Q) {
+    const uint32_t a0 = a.v[0], a1 = a.v[1], a2 = a.v[2], a3 = a.v[3];
+    fe_cf c, b;
+    uint64_t W0 = (uint64_t)a0 * P.v[0];
+    W0 = fe_madc(a2, Q.v[0], W0, c); uint32_t c0 = fe_cnt0(c);
+    uint64_t W1 = (uint64_t)a0 * P.v[1];
+    W1 = fe_madc(a1, P.v[0], W1, c); uint32_t c1 = fe_cnt0(c);
+    W1 = fe_madc(a2, Q.v[1], W1, c); c1 = fe_cnt(c1, c);
+    W1 = fe_madc(a3, Q.v[0], W1, c); c1 = fe_cnt(c1, c);
+    uint64_t W2 = fe_madc(a0, P.v[2], FE_PAIR(c0, c1), c); uint32_t c2 = fe_cnt0(c);
+    W2 = fe_madc(a1, P.v[1], W2, c); c2 = fe_cnt(c2, c);
+    W2 = fe_madc(a2, Q.v[2], W2, c); c2 = fe_cnt(c2, c);
+    W2 = fe_madc(a3, Q.v[1], W2, c); c2 = fe_cnt(c2, c);
+    uint64_t W3 = (uint64_t)a0 * P.v[3];
+    W3 = fe_madc(a1, P.v[2], W3, c); uint32_t c3 = fe_cnt0(c);
+    W3 = fe_madc(a2, Q.v[3], W3, c); c3 = fe_cnt(c3, c);
+    W3 = fe_madc(a3, Q.v[2], W3, c); c3 = fe_cnt(c3, c);
+    uint64_t W4 = fe_madc(a1, P.v[3], FE_PAIR(c2, c3), c); uint32_t c4 = fe_cnt0(c);
+    W4 = fe_madc(a3, Q.v[3], W4, c); c4 = fe_cnt(c4, c);
+    uint32_t T0 = FE_LO(W0);
+    uint32_t T1 = fe_add_co(FE_HI(W0), FE_LO(W1), c);
+    uint32_t T2 = fe_addc_co(FE_HI(W1), FE_LO(W2), c, c);
+    uint32_t T3 = fe_addc_co(FE_HI(W2), FE_LO(W3), c, c);
+    uint32_t T4 = fe_addc_co(FE_HI(W3), FE_LO(W4), c, c);
+    uint32_t T5 = fe_addc0_co(FE_HI(W4), c, c);
+    uint32_t T6 = fe_cnt(c4, c);                              // 0 or 1: the sum is below 2^193
+    // fold H = T6:T5:T4 (< 2^65): r = L + ((H * K) << 32) - H
+    uint64_t P4 = (uint64_t)T4 * FE_K, P5 = (uint64_t)T5 * FE_K;
+    uint32_t X1 = fe_add_co(FE_HI(P4), FE_LO(P5), c);
+    uint32_t X2 = fe_cnt(fe_mad24(T6, FE_K, FE_HI(P5)), c);
+    uint32_t u1 = fe_add_co(T1, FE_LO(P4), c);
+    uint32_t u2 = fe_addc_co(T2, X1, c, c);
+    uint32_t u3 = fe_addc_co(T3, X2, c, c);
+    uint32_t r0 = fe_sub_co(T0, T4, b);
+    uint32_t r1 = fe_subb_co(u1, T5, b, b);
+    uint32_t r2 = fe_subb_co(u2, T6, b, b);
+    uint32_t r3 = fe_subb0_co(u3, b, b);
+    return fe_final(r0, r1, r2, r3, c & ~b);                 // the value is below 2^128 + 2^111 < 2p
+}
+FE_HD fe fe_mul_tw(const fe& a, const fe_tw& w) { return fe_mul_tw(a, w.p, w.q); }
+// Q = w * 2^64 mod p (table construction; also on the fly where one multiplier serves several products)
+FE_HD fe fe_shift64(const fe& w) {
+    uint32_t t[8] = {0, 0, w.v[0], w.v[1], w.v[2], w.v[3], 0, 0};
+    return fe_reduce8(t);
+}
+FE_HD fe_tw fe_tw_make(const fe& w) { fe_tw t; t.p = w; t.q = fe_shift64(w); return t; }
+
+#if defined(__HIP_DEVICE_COMPILE__)
 // ---- sums of products with ONE reduction ----------------------------------------------------------------------------------------
-// A dot product sum_i a_i * b_i accumulates the 256-bit partial products in the same even/odd 64-bit windows as fe_mul (every
-// accumulating mad counts its carry-out) and folds once at the end: 32 instructions per term + one reduction instead of a full
-// multiplication (89) and a modular addition (14) per term.  Up to 64 terms (the overflow limb stays below 2^7).
+// A dot product sum_i a_i * b_i accumulates the 256-bit partial products in even/odd 64-bit windows (every accumulating mad counts its
+// carry-out) and folds once at the end: 32 instructions per term + one reduction instead of a full multiplication and a modular
+// addition per term.  Up to 64 terms (the overflow limb stays below 2^7).
+__device__ __forceinline__ void fe_mac_c(uint64_t& acc, uint32_t& cnt, uint32_t a, uint32_t b) {
+    fe_cf c; acc = fe_madc(a, b, acc, c); cnt = fe_cnt(cnt, c);
+}
 struct fe_acc {
     uint64_t E0, E1, E2, E3, O0, O1, O2;              // windows at limbs 0, 2, 4, 6 and 1, 3, 5
     uint32_t cE0, cE1, cE2, cE3, cO0, cO1, cO2;       // 2^64 overflows of each window
@@ -263,67 +319,24 @@ __device__ __forceinline__ void fe_acc_add(fe_acc& A, const fe& a) {
     fe_mac_c(A.E0, A.cE0, a.v[0], 1u); fe_mac_c(A.O0, A.cO0, a.v[1], 1u); fe_mac_c(A.E1, A.cE1, a.v[2], 1u); fe_mac_c(A.O1, A.cO1, a.v[3], 1u);
 }
 __device__ __forceinline__ fe fe_acc_reduce(const fe_acc& A) {
-#define FE_LO(x) ((uint32_t)(x))
-#define FE_HI(x) ((uint32_t)((x) >> 32))
-    uint32_t t0, t1, t2, t3, t4, t5, t6, t7, t8, c, bw;
-    t0 = FE_LO(A.E0);
-    t1 = fe_addc(FE_HI(A.E0), FE_LO(A.O0), 0, &c);
-    t2 = fe_addc(FE_LO(A.E1), FE_HI(A.O0), c, &c);
-    t3 = fe_addc(FE_HI(A.E1), FE_LO(A.O1), c, &c);
-    t4 = fe_addc(FE_LO(A.E2), FE_HI(A.O1), c, &c);
-    t5 = fe_addc(FE_HI(A.E2), FE_LO(A.O2), c, &c);
-    t6 = fe_addc(FE_LO(A.E3), FE_HI(A.O2), c, &c);
-    t7 = fe_addc(FE_HI(A.E3), 0, c, &c);
-    t8 = c;
-    t2 = fe_addc(t2, A.cE0, 0, &c);
-    t3 = fe_addc(t3, A.cO0, c, &c);
-    t4 = fe_addc(t4, A.cE1, c, &c);
-    t5 = fe_addc(t5, A.cO1, c, &c);
-    t6 = fe_addc(t6, A.cE2, c, &c);
-    t7 = fe_addc(t7, A.cO2, c, &c);
-    t8 = t8 + A.cE3 + c;
-    // fold 1: v = lo + ((hi * K) << 32) - hi, hi = t8:t7:t6:t5:t4 < 2^135
-    uint64_t P0 = (uint64_t)t4 * FE_K, P1 = (uint64_t)t5 * FE_K, P2 = (uint64_t)t6 * FE_K, P3 = (uint64_t)t7 * FE_K, P4 = (uint64_t)t8 * FE_K;
-    uint32_t u1, u2, u3, u4, u5;
-    u1 = fe_addc(t1, FE_LO(P0), 0, &c);
-    u2 = fe_addc(t2, FE_LO(P1), c, &c);
-    u3 = fe_addc(t3, FE_LO(P2), c, &c);
-    u4 = fe_addc(FE_LO(P3), 0, c, &c);
-    u5 = FE_LO(P4) + c;                                  // P4 < 2^21: no carry out
-    u2 = fe_addc(u2, FE_HI(P0), 0, &c);
-    u3 = fe_addc(u3, FE_HI(P1), c, &c);
-    u4 = fe_addc(u4, FE_HI(P2), c, &c);
-    u5 = u5 + FE_HI(P3) + c;                             // < 2^22 + 2^14
-    uint32_t v0, v1, v2, v3, v4, v5;
-    v0 = fe_subb(t0, t4, 0, &bw);
-    v1 = fe_subb(u1, t5, bw, &bw);
-    v2 = fe_subb(u2, t6, bw, &bw);
-    v3 = fe_subb(u3, t7, bw, &bw);
-    v4 = fe_subb(u4, t8, bw, &bw);
-    v5 = u5 - bw;
-    // fold 2: y = v_lo + ((V * K) << 32) - V, V = v5:v4 < 2^54, V * K = w0 + x0 * 2^32 + x1 * 2^64
-    uint64_t w = (uint64_t)v4 * FE_K;
-    uint64_t x = (uint64_t)v5 * FE_K + FE_HI(w);
-    uint32_t y0, y1, y2, y3, y4;
-    y1 = fe_addc(v1, FE_LO(w), 0, &c);
-    y2 = fe_addc(v2, FE_LO(x), c, &c);
-    y3 = fe_addc(v3, FE_HI(x), c, &c);
-    y4 = c;
-    y0 = fe_subb(v0, v4, 0, &bw);
-    y1 = fe_subb(y1, v5, bw, &bw);
-    y2 = fe_subb(y2, 0, bw, &bw);
-    y3 = fe_subb(y3, 0, bw, &bw);
-    y4 = y4 - bw;
-    // fold 3 + canonical form (see fe_mul_gfx950)
-    uint32_t z0, z1, z2, z3;
-    z0 = fe_addc(y0, FE_C0, 0, &c);
-    z1 = fe_addc(y1, FE_C1, c, &c);
-    z2 = fe_addc(y2, 0, c, &c);
-    z3 = fe_addc(y3, 0, c, &c);
-    c |= y4;
-#undef FE_LO
-#undef FE_HI
-    return c ? fe_make(z0, z1, z2, z3) : fe_make(y0, y1, y2, y3);
+    fe_cf c;
+    uint32_t t0 = FE_LO(A.E0);
+    uint32_t t1 = fe_add_co(FE_HI(A.E0), FE_LO(A.O0), c);
+    uint32_t t2 = fe_addc_co(FE_LO(A.E1), FE_HI(A.O0), c, c);
+    uint32_t t3 = fe_addc_co(FE_HI(A.E1), FE_LO(A.O1), c, c);
+    uint32_t t4 = fe_addc_co(FE_LO(A.E2), FE_HI(A.O1), c, c);
+    uint32_t t5 = fe_addc_co(FE_HI(A.E2), FE_LO(A.O2), c, c);
+    uint32_t t6 = fe_addc_co(FE_LO(A.E3), FE_HI(A.O2), c, c);
+    uint32_t t7 = fe_addc0_co(FE_HI(A.E3), c, c);
+    uint32_t t8 = fe_cnt(A.cE3, c);
+    t2 = fe_add_co(t2, A.cE0, c);
+    t3 = fe_addc_co(t3, A.cO0, c, c);
+    t4 = fe_addc_co(t4, A.cE1, c, c);
+    t5 = fe_addc_co(t5, A.cO1, c, c);
+    t6 = fe_addc_co(t6, A.cE2, c, c);
+    t7 = fe_addc_co(t7, A.cO2, c, c);
+    t8 = fe_cnt(t8, c);
+    return fe_fold9(t0, t1, t2, t3, t4, t5, t6, t7, t8, true);
 }
 #else
 // host pass of the same translation units: same interface, plain modular arithmetic (never on a hot path)
@@ -334,9 +347,11 @@ FE_HD void fe_acc_add(fe_acc& A, const fe& a) { A.sum = fe_add(A.sum, a); }
 FE_HD fe fe_acc_reduce(const fe_acc& A) { return A.sum; }
 #endif
 
+// On the device, and in the host-emulated test build (FE_EMULATE_GFX950: the limb-level dataflow on plain integers), the windowed
+// formulation; elsewhere on the host the portable one (tables).
 FE_HD fe fe_mul(const fe& a, const fe& b) {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(FE_PORTABLE_MUL)
-    return fe_mul_gfx950(a, b);
+#if (defined(__HIP_DEVICE_COMPILE__) || defined(FE_EMULATE_GFX950)) && !defined(FE_PORTABLE_MUL)
+    return fe_mul_wide(a, b);
 #else
     return fe_mul_portable(a, b);
 #endif
