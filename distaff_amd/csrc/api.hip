@@ -27,6 +27,12 @@ static std::vector<fe> h_powers(fe base, size_t count) {
     for (size_t i = 0; i < count; i++) { v[i] = fe_from_u128(cur); cur = hf_mul(cur, b); }
     return v;
 }
+static std::vector<fe_tw> h_powers_tw(fe base, size_t count) {     // table pairs (w, w * 2^64 mod p) of the powers
+    std::vector<fe_tw> v(count);
+    u128 b = fe_to_u128(base), cur = 1;
+    for (size_t i = 0; i < count; i++) { v[i] = fe_tw_make(fe_from_u128(cur)); cur = hf_mul(cur, b); }
+    return v;
+}
 static fe h_inv(fe a) { return fe_from_u128(hf_pow(fe_to_u128(a), FIELD_P - 2)); }
 static fe h_pow(fe a, u128 e) { return fe_from_u128(hf_pow(fe_to_u128(a), e)); }
 
@@ -136,7 +142,7 @@ static int ctx_init(dst_ctx* c) {
         const bool reg_ok = !three && pl.log_n2 >= 6 && pl.log_n1 <= 12;
         pl.reg_a = reg_ok && pl.log_n1 >= 12; pl.reg_b = reg_ok && pl.log_n2 >= 12;      // 4096-point tiles: the LDS family is down to one column (16-byte segments)
         if (force && !strcmp(force, "reg") && reg_ok) pl.reg_a = pl.reg_b = true;
-        if (force && !strcmp(force, "lds")) pl.reg_a = pl.reg_b = false;
+        if (force && !strcmp(force, "lds")) { pl.reg_a = pl.reg_a && pl.log_n1 >= 12; pl.reg_b = pl.reg_b && pl.log_n2 >= 12; }   // a 4096-point coset DIT (64 KiB tile + 128 KiB of twiddle pairs) does not fit LDS
     }
     {
         fe w16 = h_root_of_unity(4), w16i = h_inv(w16);
@@ -155,23 +161,24 @@ static int ctx_init(dst_ctx* c) {
     if ((r = dev_upload(c, &c->itw_hi, h_powers(h_pow(wN_inv, (u128)1 << c->tw_lo_bits), (size_t)1 << hi_bits)))) return r;
     const uint32_t log_second = pl.log_n3 ? pl.log_n2 - pl.log_n3 : pl.log_n2;        // three-pass: w2* serve the middle pass
     fe w1 = h_root_of_unity(pl.log_n1), w2 = h_root_of_unity(log_second);
-    if ((r = dev_upload(c, &c->w1f, h_powers(w1, (size_t)1 << (pl.log_n1 - 1))))) return r;
-    if ((r = dev_upload(c, &c->w2f, h_powers(w2, (size_t)1 << (log_second - 1))))) return r;
-    if ((r = dev_upload(c, &c->w1i, h_powers(h_inv(w1), (size_t)1 << (pl.log_n1 - 1))))) return r;
-    if ((r = dev_upload(c, &c->w2i, h_powers(h_inv(w2), (size_t)1 << (log_second - 1))))) return r;
+    if ((r = dev_upload(c, &c->w1f, h_powers_tw(w1, (size_t)1 << (pl.log_n1 - 1))))) return r;
+    if ((r = dev_upload(c, &c->w2f, h_powers_tw(w2, (size_t)1 << (log_second - 1))))) return r;
+    if ((r = dev_upload(c, &c->w1i, h_powers_tw(h_inv(w1), (size_t)1 << (pl.log_n1 - 1))))) return r;
+    if ((r = dev_upload(c, &c->w2i, h_powers_tw(h_inv(w2), (size_t)1 << (log_second - 1))))) return r;
     if (pl.log_n3) {
         fe w3 = h_root_of_unity(pl.log_n3);
-        if ((r = dev_upload(c, &c->w3f, h_powers(w3, (size_t)1 << (pl.log_n3 - 1))))) return r;
-        if ((r = dev_upload(c, &c->w3i, h_powers(h_inv(w3), (size_t)1 << (pl.log_n3 - 1))))) return r;
+        if ((r = dev_upload(c, &c->w3f, h_powers_tw(w3, (size_t)1 << (pl.log_n3 - 1))))) return r;
+        if ((r = dev_upload(c, &c->w3i, h_powers_tw(h_inv(w3), (size_t)1 << (pl.log_n3 - 1))))) return r;
         if ((r = dev_alloc(c, &c->tw4_row_fwd, (size_t)1 << pl.log_n2))) return r;
         if ((r = dev_alloc(c, &c->tw4_row_inv, (size_t)1 << pl.log_n2))) return r;
     }
-    if ((r = dev_upload(c, &c->prescale, h_powers(h_root_of_unity(c->log_b + pl.log_n1), (size_t)1 << (c->log_b + pl.log_n1))))) return r;
+    if ((r = dev_upload(c, &c->prescale, h_powers_tw(h_root_of_unity(c->log_b + pl.log_n1), (size_t)1 << (c->log_b + pl.log_n1))))) return r;
     if ((r = dev_alloc(c, &c->tw4_lde, c->Bc * c->n))) return r;
     if ((r = dev_alloc(c, &c->tw4_fwd, c->n))) return r;
     if ((r = dev_alloc(c, &c->tw4_inv, c->n))) return r;
     if ((r = dev_upload(c, &c->periodic, build_periodic_table()))) return r;
     c->n_inv = fe_from_u128(hf_pow((u128)c->n, FIELD_P - 2));
+    c->n_inv_tw = fe_tw_make(c->n_inv);
     c->eight_inv = fe_from_u128(hf_pow(8, FIELD_P - 2));
     c->four_inv = fe_from_u128(hf_pow(4, FIELD_P - 2));
     c->iota = h_root_of_unity(2);

@@ -76,18 +76,20 @@ struct dst_ctx {
     fe *tw_lo = nullptr, *tw_hi = nullptr;       // w_N^t, two-level: e = (hi << lo_bits) | lo
     fe *itw_lo = nullptr, *itw_hi = nullptr;     // w_N^-t
     uint32_t tw_lo_bits = 0;
-    fe *w1f = nullptr, *w2f = nullptr, *w1i = nullptr, *w2i = nullptr;   // stage twiddles w_{n1}^t, w_{n2}^t and inverses
-    fe *prescale = nullptr;                      // w_{B*n1}^t, t < B*n1
+    // every twiddle of the LDS-family transforms is a table pair (w, w * 2^64 mod p), see fe_mul_tw (fe.h)
+    fe_tw *w1f = nullptr, *w2f = nullptr, *w1i = nullptr, *w2i = nullptr;   // stage twiddles w_{n1}^t, w_{n2}^t and inverses
+    fe_tw *prescale = nullptr;                   // w_{B*n1}^t, t < B*n1
     // four-step twiddles of pass A as full tables in output order [k1][m2] (one multiplication per element instead of a two-level
     // lookup + two; the extra 16 B/element read is free: the pass runs at a tenth of the HBM bandwidth)
-    fe *tw4_lde = nullptr;                       // [Bc][n]: w_N^(m2 * (B*k1 + j)), local cosets j
-    fe *tw4_fwd = nullptr, *tw4_inv = nullptr;   // [n]: w_n^(m2*k1) and its inverse
-    fe *tw4_row_fwd = nullptr, *tw4_row_inv = nullptr;   // three-pass plans: [n2] twiddles w_{n2}^(k2*m3) of the middle pass and inverse
-    fe *w3f = nullptr, *w3i = nullptr;           // three-pass plans: stage twiddles of the last pass (length n3)
+    fe_tw *tw4_lde = nullptr;                    // [Bc][n]: w_N^(m2 * (B*k1 + j)), local cosets j
+    fe_tw *tw4_fwd = nullptr, *tw4_inv = nullptr;   // [n]: w_n^(m2*k1) and its inverse
+    fe_tw *tw4_row_fwd = nullptr, *tw4_row_inv = nullptr;   // three-pass plans: [n2] twiddles w_{n2}^(k2*m3) of the middle pass and inverse
+    fe_tw *w3f = nullptr, *w3i = nullptr;        // three-pass plans: stage twiddles of the last pass (length n3)
     fe *tmp2 = nullptr;                          // three-pass plans: second staging buffer
     fe *periodic = nullptr;                      // [128][23] extended Rescue round constants + cycle masks
     void *air_consts = nullptr;                  // AirConsts (Rescue MDS matrices) in device memory
     fe c16f[8], c16i[8];                         // w_16^j and w_16^-j, j < 8 (passed to the NTT kernels by value)
+    fe_tw n_inv_tw{};                            // 1/n as a table pair
     fe n_inv{}, eight_inv{}, four_inv{}, iota{}, g_trace{}, x_last{};   // 1/n, 1/8, 1/4, w_N^(N/4), w_n, w_n^(n-1)
 
     // data (device)

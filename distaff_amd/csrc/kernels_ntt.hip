@@ -20,29 +20,28 @@
 #include "ctx.h"
 #include <type_traits>
 
-#define NTT_THREADS 512
+#define NTT_TILE_ELEMS 4096      // elements of an LDS tile (64 KiB); a workgroup of 512 lanes holds 8 per lane, one of 1024 lanes 4
 
 struct NttArgs {
     const fe* src; fe* dst;
     size_t src_col_stride, src_coset_stride;   // elements
     size_t dst_col_stride, dst_coset_stride;
-    const fe* stage_tw;        // w_len^t, t < len/2 (forward or inverse)
-    const fe* tw_lo; const fe* tw_hi;           // two-level table of the domain generator (forward or inverse, maybe pre-scaled)
-    const fe* prescale;        // w_{B*n1}^t or nullptr
-    const fe* tw4;             // four-step twiddles in output order [coset][k1][m2] (coset stride tw4_coset_stride) or nullptr
+    const fe_tw* stage_tw;     // w_len^t, t < len/2 (forward or inverse), as table pairs
+    const fe_tw* prescale;     // w_{B*n1}^t or nullptr
+    const fe_tw* tw4;          // four-step twiddles in output order [coset][k1][m2] (coset stride tw4_coset_stride)
     size_t tw4_coset_stride;
-    uint32_t log_n1, log_n2, tile /* log2 of the tile width */, lo_bits, log_N, log_b;
-    uint32_t j0;               // global index of the first local coset (0 when `coset_twiddle` is off)
-    uint32_t coset_twiddle;    // 1: four-step twiddle includes the coset offset j (LDE), 0: plain transform
+    uint32_t log_n1, log_n2, tile /* log2 of the tile width */, log_N, log_b;
+    uint32_t j0;               // global index of the first local coset
     uint32_t has_scale;        // 1: multiply the result by `scale` (1/n of inverse transforms)
     uint32_t tiles_per_block;  // adjacent tiles one workgroup walks through
-    uint32_t debug;            // DISTAFF_NTT_DEBUG ablation bits (timing experiments only): 1 no pre-scale, 2 no four-step twiddle
+    uint32_t debug;            // DISTAFF_NTT_DEBUG ablation bits (timing experiments only): 2 no four-step twiddle
     // pass B addressing (two-pass plans: row stride n2, frequency stride n1, no batch); three-pass plans run the last pass once per
-    // middle frequency k2 (batch index = low bits of blockIdx.x): source rows (k1, k2, .) and destination k1 + n1 * (k2 + n2' * k3)
+    // middle frequency k2 (batch index = low bits of the tile-group index): source rows (k1, k2, .) and destination k1 + n1 * (k2 + n2' * k3)
     size_t src_row_stride, dst_k_stride, src_batch_stride, dst_batch_stride;
     uint32_t batch_log;
     uint32_t dit;              // pass A of an extension: coset DIT (pre-scale folded into the stage twiddles, taken from `prescale`)
-    fe scale;
+    uint32_t groups, cosets, cols;   // extent of the linear block index: tile groups x cosets x columns (registers)
+    fe_tw scale;
 };
 
 __device__ __forceinline__ fe load_fe(const fe* p) { return *p; }
@@ -61,39 +60,54 @@ __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
 }
 
+// Linear block index -> (tile group, local coset, column).  The COLUMN (register) is the fastest dimension and the blocks that
+// differ only in it carry the same index modulo 8, i.e. run on the same XCD at the same time (block b runs on XCD b % 8): the
+// four-step twiddles of a (coset, tile) - the same for every register - are fetched from HBM once and served to the other
+// registers by that XCD's L2.  (Round 1 had the register as the slowest grid dimension: the table was streamed once per register.)
+__device__ __forceinline__ void ntt_block(const NttArgs& a, uint32_t& group, uint32_t& jl, uint32_t& col) {
+    const uint32_t b = blockIdx.x, units = a.groups * a.cosets;
+    uint32_t u;
+    if ((units & 7u) == 0) { const uint32_t s = b >> 3; col = s % a.cols; u = (s / a.cols) * 8u + (b & 7u); }
+    else { col = b % a.cols; u = b / a.cols; }
+    jl = u / a.groups; group = u % a.groups;
+}
+
+__device__ __forceinline__ uint32_t lds_slot(uint32_t i, uint32_t t, uint32_t log_t) { return (i << log_t) + t; }
+
 // in-LDS DIF over the first index of L[len][T]; output position r holds frequency bitrev(r).  W: stage twiddles w_len^t in LDS.
 // Two radix-2 stages are fused into one radix-4 round (one LDS round trip, one barrier and one index computation per two
 // stages; the arithmetic is exactly the two radix-2 stages); an odd stage count ends with a plain radix-2 stage.
-__device__ __forceinline__ void lds_ntt_dif(fe* L, const fe* W, uint32_t log_len, uint32_t log_t) {
+template <int THREADS>
+__device__ __forceinline__ void lds_ntt_dif(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s_from, uint32_t s_to) {
     const uint32_t T = 1u << log_t;
-    uint32_t s = 1;
-    for (; s + 1 <= log_len; s += 2) {
+    uint32_t s = s_from;                             // stages [s_from, s_to), s_from odd
+    for (; s + 1 <= log_len && s < s_to; s += 2) {
         const uint32_t ld = log_len - s;             // log2 of the first stage's butterfly distance d
         const uint32_t d = 1u << ld, hd = d >> 1;
         const bool last = (s + 1 == log_len);        // second stage has distance 1: its twiddles are 1
-        for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 2) * T; w += NTT_THREADS) {
+        for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 2) * T; w += THREADS) {
             const uint32_t t = w & (T - 1), q = w >> log_t;
             const uint32_t pos = q & (hd - 1), blk = q >> (ld - 1);
             const uint32_t i0 = (blk << (ld + 1)) + pos;
-            fe* p0 = L + ((i0 << log_t) + t); fe* p1 = p0 + (hd << log_t); fe* p2 = p0 + (d << log_t); fe* p3 = p2 + (hd << log_t);
+            fe* p0 = L + lds_slot(i0, t, log_t); fe* p1 = L + lds_slot(i0 + hd, t, log_t); fe* p2 = L + lds_slot(i0 + d, t, log_t); fe* p3 = L + lds_slot(i0 + d + hd, t, log_t);
             const fe x0 = *p0, x1 = *p1, x2 = *p2, x3 = *p3;
             // stage s: (x0, x2) with w_2d^pos, (x1, x3) with w_2d^(pos + d/2)
             fe a0 = fe_add(x0, x2), a2 = fe_sub(x0, x2);
             fe a1 = fe_add(x1, x3), a3 = fe_sub(x1, x3);
-            if (pos != 0) a2 = fe_mul(a2, W[pos << (s - 1)]);
-            a3 = fe_mul(a3, W[(pos + hd) << (s - 1)]);
+            if (hd != 1) a2 = fe_mul_tw(a2, W[pos << (s - 1)]);          // hd == 1: pos == 0 in every lane
+            a3 = fe_mul_tw(a3, W[(pos + hd) << (s - 1)]);
             // stage s + 1: (a0, a1) and (a2, a3) with w_d^pos
             fe y0 = fe_add(a0, a1), y1 = fe_sub(a0, a1);
             fe y2 = fe_add(a2, a3), y3 = fe_sub(a2, a3);
-            if (!last && pos != 0) { const fe tw = W[pos << s]; y1 = fe_mul(y1, tw); y3 = fe_mul(y3, tw); }
+            if (!last && hd != 1) { const fe_tw tw = W[pos << s]; y1 = fe_mul_tw(y1, tw); y3 = fe_mul_tw(y3, tw); }
             *p0 = y0; *p1 = y1; *p2 = y2; *p3 = y3;
         }
         __syncthreads();
     }
-    if (s == log_len) {                              // distance-1 stage, no twiddles
-        for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 1) * T; w += NTT_THREADS) {
+    if (s == log_len && s < s_to) {                  // distance-1 stage, no twiddles
+        for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 1) * T; w += THREADS) {
             const uint32_t t = w & (T - 1), q = w >> log_t;
-            fe* p0 = L + (((q << 1) << log_t) + t); fe* p1 = p0 + T;
+            fe* p0 = L + lds_slot(q << 1, t, log_t); fe* p1 = L + lds_slot((q << 1) + 1, t, log_t);
             const fe a = *p0, b = *p1;
             *p0 = fe_add(a, b); *p1 = fe_sub(a, b);
         }
@@ -106,30 +120,31 @@ __device__ __forceinline__ void lds_ntt_dif(fe* L, const fe* W, uint32_t log_len
 // odd indices are coset transforms with g^2, so the stage that merges blocks of size B multiplies by g^(len/B) * w_B^k: the
 // pre-scale by g^m costs nothing -- it is part of twiddles that had to be applied anyway.  W holds them per stage at offset
 // B/2 - 1 (len - 1 entries for the workgroup's coset).  Two stages per LDS round trip, as in lds_ntt_dif.
-__device__ __forceinline__ void lds_ntt_dit(fe* L, const fe* W, uint32_t log_len, uint32_t log_t) {
+template <int THREADS>
+__device__ __forceinline__ void lds_ntt_dit(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s_from, uint32_t s_to) {
     const uint32_t T = 1u << log_t;
-    uint32_t s = 1;
-    for (; s + 1 <= log_len; s += 2) {
+    uint32_t s = s_from;                             // stages [s_from, s_to), s_from odd
+    for (; s + 1 <= log_len && s < s_to; s += 2) {
         const uint32_t B = 1u << s, half = B >> 1;                     // first stage merges blocks of size B / 2 into B, second B into 2B
-        for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 2) * T; w += NTT_THREADS) {
+        for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 2) * T; w += THREADS) {
             const uint32_t t = w & (T - 1), q = w >> log_t;
             const uint32_t k = q & (half - 1), base = (q >> (s - 1)) << (s + 1);
-            fe* p0 = L + (((base + k) << log_t) + t); fe* p1 = p0 + (half << log_t); fe* p2 = p0 + (B << log_t); fe* p3 = p2 + (half << log_t);
-            const fe tb = W[half - 1 + k];
-            const fe x0 = *p0, x1 = fe_mul(*p1, tb), x2 = *p2, x3 = fe_mul(*p3, tb);
+            fe* p0 = L + lds_slot(base + k, t, log_t); fe* p1 = L + lds_slot(base + k + half, t, log_t); fe* p2 = L + lds_slot(base + k + B, t, log_t); fe* p3 = L + lds_slot(base + k + B + half, t, log_t);
+            const fe_tw tb = W[half - 1 + k];
+            const fe x0 = *p0, x1 = fe_mul_tw(*p1, tb), x2 = *p2, x3 = fe_mul_tw(*p3, tb);
             const fe a0 = fe_add(x0, x1), a1 = fe_sub(x0, x1);
-            const fe a2 = fe_mul(fe_add(x2, x3), W[B - 1 + k]), a3 = fe_mul(fe_sub(x2, x3), W[B - 1 + k + half]);
+            const fe a2 = fe_mul_tw(fe_add(x2, x3), W[B - 1 + k]), a3 = fe_mul_tw(fe_sub(x2, x3), W[B - 1 + k + half]);
             *p0 = fe_add(a0, a2); *p2 = fe_sub(a0, a2);
             *p1 = fe_add(a1, a3); *p3 = fe_sub(a1, a3);
         }
         __syncthreads();
     }
-    if (s == log_len) {                              // last single stage: blocks of len / 2 into len
+    if (s == log_len && s < s_to) {                  // last single stage: blocks of len / 2 into len
         const uint32_t half = 1u << (log_len - 1);
-        for (uint32_t w = threadIdx.x; w < half * T; w += NTT_THREADS) {
+        for (uint32_t w = threadIdx.x; w < half * T; w += THREADS) {
             const uint32_t t = w & (T - 1), k = w >> log_t;
-            fe* p0 = L + ((k << log_t) + t); fe* p1 = p0 + (half << log_t);
-            const fe u = *p0, v = fe_mul(*p1, W[half - 1 + k]);
+            fe* p0 = L + lds_slot(k, t, log_t); fe* p1 = L + lds_slot(k + half, t, log_t);
+            const fe u = *p0, v = fe_mul_tw(*p1, W[half - 1 + k]);
             *p0 = fe_add(u, v); *p1 = fe_sub(u, v);
         }
         __syncthreads();
@@ -141,106 +156,108 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
 // Both passes are persistent over `tiles_per_block` adjacent tiles: the tile's elements for the NEXT iteration are fetched from HBM
 // into registers before the butterfly stages of the current one start, so the HBM latency and most of the transfer overlap
 // with the arithmetic (measured: a block that loads, computes and stores in sequence pays HBM time + ALU time, not their maximum).
-// The stage twiddles live in LDS behind the tile, so the stages issue no global loads that would have to wait behind the prefetch.
-#define NTT_EPT 8      // elements per lane: tile elements (<= 4096) / NTT_THREADS
-
-// grid: (n2 / T / tiles_per_block, cosets, columns)
-__global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_a(NttArgs a, const fe* __restrict__ src_base, fe* __restrict__ dst_base) {
+// The stage twiddles live in LDS behind the tile as table pairs (32 bytes each), so the stages issue no global loads that would
+// have to wait behind the prefetch.  A 1024-point coset DIT needs 64 KiB of tile + 32 KiB of twiddles: that instance runs as ONE
+// workgroup of 1024 lanes per CU (4 elements per lane); everything that fits 80 KiB runs as two workgroups of 512 lanes (8 per lane).
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS, 4) ntt_pass_a(NttArgs a, const fe* __restrict__ src_base, fe* __restrict__ dst_base) {
+    constexpr int EPT = NTT_TILE_ELEMS / THREADS;
     fe* L = reinterpret_cast<fe*>(ntt_smem);
-    const uint32_t log_t = a.tile, T = 1u << log_t, n1 = 1u << a.log_n1, n2 = 1u << a.log_n2;
-    fe* TW = L + n1 * T;
-    const uint32_t jl = blockIdx.y, jg = a.j0 + jl;
-    const fe* __restrict__ src = src_base + (size_t)blockIdx.z * a.src_col_stride + (size_t)jl * a.src_coset_stride;
-    fe* __restrict__ dst = dst_base + (size_t)blockIdx.z * a.dst_col_stride + (size_t)jl * a.dst_coset_stride;
+    const uint32_t log_t = a.tile, T = 1u << log_t, n1 = 1u << a.log_n1;
+    fe_tw* TW = reinterpret_cast<fe_tw*>(L + n1 * T);
+    uint32_t group, jl, col;
+    ntt_block(a, group, jl, col);
+    const uint32_t jg = a.j0 + jl;
+    const fe* __restrict__ src = src_base + (size_t)col * a.src_col_stride + (size_t)jl * a.src_coset_stride;
+    fe* __restrict__ dst = dst_base + (size_t)col * a.dst_col_stride + (size_t)jl * a.dst_coset_stride;
     const uint32_t pmask = (1u << (a.log_b + a.log_n1)) - 1u;
-    const uint64_t nmask = (1ull << a.log_N) - 1ull;
     if (a.dit) {
         // stage twiddles of this coset: g^(n1/B) * w_B^k = w_{B_lde*n1}^((j + B_lde*k) * n1/B) straight from the pre-scale table
-        for (uint32_t i = threadIdx.x; i + 1 < n1; i += NTT_THREADS) {
+        for (uint32_t i = threadIdx.x; i + 1 < n1; i += THREADS) {
             const uint32_t lb = 31u - (uint32_t)__clz(i + 1), k = i + 1 - (1u << lb);         // entry i: block size B = 2^(lb+1), index k
             TW[i] = a.prescale[((jg + (k << a.log_b)) << (a.log_n1 - lb - 1)) & pmask];
         }
     } else
-    for (uint32_t i = threadIdx.x; i < n1 / 2; i += NTT_THREADS) TW[i] = a.stage_tw[i];
-    const bool scaled = !a.dit && a.prescale != nullptr && jg != 0 && !(a.debug & 1u);
+    for (uint32_t i = threadIdx.x; i < n1 / 2; i += THREADS) TW[i] = a.stage_tw[i];
+    const bool scaled = !a.dit && a.prescale != nullptr && jg != 0;
     fe pre0 = fe_zero(), pre1 = fe_zero(), pre2 = fe_zero(), pre3 = fe_zero(), pre4 = fe_zero(), pre5 = fe_zero(), pre6 = fe_zero(), pre7 = fe_zero();
     const uint32_t count = n1 * T;
-#define NTT_FETCH_A1(e, var, m2_0) { uint32_t idx = threadIdx.x + (e) * NTT_THREADS; idx = idx < count ? idx : 0u; /* branch-free: a lane past the tile re-reads element 0 */ var = src[((size_t)(idx >> log_t) << a.log_n2) + (m2_0) + (idx & (T - 1))]; }
-#define NTT_FETCH_A(tile) { const uint32_t f0 = (tile) * T; NTT_FETCH_A1(0, pre0, f0) NTT_FETCH_A1(1, pre1, f0) NTT_FETCH_A1(2, pre2, f0) NTT_FETCH_A1(3, pre3, f0) \
-                                                        NTT_FETCH_A1(4, pre4, f0) NTT_FETCH_A1(5, pre5, f0) NTT_FETCH_A1(6, pre6, f0) NTT_FETCH_A1(7, pre7, f0) }
-    const uint32_t jtw = a.coset_twiddle ? jg : 0u;
-    const fe* __restrict__ tw4 = a.tw4 ? a.tw4 + (size_t)jl * a.tw4_coset_stride : nullptr;
-    const uint32_t tile0 = blockIdx.x * a.tiles_per_block;
+    // named registers, not an array: the prefetched elements must stay in VGPRs across the butterfly stages.  Branch-free fetch: a
+    // lane past the tile re-reads element 0.
+#define NTT_EACH(M) { M(0, pre0) M(1, pre1) M(2, pre2) M(3, pre3) M(4, pre4) M(5, pre5) M(6, pre6) M(7, pre7) }
+#define NTT_FETCH_A1(e, var) if constexpr ((e) < EPT) { uint32_t idx = threadIdx.x + (e) * THREADS; idx = idx < count ? idx : 0u; var = src[((size_t)(idx >> log_t) << a.log_n2) + f0 + (idx & (T - 1))]; }
+#define NTT_FETCH_A(tile) { const uint32_t f0 = (tile) * T; NTT_EACH(NTT_FETCH_A1) }
+    const fe_tw* __restrict__ tw4 = a.tw4 + (size_t)jl * a.tw4_coset_stride;
+    const uint32_t tile0 = group * a.tiles_per_block;
     NTT_FETCH_A(tile0)
     for (uint32_t it = 0; it < a.tiles_per_block; it++) {
         const uint32_t m2_0 = (tile0 + it) * T;
         __syncthreads();                                   // the previous tile has left LDS (and TW is complete)
-        // the coset pre-scale depends on the row m1 of an element only; the table is small and stays in L2
-#define NTT_PUT_A(e, var) { const uint32_t idx = threadIdx.x + (e) * NTT_THREADS; if (idx < count) { if (a.dit) L[((__brev(idx >> log_t) >> (32 - a.log_n1)) << log_t) + (idx & (T - 1))] = var; else L[idx] = scaled ? fe_mul(var, a.prescale[(jg * (idx >> log_t)) & pmask]) : var; } }
-        NTT_PUT_A(0, pre0) NTT_PUT_A(1, pre1) NTT_PUT_A(2, pre2) NTT_PUT_A(3, pre3) NTT_PUT_A(4, pre4) NTT_PUT_A(5, pre5) NTT_PUT_A(6, pre6) NTT_PUT_A(7, pre7)
+        // DISTAFF_NTT_DIF: pre-scale + DIF instead of the coset DIT
+#define NTT_PUT_A(e, var) if constexpr ((e) < EPT) { const uint32_t idx = threadIdx.x + (e) * THREADS; if (idx < count) { if (a.dit) L[lds_slot(__brev(idx >> log_t) >> (32 - a.log_n1), idx & (T - 1), log_t)] = var; else L[lds_slot(idx >> log_t, idx & (T - 1), log_t)] = scaled ? fe_mul_tw(var, a.prescale[(jg * (idx >> log_t)) & pmask]) : var; } }
+        NTT_EACH(NTT_PUT_A)
 #undef NTT_PUT_A
         __syncthreads();
         if (it + 1 < a.tiles_per_block) NTT_FETCH_A(tile0 + it + 1)
-        if (a.dit) lds_ntt_dit(L, TW, a.log_n1, log_t); else lds_ntt_dif(L, TW, a.log_n1, log_t);
-        // read-out in batches of four elements per lane: the four twiddle loads are in flight together
-        for (uint32_t base = 0; base < count; base += 4 * NTT_THREADS) {
-            fe v[4], w[4]; uint32_t k1s[4], m2s[4]; bool ok[4], scale[4];
-            static_for<0, 4>([&](auto q_) {
+        if (a.dit) lds_ntt_dit<THREADS>(L, TW, a.log_n1, log_t, 1u, a.log_n1 + 1u); else lds_ntt_dif<THREADS>(L, TW, a.log_n1, log_t, 1u, a.log_n1 + 1u);
+        // read-out in batches of RB elements per lane: the twiddle loads of a batch are in flight together (the 512-lane instance also
+        // holds eight prefetched elements: a batch of four would spill).  Measured alternatives that did not pay: requesting the
+        // twiddles before the last round (spills), a bank-conflict-free permutation of the LDS slots, rounds without workgroup barriers.
+        constexpr int RB = THREADS == 512 ? 2 : 4;
+        for (uint32_t base = 0; base < count; base += RB * THREADS) {
+            fe v[RB]; fe_tw w[RB]; uint32_t k1s[RB], m2s[RB]; bool ok[RB];
+            static_for<0, RB>([&](auto q_) {
                 constexpr int q = decltype(q_)::value;
-                uint32_t idx = base + q * NTT_THREADS + threadIdx.x;
+                uint32_t idx = base + q * THREADS + threadIdx.x;
                 ok[q] = idx < count;
                 idx = ok[q] ? idx : 0u;
                 const uint32_t t = idx & (T - 1), r = idx >> log_t;
                 k1s[q] = a.dit ? r : __brev(r) >> (32 - a.log_n1);        // DIT leaves the tile in natural order
                 m2s[q] = m2_0 + t;
                 v[q] = L[idx];
-                if (a.debug & 2u) { scale[q] = false; w[q] = fe_one(); }
-                else if (tw4 != nullptr) { scale[q] = (k1s[q] | jtw) != 0 && m2s[q] != 0; w[q] = tw4[((size_t)k1s[q] << a.log_n2) + m2s[q]]; }
-                else {
-                    const uint64_t e = ((uint64_t)m2s[q] * (((uint64_t)k1s[q] << a.log_b) + jtw)) & nmask;
-                    scale[q] = e != 0; w[q] = dom_pow(a.tw_lo, a.tw_hi, a.lo_bits, e);
-                }
+                w[q] = tw4[((size_t)k1s[q] << a.log_n2) + m2s[q]];
             });
-            static_for<0, 4>([&](auto q_) {
+            static_for<0, RB>([&](auto q_) {
                 constexpr int q = decltype(q_)::value;
-                if (ok[q]) dst[((size_t)k1s[q] << a.log_n2) + m2s[q]] = scale[q] ? fe_mul(v[q], w[q]) : v[q];
+                if (ok[q]) dst[((size_t)k1s[q] << a.log_n2) + m2s[q]] = (a.debug & 2u) ? v[q] : fe_mul_tw(v[q], w[q]);
             });
         }
     }
 }
 
-// grid: (n1 / T / tiles_per_block, cosets, columns)
-__global__ void __launch_bounds__(NTT_THREADS, 4) ntt_pass_b(NttArgs a, const fe* __restrict__ src_base, fe* __restrict__ dst_base) {
+template <int THREADS>
+__global__ void __launch_bounds__(THREADS, 4) ntt_pass_b(NttArgs a, const fe* __restrict__ src_base, fe* __restrict__ dst_base) {
+    constexpr int EPT = NTT_TILE_ELEMS / THREADS;
     fe* L = reinterpret_cast<fe*>(ntt_smem);
-    const uint32_t log_t = a.tile, T = 1u << log_t, n1 = 1u << a.log_n1, n2 = 1u << a.log_n2;
-    fe* TW = L + n2 * T;
-    const uint32_t jl = blockIdx.y;
-    const uint32_t batch = blockIdx.x & ((1u << a.batch_log) - 1u), group = blockIdx.x >> a.batch_log;
-    const fe* __restrict__ src = src_base + (size_t)blockIdx.z * a.src_col_stride + (size_t)jl * a.src_coset_stride + (size_t)batch * a.src_batch_stride;
-    fe* __restrict__ dst = dst_base + (size_t)blockIdx.z * a.dst_col_stride + (size_t)jl * a.dst_coset_stride + (size_t)batch * a.dst_batch_stride;
-    for (uint32_t i = threadIdx.x; i < n2 / 2; i += NTT_THREADS) TW[i] = a.stage_tw[i];
+    const uint32_t log_t = a.tile, T = 1u << log_t, n2 = 1u << a.log_n2;
+    fe_tw* TW = reinterpret_cast<fe_tw*>(L + n2 * T);
+    uint32_t g, jl, col;
+    ntt_block(a, g, jl, col);
+    const uint32_t batch = g & ((1u << a.batch_log) - 1u), group = g >> a.batch_log;
+    const fe* __restrict__ src = src_base + (size_t)col * a.src_col_stride + (size_t)jl * a.src_coset_stride + (size_t)batch * a.src_batch_stride;
+    fe* __restrict__ dst = dst_base + (size_t)col * a.dst_col_stride + (size_t)jl * a.dst_coset_stride + (size_t)batch * a.dst_batch_stride;
+    for (uint32_t i = threadIdx.x; i < n2 / 2; i += THREADS) TW[i] = a.stage_tw[i];
     fe pre0 = fe_zero(), pre1 = fe_zero(), pre2 = fe_zero(), pre3 = fe_zero(), pre4 = fe_zero(), pre5 = fe_zero(), pre6 = fe_zero(), pre7 = fe_zero();
     const uint32_t count = n2 * T;
     // contiguous along m2
-#define NTT_FETCH_B1(e, var, k1_0) { uint32_t idx = threadIdx.x + (e) * NTT_THREADS; idx = idx < count ? idx : 0u; var = src[(size_t)((k1_0) + (idx >> a.log_n2)) * a.src_row_stride + (idx & (n2 - 1))]; }
-#define NTT_FETCH_B(tile) { const uint32_t f0 = (tile) * T; NTT_FETCH_B1(0, pre0, f0) NTT_FETCH_B1(1, pre1, f0) NTT_FETCH_B1(2, pre2, f0) NTT_FETCH_B1(3, pre3, f0) \
-                                                        NTT_FETCH_B1(4, pre4, f0) NTT_FETCH_B1(5, pre5, f0) NTT_FETCH_B1(6, pre6, f0) NTT_FETCH_B1(7, pre7, f0) }
+#define NTT_FETCH_B1(e, var) if constexpr ((e) < EPT) { uint32_t idx = threadIdx.x + (e) * THREADS; idx = idx < count ? idx : 0u; var = src[(size_t)(f0 + (idx >> a.log_n2)) * a.src_row_stride + (idx & (n2 - 1))]; }
+#define NTT_FETCH_B(tile) { const uint32_t f0 = (tile) * T; NTT_EACH(NTT_FETCH_B1) }
     const uint32_t tile0 = group * a.tiles_per_block;
     NTT_FETCH_B(tile0)
     for (uint32_t it = 0; it < a.tiles_per_block; it++) {
         const uint32_t k1_0 = (tile0 + it) * T;
         __syncthreads();
-#define NTT_PUT_B(e, var) { const uint32_t idx = threadIdx.x + (e) * NTT_THREADS; if (idx < count) L[((idx & (n2 - 1)) << log_t) + (idx >> a.log_n2)] = var; }
-        NTT_PUT_B(0, pre0) NTT_PUT_B(1, pre1) NTT_PUT_B(2, pre2) NTT_PUT_B(3, pre3) NTT_PUT_B(4, pre4) NTT_PUT_B(5, pre5) NTT_PUT_B(6, pre6) NTT_PUT_B(7, pre7)
+#define NTT_PUT_B(e, var) if constexpr ((e) < EPT) { const uint32_t idx = threadIdx.x + (e) * THREADS; if (idx < count) L[lds_slot(idx & (n2 - 1), idx >> a.log_n2, log_t)] = var; }
+        NTT_EACH(NTT_PUT_B)
 #undef NTT_PUT_B
         __syncthreads();
         if (it + 1 < a.tiles_per_block) NTT_FETCH_B(tile0 + it + 1)
-        lds_ntt_dif(L, TW, a.log_n2, log_t);
-        for (uint32_t idx = threadIdx.x; idx < n2 * T; idx += NTT_THREADS) {
-            uint32_t t = idx & (T - 1), r = idx >> log_t;
-            uint32_t k2 = a.log_n2 ? (__brev(r) >> (32 - a.log_n2)) : 0u;
+        lds_ntt_dif<THREADS>(L, TW, a.log_n2, log_t, 1u, a.log_n2 + 1u);
+        for (uint32_t idx = threadIdx.x; idx < n2 * T; idx += THREADS) {
+            const uint32_t t = idx & (T - 1), r = idx >> log_t;
+            const uint32_t k2 = a.log_n2 ? (__brev(r) >> (32 - a.log_n2)) : 0u;
             fe v = L[idx];
-            if (a.has_scale) v = fe_mul(v, a.scale);
+            if (a.has_scale) v = fe_mul_tw(v, a.scale);
             dst[(size_t)k2 * a.dst_k_stride + k1_0 + t] = v;
         }
     }
@@ -271,9 +288,9 @@ struct NttRegArgs {
     size_t src_col_stride, src_coset_stride, dst_col_stride, dst_coset_stride;
     size_t in_stride_m, in_stride_t;    // element strides of the time index and of the tile column on input
     size_t out_stride_k;                // element stride of the frequency index on output (tile columns are contiguous)
-    const fe* stage_tw;                 // w_L^t, t < L/2
+    const fe_tw* stage_tw;              // w_L^t, t < L/2 (table pairs)
     const fe* tw_lo; const fe* tw_hi;   // two-level table of w_N (pass A four-step twiddle) or nullptr
-    const fe* prescale;                 // w_{B*L}^t or nullptr
+    const fe_tw* prescale;              // w_{B*L}^t or nullptr
     uint32_t lo_bits, log_N, log_b, j0, coset_twiddle, has_scale;
     fe scale;
     fe c16[8];                          // w_16^j (forward or inverse), j < 8
@@ -285,6 +302,7 @@ constexpr __host__ __device__ int ntt_brev(int v, int bits) { int r = 0; for (in
 // 1024-point kernel is ~190 KB of straight-line code, several times the 64 KB instruction cache a CU pair shares, and the waves
 // stall on instruction fetch; as a call the kernel is a few thousand instructions.
 __device__ __attribute__((noinline)) fe fe_mul_call(fe a, fe b) { return fe_mul(a, b); }
+__device__ __attribute__((noinline)) fe fe_mul_tw_call(fe a, fe p, fe q) { return fe_mul_tw(a, p, q); }
 
 // radix-2 DIF over x[0 .. 2^r): x[rho] <- X[brev_r(rho)]
 template <int r>
@@ -303,11 +321,13 @@ __device__ __forceinline__ void dft_regs(fe* x, const fe* c16) {
     });
 }
 
+// v * w_L^e from the half table: w_L^(e + L/2) = -w_L^e
 template <int LOGL>
-__device__ __forceinline__ fe stage_twiddle(const fe* __restrict__ tw, uint32_t e) {
+__device__ __forceinline__ fe mul_stage_twiddle(const fe& v, const fe_tw* __restrict__ tw, uint32_t e) {
     constexpr uint32_t H = 1u << (LOGL - 1);
-    fe v = tw[e & (H - 1)];
-    return (e & H) ? fe_neg(v) : v;
+    const fe_tw w = tw[e & (H - 1)];
+    const fe r = fe_mul_tw_call(v, w.p, w.q);
+    return (e & H) ? fe_neg(r) : r;
 }
 
 template <int LOGL>
@@ -338,7 +358,8 @@ __global__ void __launch_bounds__((1 << (LOGL + NttDigits<LOGL>::log_t)) / 16, (
             static_for<0, E>([&](auto i_) {
                 constexpr int i = decltype(i_)::value, u = i / R, d = i % R;
                 const uint32_t p = (tid + NT * u) >> LT;
-                x[i] = fe_mul_call(x[i], a.prescale[(jg * (uint32_t)(d * LO + p)) & pmask]);
+                const fe_tw w = a.prescale[(jg * (uint32_t)(d * LO + p)) & pmask];
+                x[i] = fe_mul_tw_call(x[i], w.p, w.q);
             });
         }
         static_for<0, SETS>([&](auto u_) {
@@ -348,7 +369,7 @@ __global__ void __launch_bounds__((1 << (LOGL + NttDigits<LOGL>::log_t)) / 16, (
             static_for<0, R>([&](auto rho_) {
                 constexpr int rho = decltype(rho_)::value, k = ntt_brev(rho, r1);
                 fe v = x[u * R + rho];
-                if constexpr (k != 0) v = fe_mul_call(v, stage_twiddle<LOGL>(a.stage_tw, (uint32_t)k * p));
+                if constexpr (k != 0) v = mul_stage_twiddle<LOGL>(v, a.stage_tw, (uint32_t)k * p);
                 tile[phys((((uint32_t)k * LO + p) << LT) + t)] = v;
             });
         });
@@ -369,7 +390,7 @@ __global__ void __launch_bounds__((1 << (LOGL + NttDigits<LOGL>::log_t)) / 16, (
             static_for<0, R>([&](auto rho_) {
                 constexpr int rho = decltype(rho_)::value, k = ntt_brev(rho, r2);
                 fe v = x[u * R + rho];
-                if constexpr (k != 0) v = fe_mul_call(v, stage_twiddle<LOGL>(a.stage_tw, ((uint32_t)k * low) << r1));
+                if constexpr (k != 0) v = mul_stage_twiddle<LOGL>(v, a.stage_tw, ((uint32_t)k * low) << r1);
                 tile[phys(((base + k * LO) << LT) + t)] = v;
             });
         });
@@ -461,44 +482,77 @@ static uint32_t ntt_tiles_per_block(uint32_t tiles, size_t arrays) {
     while (k < 8 && tiles % (2 * k) == 0 && (size_t)(tiles / (2 * k)) * arrays >= 2048) k *= 2;
     return k;
 }
+static void ntt_raise_lds_limit(dst_ctx* c) {                  // tile + stage twiddles exceed the 64 KiB default
+    static bool raised[64] = {};
+    if (c->device < 0 || c->device >= 64 || raised[c->device]) return;
+    (void)hipFuncSetAttribute((const void*)ntt_pass_a<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ntt_pass_a<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ntt_pass_b<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ntt_pass_b<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    raised[c->device] = true;
+}
+// DISTAFF_NTT_DEBUG=1 prints, once per distinct launch shape, how many workgroups of the instance are resident per CU
+static void ntt_report_occupancy(const char* name, bool pass_b, int threads, size_t lds) {
+    static std::map<std::string, bool> seen;
+    char key[128]; snprintf(key, sizeof key, "%s/%d/%zu", name, threads, lds);
+    if (seen[key]) return; seen[key] = true;
+    int nb = -1;
+    hipError_t e;
+    if (threads == 512) e = pass_b ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ntt_pass_b<512>, 512, lds) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ntt_pass_a<512>, 512, lds);
+    else e = pass_b ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ntt_pass_b<1024>, 1024, lds) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ntt_pass_a<1024>, 1024, lds);
+    fprintf(stderr, "[distaff] %s: %d lanes, %zu B LDS -> %d workgroups per CU (%s)\n", name, threads, lds, nb, hipGetErrorString(e));
+}
+// two workgroups of 512 lanes per CU while tile + twiddles fit 80 KiB, else one of 1024 lanes (same waves per SIMD)
+#define NTT_LDS_TWO_PER_CU (80 * 1024)
+static void ntt_launch(dst_ctx* c, bool pass_b, NttArgs& a, size_t groups, size_t cosets, size_t cols, size_t lds, const char* name, double bytes) {
+    ntt_raise_lds_limit(c);
+    a.groups = (uint32_t)groups; a.cosets = (uint32_t)cosets; a.cols = (uint32_t)cols;
+    const dim3 grid((unsigned)(groups * cosets * cols));
+    if (a.debug & 1u) ntt_report_occupancy(name, pass_b, lds <= NTT_LDS_TWO_PER_CU ? 512 : 1024, lds);
+    KScope ks_(c, name, bytes, true);
+    if (lds <= NTT_LDS_TWO_PER_CU) {
+        if (pass_b) hipLaunchKernelGGL(ntt_pass_b<512>, grid, dim3(512), lds, c->stream, a, a.src, a.dst);
+        else hipLaunchKernelGGL(ntt_pass_a<512>, grid, dim3(512), lds, c->stream, a, a.src, a.dst);
+    } else {
+        if (pass_b) hipLaunchKernelGGL(ntt_pass_b<1024>, grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
+        else hipLaunchKernelGGL(ntt_pass_a<1024>, grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
+    }
+}
+static NttArgs ntt_common_args(dst_ctx* c, bool inverse, bool lde, uint32_t skip) {
+    NttArgs a{};
+    a.log_N = c->log_N; a.log_b = c->log_b;
+    a.j0 = lde ? (uint32_t)c->j0 + skip : 0u;
+    a.scale = c->n_inv_tw;
+    { const char* dbg = getenv("DISTAFF_NTT_DEBUG"); a.debug = dbg ? (uint32_t)atoi(dbg) : 0u; }
+    (void)inverse;
+    return a;
+}
 static void launch_pass_lds(dst_ctx* c, bool pass_b, const fe* src, size_t src_col_stride, size_t src_coset_stride,
                             fe* dst, size_t dst_col_stride, size_t dst_coset_stride, size_t cosets, size_t cols, bool inverse, bool lde, uint32_t skip) {
     const NttPlan& p = c->plan;
-    static bool lds_limit_raised[64] = {};
-    if (c->device >= 0 && c->device < 64 && !lds_limit_raised[c->device]) {     // tile + stage twiddles can exceed the 64 KiB default
-        (void)hipFuncSetAttribute((const void*)ntt_pass_a, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)ntt_pass_b, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        lds_limit_raised[c->device] = true;
-    }
-    NttArgs a{};
-    a.log_n1 = p.log_n1; a.log_n2 = p.log_n2; a.log_N = c->log_N; a.log_b = c->log_b; a.lo_bits = c->tw_lo_bits;
-    a.j0 = lde ? (uint32_t)c->j0 + skip : 0u; a.coset_twiddle = lde ? 1u : 0u;
-    a.tw_lo = inverse ? c->itw_lo : c->tw_lo;
-    a.tw_hi = inverse ? c->itw_hi : c->tw_hi;
+    NttArgs a = ntt_common_args(c, inverse, lde, skip);
+    a.log_n1 = p.log_n1; a.log_n2 = p.log_n2;
     a.prescale = lde ? c->prescale : nullptr;
-    a.has_scale = inverse ? 1u : 0u; a.scale = c->n_inv;
-    { const char* dbg = getenv("DISTAFF_NTT_DEBUG"); a.debug = dbg ? (uint32_t)atoi(dbg) : 0u; }
+    a.has_scale = inverse ? 1u : 0u;
     a.src = src; a.src_col_stride = src_col_stride; a.src_coset_stride = src_coset_stride;
     a.dst = dst; a.dst_col_stride = dst_col_stride; a.dst_coset_stride = dst_coset_stride;
     if (!pass_b) {
         a.tw4 = lde ? c->tw4_lde + (size_t)skip * c->n : (inverse ? c->tw4_inv : c->tw4_fwd); a.tw4_coset_stride = lde ? c->n : 0;
         a.stage_tw = inverse ? c->w1i : c->w1f; a.tile = (uint32_t)__builtin_ctz(p.tile_a);
         a.dit = (lde && getenv("DISTAFF_NTT_DIF") == nullptr) ? 1u : 0u;
-        size_t lds_a = (((size_t)1 << p.log_n1) * p.tile_a + (a.dit ? ((size_t)1 << p.log_n1) : ((size_t)1 << p.log_n1) / 2)) * sizeof(fe);
+        const size_t n1 = (size_t)1 << p.log_n1;
+        const size_t lds_a = n1 * p.tile_a * sizeof(fe) + (a.dit ? n1 : n1 / 2) * sizeof(fe_tw);
         const uint32_t tiles = (1u << p.log_n2) / p.tile_a;
         a.tiles_per_block = ntt_tiles_per_block(tiles, cosets * cols);
-        dim3 ga((unsigned)(tiles / a.tiles_per_block), (unsigned)cosets, (unsigned)cols);
-        KScope ks_(c, "ntt_pass_a", 16.0 * c->n * cols * (lde ? (1 + cosets) : 2 * cosets), true);
-        hipLaunchKernelGGL(ntt_pass_a, ga, dim3(NTT_THREADS), lds_a, c->stream, a, a.src, a.dst);
+        ntt_launch(c, false, a, tiles / a.tiles_per_block, cosets, cols, lds_a, "ntt_pass_a", 16.0 * c->n * cols * (lde ? (1 + cosets) : 2 * cosets));
     } else {
         a.stage_tw = inverse ? c->w2i : c->w2f; a.tile = (uint32_t)__builtin_ctz(p.tile_b);
         a.src_row_stride = (size_t)1 << p.log_n2; a.dst_k_stride = (size_t)1 << p.log_n1; a.batch_log = 0; a.src_batch_stride = a.dst_batch_stride = 0;
-        size_t lds_b = (((size_t)1 << p.log_n2) * p.tile_b + ((size_t)1 << p.log_n2) / 2) * sizeof(fe);
+        const size_t n2 = (size_t)1 << p.log_n2;
+        const size_t lds_b = n2 * p.tile_b * sizeof(fe) + (n2 / 2) * sizeof(fe_tw);
         const uint32_t tiles = (1u << p.log_n1) / p.tile_b;
         a.tiles_per_block = ntt_tiles_per_block(tiles, cosets * cols);
-        dim3 gb((unsigned)(tiles / a.tiles_per_block), (unsigned)cosets, (unsigned)cols);
-        KScope ks_(c, "ntt_pass_b", 32.0 * c->n * cols * cosets, true);
-        hipLaunchKernelGGL(ntt_pass_b, gb, dim3(NTT_THREADS), lds_b, c->stream, a, a.src, a.dst);
+        ntt_launch(c, true, a, tiles / a.tiles_per_block, cosets, cols, lds_b, "ntt_pass_b", 32.0 * c->n * cols * cosets);
     }
 }
 
@@ -512,20 +566,9 @@ static void launch_three_pass(dst_ctx* c, const fe* src, size_t src_col_stride, 
     const NttPlan& p = c->plan;
     const uint32_t log_mid = p.log_n2 - p.log_n3;                      // 8
     const size_t n = c->n, nrow = (size_t)1 << p.log_n2, n3 = (size_t)1 << p.log_n3, n1 = (size_t)1 << p.log_n1;
-    static bool lds_limit_raised[64] = {};
-    if (c->device >= 0 && c->device < 64 && !lds_limit_raised[c->device]) {
-        (void)hipFuncSetAttribute((const void*)ntt_pass_a, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute((const void*)ntt_pass_b, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        lds_limit_raised[c->device] = true;
-    }
-    NttArgs a{};
-    a.log_N = c->log_N; a.log_b = c->log_b; a.lo_bits = c->tw_lo_bits;
-    a.tw_lo = inverse ? c->itw_lo : c->tw_lo; a.tw_hi = inverse ? c->itw_hi : c->tw_hi;
-    a.scale = c->n_inv;
-    { const char* dbg = getenv("DISTAFF_NTT_DEBUG"); a.debug = dbg ? (uint32_t)atoi(dbg) : 0u; }
+    NttArgs a = ntt_common_args(c, inverse, lde, skip);
     // pass 1: src -> tmp
     a.log_n1 = p.log_n1; a.log_n2 = p.log_n2; a.tile = (uint32_t)__builtin_ctz(p.tile_a);
-    a.j0 = lde ? (uint32_t)c->j0 + skip : 0u; a.coset_twiddle = lde ? 1u : 0u;
     a.prescale = lde ? c->prescale : nullptr; a.has_scale = 0;
     a.tw4 = lde ? c->tw4_lde + (size_t)skip * n : (inverse ? c->tw4_inv : c->tw4_fwd); a.tw4_coset_stride = lde ? n : 0;
     a.stage_tw = inverse ? c->w1i : c->w1f;
@@ -535,14 +578,12 @@ static void launch_three_pass(dst_ctx* c, const fe* src, size_t src_col_stride, 
     {
         const uint32_t tiles = (uint32_t)(nrow / p.tile_a);
         a.tiles_per_block = ntt_tiles_per_block(tiles, cosets * cols);
-        const size_t lds = (n1 * p.tile_a + (a.dit ? n1 : n1 / 2)) * sizeof(fe);
-        dim3 g((unsigned)(tiles / a.tiles_per_block), (unsigned)cosets, (unsigned)cols);
-        KScope ks_(c, "ntt_pass_a", 16.0 * n * cols * (lde ? (1 + cosets) : 2 * cosets), true);
-        hipLaunchKernelGGL(ntt_pass_a, g, dim3(NTT_THREADS), lds, c->stream, a, a.src, a.dst);
+        const size_t lds = n1 * p.tile_a * sizeof(fe) + (a.dit ? n1 : n1 / 2) * sizeof(fe_tw);
+        ntt_launch(c, false, a, tiles / a.tiles_per_block, cosets, cols, lds, "ntt_pass_a", 16.0 * n * cols * (lde ? (1 + cosets) : 2 * cosets));
     }
     // pass 2: tmp -> tmp2, every (coset, k1) row of nrow points is an array of shape 2^log_mid x n3
     a.log_n1 = log_mid; a.log_n2 = p.log_n3; a.tile = (uint32_t)__builtin_ctz(p.tile_m);
-    a.j0 = 0; a.coset_twiddle = 0; a.prescale = nullptr; a.dit = 0;
+    a.j0 = 0; a.prescale = nullptr; a.dit = 0;
     a.tw4 = inverse ? c->tw4_row_inv : c->tw4_row_fwd; a.tw4_coset_stride = 0;
     a.stage_tw = inverse ? c->w2i : c->w2f;
     a.src = c->tmp; a.src_col_stride = n * cosets; a.src_coset_stride = nrow;
@@ -551,10 +592,8 @@ static void launch_three_pass(dst_ctx* c, const fe* src, size_t src_col_stride, 
         const uint32_t tiles = (uint32_t)(n3 / p.tile_m);
         const size_t rows = cosets * n1;
         a.tiles_per_block = ntt_tiles_per_block(tiles, rows * cols);
-        const size_t lds = (((size_t)1 << log_mid) * p.tile_m + ((size_t)1 << log_mid) / 2) * sizeof(fe);
-        dim3 g((unsigned)(tiles / a.tiles_per_block), (unsigned)rows, (unsigned)cols);
-        KScope ks_(c, "ntt_pass_mid", 32.0 * n * cols * cosets, true);
-        hipLaunchKernelGGL(ntt_pass_a, g, dim3(NTT_THREADS), lds, c->stream, a, a.src, a.dst);
+        const size_t lds = ((size_t)1 << log_mid) * p.tile_m * sizeof(fe) + (((size_t)1 << log_mid) / 2) * sizeof(fe_tw);
+        ntt_launch(c, false, a, tiles / a.tiles_per_block, rows, cols, lds, "ntt_pass_mid", 32.0 * n * cols * cosets);
     }
     // pass 3: tmp2 -> dst
     a.log_n1 = p.log_n1; a.log_n2 = p.log_n3; a.tile = (uint32_t)__builtin_ctz(p.tile_b);
@@ -567,10 +606,8 @@ static void launch_three_pass(dst_ctx* c, const fe* src, size_t src_col_stride, 
     {
         const uint32_t tiles = (uint32_t)(n1 / p.tile_b);
         a.tiles_per_block = ntt_tiles_per_block(tiles, ((size_t)cosets << log_mid) * cols);
-        const size_t lds = (n3 * p.tile_b + n3 / 2) * sizeof(fe);
-        dim3 g((unsigned)((tiles / a.tiles_per_block) << log_mid), (unsigned)cosets, (unsigned)cols);
-        KScope ks_(c, "ntt_pass_b", 32.0 * n * cols * cosets, true);
-        hipLaunchKernelGGL(ntt_pass_b, g, dim3(NTT_THREADS), lds, c->stream, a, a.src, a.dst);
+        const size_t lds = n3 * p.tile_b * sizeof(fe) + (n3 / 2) * sizeof(fe_tw);
+        ntt_launch(c, true, a, (size_t)(tiles / a.tiles_per_block) << log_mid, cosets, cols, lds, "ntt_pass_b", 32.0 * n * cols * cosets);
     }
 }
 
@@ -587,7 +624,7 @@ static void launch_two_pass(dst_ctx* c, const fe* src, size_t src_col_stride, si
 // ---- four-step twiddle tables -------------------------------------------------------------------------------------------------------
 // out[coset][k1][m2] = w_N^(m2 * ((k1 << log_b) + j)) for a transform of 2^log_n points whose inner dimension has 2^log_n2 points;
 // a sub-transform of length n' = n / 2^s is expressed with log_b + s (its root is w_N^(B * 2^s))
-__global__ void twiddle_table_kernel(fe* out, const fe* tw_lo, const fe* tw_hi, uint32_t lo_bits, uint32_t log_n2, uint32_t log_n, uint32_t log_b,
+__global__ void twiddle_table_kernel(fe_tw* out, const fe* tw_lo, const fe* tw_hi, uint32_t lo_bits, uint32_t log_n2, uint32_t log_n, uint32_t log_b,
                                      uint32_t log_N, uint32_t j0, uint32_t coset_twiddle) {
     const size_t n = (size_t)1 << log_n;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -595,7 +632,7 @@ __global__ void twiddle_table_kernel(fe* out, const fe* tw_lo, const fe* tw_hi, 
     const uint64_t k1 = i >> log_n2, m2 = i & (((size_t)1 << log_n2) - 1);
     const uint64_t jg = coset_twiddle ? j0 + blockIdx.y : 0;
     const uint64_t e = (m2 * ((k1 << log_b) + jg)) & (((uint64_t)1 << log_N) - 1);
-    out[(size_t)blockIdx.y * n + i] = dom_pow(tw_lo, tw_hi, lo_bits, e);
+    out[(size_t)blockIdx.y * n + i] = fe_tw_make(dom_pow(tw_lo, tw_hi, lo_bits, e));
 }
 int k_build_twiddle_tables(dst_ctx* c) {
     const NttPlan& p = c->plan;
@@ -631,10 +668,16 @@ void k_lde_columns(dst_ctx* c, const fe* polys, fe* lde, size_t ncols) {
     // the interpolated trace, it is copied instead of transformed (1/B of the extension work)
     const uint32_t skip = (c->j0 == 0 && polys == c->polys && c->Bc > 1) ? 1u : 0u;
     if (skip) (void)hipMemcpy2DAsync(lde, c->Bc * c->n * sizeof(fe), c->trace, c->n * sizeof(fe), c->n * sizeof(fe), ncols, hipMemcpyDeviceToDevice, c->stream);
-    size_t cap = tmp_capacity_arrays(c) / c->Bc;
+    // launch granularity: `bcols` registers x `bcos` cosets per pair of passes (the staging buffer holds tmp_capacity_arrays arrays)
+    size_t bcols = tmp_capacity_arrays(c) / c->Bc, bcos = c->Bc - skip;
+    if (const char* e = getenv("DISTAFF_LDE_BATCH")) { unsigned x = 0, y = 0; if (sscanf(e, "%u,%u", &x, &y) == 2 && x >= 1 && y >= 1 && (size_t)x * y <= tmp_capacity_arrays(c)) { bcols = x; bcos = y; } }
     for (size_t done = 0; done < ncols;) {
-        size_t cols = ncols - done < cap ? ncols - done : cap;
-        launch_two_pass(c, polys + done * c->n, c->n, 0, lde + done * c->Bc * c->n + (size_t)skip * c->n, c->Bc * c->n, c->n, c->Bc - skip, cols, false, true, skip);
+        const size_t cols = ncols - done < bcols ? ncols - done : bcols;
+        for (size_t s = skip; s < c->Bc;) {
+            const size_t cc = c->Bc - s < bcos ? c->Bc - s : bcos;
+            launch_two_pass(c, polys + done * c->n, c->n, 0, lde + done * c->Bc * c->n + s * c->n, c->Bc * c->n, c->n, cc, cols, false, true, (uint32_t)s);
+            s += cc;
+        }
         done += cols;
     }
 }
