@@ -19,6 +19,7 @@
 // implementation that the tests run at every tile length.
 #include "ctx.h"
 #include <type_traits>
+#include "ntt_lds.h"
 
 #define NTT_TILE_ELEMS 4096      // elements of an LDS tile (64 KiB); a workgroup of 512 lanes holds 8 per lane, one of 1024 lanes 4
 
@@ -53,13 +54,6 @@ __device__ __forceinline__ fe dom_pow(const fe* lo, const fe* hi, uint32_t lo_bi
     return fe_mul(a, hi[h]);
 }
 
-// compile-time loop: the bodies hold fully inlined 128-bit multiplications, far beyond the size the loop unroller accepts, so the
-// unrolling is structural and every register-array index is a constant
-template <int I, int N, class F>
-__device__ __forceinline__ void static_for(F&& f) {
-    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
-}
-
 // Linear block index -> (tile group, local coset, column).  The COLUMN (register) is the fastest dimension and the blocks that
 // differ only in it carry the same index modulo 8, i.e. run on the same XCD at the same time (block b runs on XCD b % 8): the
 // four-step twiddles of a (coset, tile) - the same for every register - are fetched from HBM once and served to the other
@@ -70,85 +64,6 @@ __device__ __forceinline__ void ntt_block(const NttArgs& a, uint32_t& group, uin
     if ((units & 7u) == 0) { const uint32_t s = b >> 3; col = s % a.cols; u = (s / a.cols) * 8u + (b & 7u); }
     else { col = b % a.cols; u = b / a.cols; }
     jl = u / a.groups; group = u % a.groups;
-}
-
-__device__ __forceinline__ uint32_t lds_slot(uint32_t i, uint32_t t, uint32_t log_t) { return (i << log_t) + t; }
-
-// in-LDS DIF over the first index of L[len][T]; output position r holds frequency bitrev(r).  W: stage twiddles w_len^t in LDS.
-// Two radix-2 stages are fused into one radix-4 round (one LDS round trip, one barrier and one index computation per two
-// stages; the arithmetic is exactly the two radix-2 stages); an odd stage count ends with a plain radix-2 stage.
-template <int THREADS>
-__device__ __forceinline__ void lds_ntt_dif(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s_from, uint32_t s_to) {
-    const uint32_t T = 1u << log_t;
-    uint32_t s = s_from;                             // stages [s_from, s_to), s_from odd
-    for (; s + 1 <= log_len && s < s_to; s += 2) {
-        const uint32_t ld = log_len - s;             // log2 of the first stage's butterfly distance d
-        const uint32_t d = 1u << ld, hd = d >> 1;
-        const bool last = (s + 1 == log_len);        // second stage has distance 1: its twiddles are 1
-        for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 2) * T; w += THREADS) {
-            const uint32_t t = w & (T - 1), q = w >> log_t;
-            const uint32_t pos = q & (hd - 1), blk = q >> (ld - 1);
-            const uint32_t i0 = (blk << (ld + 1)) + pos;
-            fe* p0 = L + lds_slot(i0, t, log_t); fe* p1 = L + lds_slot(i0 + hd, t, log_t); fe* p2 = L + lds_slot(i0 + d, t, log_t); fe* p3 = L + lds_slot(i0 + d + hd, t, log_t);
-            const fe x0 = *p0, x1 = *p1, x2 = *p2, x3 = *p3;
-            // stage s: (x0, x2) with w_2d^pos, (x1, x3) with w_2d^(pos + d/2)
-            fe a0 = fe_add(x0, x2), a2 = fe_sub(x0, x2);
-            fe a1 = fe_add(x1, x3), a3 = fe_sub(x1, x3);
-            if (hd != 1) a2 = fe_mul_tw(a2, W[pos << (s - 1)]);          // hd == 1: pos == 0 in every lane
-            a3 = fe_mul_tw(a3, W[(pos + hd) << (s - 1)]);
-            // stage s + 1: (a0, a1) and (a2, a3) with w_d^pos
-            fe y0 = fe_add(a0, a1), y1 = fe_sub(a0, a1);
-            fe y2 = fe_add(a2, a3), y3 = fe_sub(a2, a3);
-            if (!last && hd != 1) { const fe_tw tw = W[pos << s]; y1 = fe_mul_tw(y1, tw); y3 = fe_mul_tw(y3, tw); }
-            *p0 = y0; *p1 = y1; *p2 = y2; *p3 = y3;
-        }
-        __syncthreads();
-    }
-    if (s == log_len && s < s_to) {                  // distance-1 stage, no twiddles
-        for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 1) * T; w += THREADS) {
-            const uint32_t t = w & (T - 1), q = w >> log_t;
-            fe* p0 = L + lds_slot(q << 1, t, log_t); fe* p1 = L + lds_slot((q << 1) + 1, t, log_t);
-            const fe a = *p0, b = *p1;
-            *p0 = fe_add(a, b); *p1 = fe_sub(a, b);
-        }
-        __syncthreads();
-    }
-}
-
-// in-LDS DIT over the first index of L[len][T] for a COSET transform: X[k] = sum_m x[m] * g^m * w_len^(m*k).  The input sits in
-// bit-reversed order (position brev(m) holds x[m]), the output is in natural order.  The sub-transforms over the even and
-// odd indices are coset transforms with g^2, so the stage that merges blocks of size B multiplies by g^(len/B) * w_B^k: the
-// pre-scale by g^m costs nothing -- it is part of twiddles that had to be applied anyway.  W holds them per stage at offset
-// B/2 - 1 (len - 1 entries for the workgroup's coset).  Two stages per LDS round trip, as in lds_ntt_dif.
-template <int THREADS>
-__device__ __forceinline__ void lds_ntt_dit(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s_from, uint32_t s_to) {
-    const uint32_t T = 1u << log_t;
-    uint32_t s = s_from;                             // stages [s_from, s_to), s_from odd
-    for (; s + 1 <= log_len && s < s_to; s += 2) {
-        const uint32_t B = 1u << s, half = B >> 1;                     // first stage merges blocks of size B / 2 into B, second B into 2B
-        for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 2) * T; w += THREADS) {
-            const uint32_t t = w & (T - 1), q = w >> log_t;
-            const uint32_t k = q & (half - 1), base = (q >> (s - 1)) << (s + 1);
-            fe* p0 = L + lds_slot(base + k, t, log_t); fe* p1 = L + lds_slot(base + k + half, t, log_t); fe* p2 = L + lds_slot(base + k + B, t, log_t); fe* p3 = L + lds_slot(base + k + B + half, t, log_t);
-            const fe_tw tb = W[half - 1 + k];
-            const fe x0 = *p0, x1 = fe_mul_tw(*p1, tb), x2 = *p2, x3 = fe_mul_tw(*p3, tb);
-            const fe a0 = fe_add(x0, x1), a1 = fe_sub(x0, x1);
-            const fe a2 = fe_mul_tw(fe_add(x2, x3), W[B - 1 + k]), a3 = fe_mul_tw(fe_sub(x2, x3), W[B - 1 + k + half]);
-            *p0 = fe_add(a0, a2); *p2 = fe_sub(a0, a2);
-            *p1 = fe_add(a1, a3); *p3 = fe_sub(a1, a3);
-        }
-        __syncthreads();
-    }
-    if (s == log_len && s < s_to) {                  // last single stage: blocks of len / 2 into len
-        const uint32_t half = 1u << (log_len - 1);
-        for (uint32_t w = threadIdx.x; w < half * T; w += THREADS) {
-            const uint32_t t = w & (T - 1), k = w >> log_t;
-            fe* p0 = L + lds_slot(k, t, log_t); fe* p1 = L + lds_slot(k + half, t, log_t);
-            const fe u = *p0, v = fe_mul_tw(*p1, W[half - 1 + k]);
-            *p0 = fe_add(u, v); *p1 = fe_sub(u, v);
-        }
-        __syncthreads();
-    }
 }
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
@@ -178,7 +93,7 @@ __global__ void __launch_bounds__(THREADS, 4) ntt_pass_a(NttArgs a, const fe* __
             TW[i] = a.prescale[((jg + (k << a.log_b)) << (a.log_n1 - lb - 1)) & pmask];
         }
     } else
-    for (uint32_t i = threadIdx.x; i < n1 / 2; i += THREADS) TW[i] = a.stage_tw[i];
+    for (uint32_t i = threadIdx.x; i < n1 / 2; i += THREADS) TW[dif_tw_slot(i)] = a.stage_tw[i];
     const bool scaled = !a.dit && a.prescale != nullptr && jg != 0;
     fe pre0 = fe_zero(), pre1 = fe_zero(), pre2 = fe_zero(), pre3 = fe_zero(), pre4 = fe_zero(), pre5 = fe_zero(), pre6 = fe_zero(), pre7 = fe_zero();
     const uint32_t count = n1 * T;
@@ -236,7 +151,7 @@ __global__ void __launch_bounds__(THREADS, 4) ntt_pass_b(NttArgs a, const fe* __
     const uint32_t batch = g & ((1u << a.batch_log) - 1u), group = g >> a.batch_log;
     const fe* __restrict__ src = src_base + (size_t)col * a.src_col_stride + (size_t)jl * a.src_coset_stride + (size_t)batch * a.src_batch_stride;
     fe* __restrict__ dst = dst_base + (size_t)col * a.dst_col_stride + (size_t)jl * a.dst_coset_stride + (size_t)batch * a.dst_batch_stride;
-    for (uint32_t i = threadIdx.x; i < n2 / 2; i += THREADS) TW[i] = a.stage_tw[i];
+    for (uint32_t i = threadIdx.x; i < n2 / 2; i += THREADS) TW[dif_tw_slot(i)] = a.stage_tw[i];
     fe pre0 = fe_zero(), pre1 = fe_zero(), pre2 = fe_zero(), pre3 = fe_zero(), pre4 = fe_zero(), pre5 = fe_zero(), pre6 = fe_zero(), pre7 = fe_zero();
     const uint32_t count = n2 * T;
     // contiguous along m2
@@ -518,6 +433,14 @@ static void ntt_launch(dst_ctx* c, bool pass_b, NttArgs& a, size_t groups, size_
         else hipLaunchKernelGGL(ntt_pass_a<1024>, grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
     }
 }
+// First pass of an extension: coset DIT (the pre-scale costs nothing, but the workgroup holds n1 - 1 twiddle pairs of ITS coset) while
+// tile + pairs fit the 80 KiB that let two workgroups share a CU; otherwise pre-scale + DIF with the n1/2 shared stage twiddles (one
+// more multiplication per element, two workgroups per CU: measured 14.5 against 15.0 ms per proof for the 1024-point tiles of n = 2^20).
+// DISTAFF_NTT_DIF=1 / 0 forces one or the other (the tests run both).
+static bool ntt_first_pass_dit(size_t n1, size_t tile) {
+    if (const char* e = getenv("DISTAFF_NTT_DIF")) return e[0] == '0';
+    return n1 * tile * sizeof(fe) + n1 * sizeof(fe_tw) <= NTT_LDS_TWO_PER_CU;
+}
 static NttArgs ntt_common_args(dst_ctx* c, bool inverse, bool lde, uint32_t skip) {
     NttArgs a{};
     a.log_N = c->log_N; a.log_b = c->log_b;
@@ -539,8 +462,8 @@ static void launch_pass_lds(dst_ctx* c, bool pass_b, const fe* src, size_t src_c
     if (!pass_b) {
         a.tw4 = lde ? c->tw4_lde + (size_t)skip * c->n : (inverse ? c->tw4_inv : c->tw4_fwd); a.tw4_coset_stride = lde ? c->n : 0;
         a.stage_tw = inverse ? c->w1i : c->w1f; a.tile = (uint32_t)__builtin_ctz(p.tile_a);
-        a.dit = (lde && getenv("DISTAFF_NTT_DIF") == nullptr) ? 1u : 0u;
         const size_t n1 = (size_t)1 << p.log_n1;
+        a.dit = (lde && ntt_first_pass_dit(n1, p.tile_a)) ? 1u : 0u;
         const size_t lds_a = n1 * p.tile_a * sizeof(fe) + (a.dit ? n1 : n1 / 2) * sizeof(fe_tw);
         const uint32_t tiles = (1u << p.log_n2) / p.tile_a;
         a.tiles_per_block = ntt_tiles_per_block(tiles, cosets * cols);
@@ -572,7 +495,7 @@ static void launch_three_pass(dst_ctx* c, const fe* src, size_t src_col_stride, 
     a.prescale = lde ? c->prescale : nullptr; a.has_scale = 0;
     a.tw4 = lde ? c->tw4_lde + (size_t)skip * n : (inverse ? c->tw4_inv : c->tw4_fwd); a.tw4_coset_stride = lde ? n : 0;
     a.stage_tw = inverse ? c->w1i : c->w1f;
-    a.dit = (lde && getenv("DISTAFF_NTT_DIF") == nullptr) ? 1u : 0u;
+    a.dit = (lde && ntt_first_pass_dit(n1, p.tile_a)) ? 1u : 0u;
     a.src = src; a.src_col_stride = src_col_stride; a.src_coset_stride = src_coset_stride;
     a.dst = c->tmp; a.dst_col_stride = n * cosets; a.dst_coset_stride = n;
     {

@@ -1,0 +1,110 @@
+// In-LDS butterfly stages of the LDS-family transforms (kernels_ntt.hip; also timed in isolation by tools/felab).
+#pragma once
+#include <type_traits>
+#include "fe.h"
+
+// compile-time loop: the bodies hold fully inlined 128-bit multiplications, far beyond the size the loop unroller accepts, so the
+// unrolling is structural and every register-array index is a constant
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); }
+}
+
+// LDS slot of tile element (row i, column t).  NTT_SWIZZLE (laboratory switch, off: it did not pay in the full kernels) permutes the
+// 16-byte slots of four-column tiles so that 64-byte-stride access patterns fall on distinct banks.
+__device__ __forceinline__ uint32_t lds_slot(uint32_t i, uint32_t t, uint32_t log_t) {
+#if defined(NTT_SWIZZLE)
+    if (log_t == 2) return ((i ^ ((i >> 2) & 3u)) << 2) + (t ^ ((i >> 1) & 3u));
+#endif
+    return (i << log_t) + t;
+}
+
+// Slot of DIF stage twiddle w_len^e in LDS.  Stage s reads the entries e = pos * 2^(s-1) of neighbouring butterflies: from the third stage
+// on that is a stride of a multiple of 256 bytes, i.e. every lane of an LDS access group on the same banks (measured on the rounds in
+// isolation: 11 % of their time).  XOR-ing bits 3..5 and 6..8 of the index into its low three bits spreads strides 4, 16 and 64 over
+// the banks and leaves unit stride alone.  The workgroup fills the table through the same map.
+__device__ __forceinline__ uint32_t dif_tw_slot(uint32_t e) {
+#if defined(NTT_LAB_PLAIN_TW)
+    return e;
+#else
+    return e ^ ((e >> 3) & 7u) ^ ((e >> 6) & 7u);
+#endif
+}
+
+// in-LDS DIF over the first index of L[len][T]; output position r holds frequency bitrev(r).  W: stage twiddles w_len^t in LDS.
+// Two radix-2 stages are fused into one radix-4 round (one LDS round trip, one barrier and one index computation per two
+// stages; the arithmetic is exactly the two radix-2 stages); an odd stage count ends with a plain radix-2 stage.
+template <int THREADS>
+__device__ __forceinline__ void lds_ntt_dif(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s_from, uint32_t s_to) {
+    const uint32_t T = 1u << log_t;
+    uint32_t s = s_from;                             // stages [s_from, s_to), s_from odd
+    for (; s + 1 <= log_len && s < s_to; s += 2) {
+        const uint32_t ld = log_len - s;             // log2 of the first stage's butterfly distance d
+        const uint32_t d = 1u << ld, hd = d >> 1;
+        const bool last = (s + 1 == log_len);        // second stage has distance 1: its twiddles are 1
+        for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 2) * T; w += THREADS) {
+            const uint32_t t = w & (T - 1), q = w >> log_t;
+            const uint32_t pos = q & (hd - 1), blk = q >> (ld - 1);
+            const uint32_t i0 = (blk << (ld + 1)) + pos;
+            fe* p0 = L + lds_slot(i0, t, log_t); fe* p1 = L + lds_slot(i0 + hd, t, log_t); fe* p2 = L + lds_slot(i0 + d, t, log_t); fe* p3 = L + lds_slot(i0 + d + hd, t, log_t);
+            const fe x0 = *p0, x1 = *p1, x2 = *p2, x3 = *p3;
+            // stage s: (x0, x2) with w_2d^pos, (x1, x3) with w_2d^(pos + d/2)
+            fe a0 = fe_add(x0, x2), a2 = fe_sub(x0, x2);
+            fe a1 = fe_add(x1, x3), a3 = fe_sub(x1, x3);
+            if (hd != 1) a2 = fe_mul_tw(a2, W[dif_tw_slot(pos << (s - 1))]);          // hd == 1: pos == 0 in every lane
+            a3 = fe_mul_tw(a3, W[dif_tw_slot((pos + hd) << (s - 1))]);
+            // stage s + 1: (a0, a1) and (a2, a3) with w_d^pos
+            fe y0 = fe_add(a0, a1), y1 = fe_sub(a0, a1);
+            fe y2 = fe_add(a2, a3), y3 = fe_sub(a2, a3);
+            if (!last && hd != 1) { const fe_tw tw = W[dif_tw_slot(pos << s)]; y1 = fe_mul_tw(y1, tw); y3 = fe_mul_tw(y3, tw); }
+            *p0 = y0; *p1 = y1; *p2 = y2; *p3 = y3;
+        }
+        __syncthreads();
+    }
+    if (s == log_len && s < s_to) {                  // distance-1 stage, no twiddles
+        for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 1) * T; w += THREADS) {
+            const uint32_t t = w & (T - 1), q = w >> log_t;
+            fe* p0 = L + lds_slot(q << 1, t, log_t); fe* p1 = L + lds_slot((q << 1) + 1, t, log_t);
+            const fe a = *p0, b = *p1;
+            *p0 = fe_add(a, b); *p1 = fe_sub(a, b);
+        }
+        __syncthreads();
+    }
+}
+
+// in-LDS DIT over the first index of L[len][T] for a COSET transform: X[k] = sum_m x[m] * g^m * w_len^(m*k).  The input sits in
+// bit-reversed order (position brev(m) holds x[m]), the output is in natural order.  The sub-transforms over the even and
+// odd indices are coset transforms with g^2, so the stage that merges blocks of size B multiplies by g^(len/B) * w_B^k: the
+// pre-scale by g^m costs nothing -- it is part of twiddles that had to be applied anyway.  W holds them per stage at offset
+// B/2 - 1 (len - 1 entries for the workgroup's coset).  Two stages per LDS round trip, as in lds_ntt_dif.
+template <int THREADS>
+__device__ __forceinline__ void lds_ntt_dit(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s_from, uint32_t s_to) {
+    const uint32_t T = 1u << log_t;
+    uint32_t s = s_from;                             // stages [s_from, s_to), s_from odd
+    for (; s + 1 <= log_len && s < s_to; s += 2) {
+        const uint32_t B = 1u << s, half = B >> 1;                     // first stage merges blocks of size B / 2 into B, second B into 2B
+        for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 2) * T; w += THREADS) {
+            const uint32_t t = w & (T - 1), q = w >> log_t;
+            const uint32_t k = q & (half - 1), base = (q >> (s - 1)) << (s + 1);
+            fe* p0 = L + lds_slot(base + k, t, log_t); fe* p1 = L + lds_slot(base + k + half, t, log_t); fe* p2 = L + lds_slot(base + k + B, t, log_t); fe* p3 = L + lds_slot(base + k + B + half, t, log_t);
+            const fe_tw tb = W[half - 1 + k];
+            const fe x0 = *p0, x1 = fe_mul_tw(*p1, tb), x2 = *p2, x3 = fe_mul_tw(*p3, tb);
+            const fe a0 = fe_add(x0, x1), a1 = fe_sub(x0, x1);
+            const fe a2 = fe_mul_tw(fe_add(x2, x3), W[B - 1 + k]), a3 = fe_mul_tw(fe_sub(x2, x3), W[B - 1 + k + half]);
+            *p0 = fe_add(a0, a2); *p2 = fe_sub(a0, a2);
+            *p1 = fe_add(a1, a3); *p3 = fe_sub(a1, a3);
+        }
+        __syncthreads();
+    }
+    if (s == log_len && s < s_to) {                  // last single stage: blocks of len / 2 into len
+        const uint32_t half = 1u << (log_len - 1);
+        for (uint32_t w = threadIdx.x; w < half * T; w += THREADS) {
+            const uint32_t t = w & (T - 1), k = w >> log_t;
+            fe* p0 = L + lds_slot(k, t, log_t); fe* p1 = L + lds_slot(k + half, t, log_t);
+            const fe u = *p0, v = fe_mul_tw(*p1, W[half - 1 + k]);
+            *p0 = fe_add(u, v); *p1 = fe_sub(u, v);
+        }
+        __syncthreads();
+    }
+}
+

@@ -361,7 +361,7 @@ def _random_columns(W, n, seed):
 
 @pytest.mark.parametrize("family,log_n,log_blowup", [("reg", 13, 5), ("reg", 14, 5), ("reg", 15, 4), ("reg", 16, 5), ("reg", 17, 4), ("reg", 18, 4),
                                                       ("reg", 19, 4), ("reg", 20, 4), ("reg", 21, 4), ("reg", 22, 4), ("reg", 23, 4), ("reg", 24, 4),
-                                                      ("lds", 13, 5), ("lds", 16, 5), ("lds", 19, 4), ("lds", 22, 4), ("auto", 21, 4), ("auto", 22, 4), ("auto", 23, 4), ("auto", 24, 4), ("3pass", 20, 5), ("dif", 16, 5), ("dif", 21, 4)])
+                                                      ("lds", 13, 5), ("lds", 16, 5), ("lds", 19, 4), ("lds", 22, 4), ("auto", 21, 4), ("auto", 22, 4), ("auto", 23, 4), ("auto", 24, 4), ("3pass", 20, 5), ("dif", 16, 5), ("dif", 21, 4), ("dit", 16, 5), ("dit", 20, 5)])
 def test_lde_every_tile_length(oracle, monkeypatch, family, log_n, log_blowup):
     """Both NTT kernel families (register-radix: every tile length 2^6 .. 2^12 in both passes; LDS radix-2) and the default per-pass
     choice at the largest size, through size-independent properties that pin the
@@ -372,9 +372,9 @@ def test_lde_every_tile_length(oracle, monkeypatch, family, log_n, log_blowup):
     n, B, W = 1 << log_n, 1 << log_blowup, 16
     cols = _random_columns(W, n, 1000 + log_n)
     monkeypatch.delenv("DISTAFF_NTT_DIF", raising=False)
-    if family == "dif":                                                  # first pass as pre-scale + DIF instead of the coset DIT
+    if family in ("dif", "dit"):                                         # first pass forced to pre-scale + DIF / to the coset DIT (1024-lane instance at 2^20)
         monkeypatch.delenv("DISTAFF_NTT", raising=False)
-        monkeypatch.setenv("DISTAFF_NTT_DIF", "1")
+        monkeypatch.setenv("DISTAFF_NTT_DIF", "1" if family == "dif" else "0")
     elif family == "auto":
         monkeypatch.delenv("DISTAFF_NTT", raising=False)
     else:
