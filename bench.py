@@ -3,7 +3,8 @@
 
 A "step" is one complete `stark::prove` (LDE + trace Merkle + constraint evaluation + combination + constraint LDE/Merkle +
 DEEP composition + FRI + proof-of-work + openings, default ProofOptions) over one Fibonacci execution trace that is already
-resident in HBM (the upload is not timed: the PCIe-inclusive rate is in DESIGN.md).  Prints ONE JSON line on rank 0.
+resident in HBM (`value`); a second timed region starts from the trace in pinned host memory, the upload overlapped with the
+extension (`prover_ms_incl_upload`, the PCIe-inclusive figure).  Prints ONE JSON line on rank 0.
 
     python bench.py --gpus 1 --steps 5 --warmup 2
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
@@ -20,6 +21,30 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 W_FIB = 20                     # registers of the Fibonacci trace
+
+
+def phase_algorithmic_bytes(n, W, B):
+    """minimum unavoidable HBM bytes of each prover phase, counted ONCE per phase (E = 16-byte elements)."""
+    E, N = 16, n * B
+    return {
+        "lde": W * n * E + W * N * E,
+        "trace_merkle": W * N * E + N * 32 + N * 32,
+        "constraint_eval": (N // 4) * W * E + 3 * 8 * n * E,
+        "combine": 3 * 8 * n * E + 8 * n * E,
+        "constraint_lde_merkle": 8 * n * E + N * E + (N // 2) * 32,
+        "deep_composition": W * n * E + 8 * n * E + N * E,
+        "fri": int(4 / 3 * (N * E + N * 20)),
+    }
+
+
+def csrc_digest():
+    """digest of the kernel sources (same rule as __graft_entry__._sources_digest): ties a rocprofv3 summary to the code it measured"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "distaff_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "distaff_amd", "csrc", "*.hip"))):
+        h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def cpu_baseline(log_n, blowup=32, queries=50):
@@ -46,6 +71,8 @@ def main():
     ap.add_argument("--log-blowup", type=int, default=5, help="log2 of the extension factor (default ProofOptions: 5; BASELINE config 5: 4)")
     ap.add_argument("--queries", type=int, default=50, help="number of queries (default ProofOptions: 50; BASELINE config 5: 100)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true", help="skip the one-time check of the timed proof by the oracle's verifier (outside the timed regions)")
+    ap.add_argument("--no-upload-leg", action="store_true", help="skip the second timed region (trace starting in pinned host memory)")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (multi-GPU) code path even with one rank")
     args = ap.parse_args()
 
@@ -143,6 +170,24 @@ def main():
     all_stats = ctx.kernel_stats(reset=True)
     ctx.set_profiling(0)
 
+    # second timed region (single context only): the trace starts in page-locked HOST memory, as stark::prove receives it (prover.rs:17);
+    # the upload is asynchronous DMA and the registers are extended group by group as they arrive
+    incl_upload_ms = None
+    if transport == "none" and not args.no_upload_leg:
+        table, handle = ctx.pinned_trace(cols)
+        for _ in range(max(1, args.warmup)):
+            ctx.upload_async(table); proof_u = ctx.prove([1, 0], [result])
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            ctx.upload_async(table)
+            proof_u = ctx.prove([1, 0], [result])
+        barrier()
+        incl_upload_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        ctx.release_pinned(handle)
+        if proof_u != proof:
+            raise SystemExit("the proof made from the asynchronously uploaded trace differs from the one made from the resident trace")
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -156,30 +201,81 @@ def main():
     roofline = None
 
     def pmc_traffic(kernel):
-        """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command (profiles/README.md):
-        FETCH_SIZE doubled (gfx950 correction for wide coalesced reads) + WRITE_SIZE, both converted from KiB."""
+        """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command (profiles/README.md): FETCH_SIZE
+        doubled (gfx950 correction for wide coalesced reads) + WRITE_SIZE, both converted from KiB.  Only a summary whose stamp
+        (profiles/<tag>_meta.json: digest of the kernel sources) matches the sources of THIS run is accepted: a stale one gives null."""
         import csv
         import glob
         files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_per_kernel.csv")))
         if not files:
-            return None, None
+            return None, "no PMC summary under profiles/"
+        meta_path = files[-1].replace("_pmc_per_kernel.csv", "_meta.json")
+        if not os.path.exists(meta_path):
+            return None, os.path.basename(files[-1]) + " carries no stamp"
+        meta = json.load(open(meta_path))
+        if meta.get("csrc_sha16") != csrc_digest():
+            return None, "%s was taken on kernel sources %s, this run is %s: refused" % (os.path.basename(files[-1]), meta.get("csrc_sha16"), csrc_digest())
         with open(files[-1], newline="") as fh:
             for row in csv.DictReader(fh):
                 if row["kernel"].replace("void ", "").replace(" ", "").startswith(kernel.replace(" ", "")) and row["fetch_bytes_per_launch_x2"] and row["write_bytes_per_launch_raw"]:
-                    return int(row["fetch_bytes_per_launch_x2"]) + int(row["write_bytes_per_launch_raw"]), os.path.basename(files[-1])
-        return None, None
+                    return int(row["fetch_bytes_per_launch_x2"]) + int(row["write_bytes_per_launch_raw"]), "%s (git %s)" % (os.path.basename(files[-1]), str(meta.get("git_head"))[:10])
+        return None, "kernel not in " + os.path.basename(files[-1])
     default_workload = log_n == 20 and world == 1 and (blowup, args.queries) == (32, 50)     # what the committed PMC passes were taken on
     if dom[0]:
         name, st = dom
         per_launch_ms = st["ms"] / st["launches"]
         per_launch_bytes = st["bytes"] / st["launches"]
         achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+        traffic, traffic_source = pmc_traffic(name) if default_workload else (None, "PMC passes exist for the default workload only")
         roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(name)[0] if default_workload else None,
-                    "traffic_source": pmc_traffic(name)[1] if default_workload else None,
+                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                     "launches_per_step": st["launches"] / args.steps, "avg_launch_ms": round(per_launch_ms, 4),
                     "algorithmic_bytes_per_launch": per_launch_bytes,
                     "note": "the path is 128-bit modular integer arithmetic on the VALU: see alu_roofline and DESIGN.md"}
+    # phase-level HBM fractions: SURVEY section 8(d)'s bytes counted once per phase, against the phase's wall time
+    phase_names = ["lde", "trace_merkle", "constraint_eval", "combine", "constraint_lde_merkle", "deep_composition", "fri", "pow_queries", "openings"]
+    phase_hbm = None
+    if transport == "none":
+        pb = phase_algorithmic_bytes(n, W_FIB, blowup)
+        phase_hbm = {}
+        for k, v in zip(phase_names, phase_sum):
+            if k in pb and v > 0:
+                gbs = pb[k] / (v / args.steps * 1e-3) / 1e9
+                phase_hbm[k] = {"algorithmic_GiB": round(pb[k] / 2**30, 3), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        total_b = sum(pb.values())
+        gbs = total_b / (ms_per_step * 1e-3) / 1e9
+        phase_hbm["proof"] = {"algorithmic_GiB": round(total_b / 2**30, 3), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+    # integer-multiplier roofline: the peak of v_mad_u64_u32 (the 32x32+64 multiply-add every field multiplication is made of) measured
+    # on this device, against the multiply-adds the kernels execute: NTT launches count theirs (18 per table-pair multiplication), the
+    # constraint kernels are priced with the static instruction counts of the current build (distaff_amd/_build_info.json)
+    mad_iters = 2048
+    mad_ms = ctx.bench_mad(1 << 21, mad_iters)
+    mad_peak = (1 << 21) * mad_iters * 32 / (mad_ms * 1e-3)
+    air_isa = {}
+    try:
+        air_isa = json.load(open(os.path.join(ROOT, "distaff_amd", "_build_info.json"))).get("air_isa", {})
+    except Exception:                                                # noqa: BLE001
+        pass
+    points = 8 * n // world
+
+    def kernel_mads(name, st):
+        if st.get("mads", 0) > 0:
+            return st["mads"]
+        if name in air_isa:
+            return float(air_isa[name]["mad64"]) * points * st["launches"]
+        return 0.0
+    alu = {"unit": "mad/s (v_mad_u64_u32: 32x32+64 multiply-add per lane)", "peak": mad_peak,
+           "peak_source": "mad_peak_kernel, 2^21 lanes x %d iterations x 32 mads, %.3f ms" % (mad_iters, mad_ms)}
+    if dom[0]:
+        name, st = dom
+        m = kernel_mads(name, st)
+        alu.update({"kernel": name, "achieved": m / (st["ms"] * 1e-3), "frac": round(m / (st["ms"] * 1e-3) / mad_peak, 4),
+                    "mads_per_launch": m / st["launches"]})
+    counted = {k: kernel_mads(k, v) for k, v in all_stats.items()}
+    proof_mads = sum(counted.values())
+    alu["proof"] = {"mads": proof_mads, "achieved": proof_mads / (ms_per_step * 1e-3), "frac": round(proof_mads / (ms_per_step * 1e-3) / mad_peak, 4),
+                    "counted_kernels": sorted(k for k, v in counted.items() if v > 0),
+                    "note": "multiply-adds of the NTT passes and the constraint kernels (the other kernels' are not counted) over the whole proof time"}
     # ALU ceiling: dependent-chain modular multiplications per second measured on this device with the same fe_mul
     mm_ms = ctx.bench_mulmod(1 << 21, 512)
     mulmod_peak = (1 << 21) * 512 * 4 / (mm_ms * 1e-3)
@@ -198,11 +294,21 @@ def main():
         "proof_bytes": len(proof),
         "shard_stage_ms_rank0": {k: round(v / args.steps, 3) for k, v in stage_sum.items()} or None,
         "roofline": roofline,
-        "alu_roofline": {"unit": "mulmod/s", "peak_measured": mulmod_peak, "kernel": "mulmod_bench_kernel (4 dependent chains per lane)"},
+        "alu_roofline": dict(alu, mulmod_peak_measured=mulmod_peak, mulmod_kernel="mulmod_bench_kernel: general fe_mul, 4 dependent chains per lane (21 mads + 50 other VALU instructions each)"),
+        "phase_hbm": phase_hbm,
+        "prover_ms_incl_upload": incl_upload_ms,
+        "upload_note": None if incl_upload_ms is None else "trace (%d MiB) in pinned host memory at the start of every step; asynchronous upload in groups of 4 registers, each group interpolated and extended as it lands" % (n * W_FIB * 16 >> 20),
         "kernels": {k: {"launches": v["launches"], "ms_per_step": round(v["ms"], 3), "GBps": round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)}
                     for k, v in sorted(all_stats.items(), key=lambda kv: -kv[1]["ms"])},
         "kernels_note": "one extra untimed proof with every launch bracketed by events; the roofline kernel is timed inside the timed region",
     }
+    if not args.no_verify:
+        # the checker, outside every timed region: the oracle's restatement of the reference verifier must accept the timed proof
+        import oracle as O
+        ok, err = O.verify(proof, program_hash, [1, 0], [result])
+        if not ok:
+            raise SystemExit("the oracle's verifier rejects the timed proof: " + err)
+        out["proof_verified"] = "accepted by oracle/verifier.hpp (restatement of stark::verify) after the timed regions"
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.cpu_log_n, blowup, args.queries)
     print(json.dumps(out), flush=True)

@@ -90,6 +90,8 @@ static void free_all(dst_ctx* c) {
         if (c->fri_leaves[d]) hipFree(c->fri_leaves[d]);
         if (c->fri_nodes[d]) hipFree(c->fri_nodes[d]);
     }
+    for (hipEvent_t e : c->upload_done) hipEventDestroy(e);
+    if (c->upload_stream) hipStreamDestroy(c->upload_stream);
     if (c->stream) hipStreamDestroy(c->stream);
 }
 
@@ -248,6 +250,7 @@ int dst_trace_upload(dst_ctx* c, const uint8_t* const* cols) {
     HIP_TRY(c, hipSetDevice(c->device));
     for (size_t i = 0; i < c->W; i++) HIP_TRY(c, hipMemcpyAsync(c->trace + i * c->n, cols[i], c->n * 16, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->upload_pending = false;
     c->have_trace = true; c->committed = c->constraints_done = c->composed = false;
     return DST_OK;
 }
@@ -255,6 +258,35 @@ int dst_trace_upload_contiguous(dst_ctx* c, const uint8_t* cols) {
     if (!c || !cols) return DST_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipMemcpy(c->trace, cols, c->W * c->n * 16, hipMemcpyHostToDevice));
+    c->upload_pending = false;
+    c->have_trace = true; c->committed = c->constraints_done = c->composed = false;
+    return DST_OK;
+}
+
+// Pinned host memory for the trace: the reference hands stark::prove a host-resident TraceTable (prover.rs:17, trace_table.rs:10); from
+// pinned memory the upload runs as asynchronous DMA and overlaps with the extension of the registers that have already arrived.
+int dst_pinned_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return DST_ERR_ARG;
+    return hipHostMalloc(out, bytes, hipHostMallocDefault) == hipSuccess ? DST_OK : DST_ERR_HIP;
+}
+int dst_pinned_free(void* p) { return (!p || hipHostFree(p) == hipSuccess) ? DST_OK : DST_ERR_HIP; }
+
+// Starts the upload of the W register columns (host pointers, ideally from dst_pinned_alloc) on a copy stream and returns at once.  The
+// next dst_commit_trace / dst_prove interpolates and extends the registers group by group as their copies complete, so only the first
+// group's transfer is exposed.  The host buffers must stay valid until that call returns.
+int dst_trace_upload_async(dst_ctx* c, const uint8_t* const* cols) {
+    if (!c || !cols) return DST_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c->upload_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
+    c->upload_group = 4;                                              // registers per extension launch (see k_lde_columns)
+    const size_t groups = (c->W + c->upload_group - 1) / c->upload_group;
+    while (c->upload_done.size() < groups) { hipEvent_t e; HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->upload_done.push_back(e); }
+    for (size_t g = 0; g < groups; g++) {
+        for (size_t i = g * c->upload_group; i < c->W && i < (g + 1) * c->upload_group; i++)
+            HIP_TRY(c, hipMemcpyAsync(c->trace + i * c->n, cols[i], c->n * 16, hipMemcpyHostToDevice, c->upload_stream));
+        HIP_TRY(c, hipEventRecord(c->upload_done[g], c->upload_stream));
+    }
+    c->upload_pending = true;
     c->have_trace = true; c->committed = c->constraints_done = c->composed = false;
     return DST_OK;
 }
@@ -266,8 +298,19 @@ int dst_commit_trace(dst_ctx* c, uint8_t trace_root[32]) {
     HIP_TRY(c, hipSetDevice(c->device));
     c->sharded_layout = false;
     double t0 = wall_ms();
-    k_intt_columns(c, c->trace, c->polys, c->W);                 // interpolate_fft_twiddles (trace_table.rs:159)
-    k_lde_columns(c, c->polys, c->lde, c->W);                    // eval_fft_twiddles over the LDE domain (trace_table.rs:166)
+    if (c->upload_pending) {
+        // registers arrive in groups (dst_trace_upload_async): each group is interpolated and extended as soon as its copy has landed
+        for (size_t g = 0, first = 0; first < c->W; g++, first += c->upload_group) {
+            const size_t cnt = c->W - first < c->upload_group ? c->W - first : c->upload_group;
+            HIP_TRY(c, hipStreamWaitEvent(c->stream, c->upload_done[g], 0));
+            k_intt_columns(c, c->trace + first * c->n, c->polys + first * c->n, cnt);
+            k_lde_columns(c, c->polys + first * c->n, c->lde + first * c->Bc * c->n, cnt);
+        }
+        c->upload_pending = false;
+    } else {
+        k_intt_columns(c, c->trace, c->polys, c->W);                 // interpolate_fft_twiddles (trace_table.rs:159)
+        k_lde_columns(c, c->polys, c->lde, c->W);                    // eval_fft_twiddles over the LDE domain (trace_table.rs:166)
+    }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     double t1 = wall_ms();
     k_trace_leaves(c);                                           // trace_table.rs:174-185
@@ -639,7 +682,7 @@ int dst_kernel_stats(dst_ctx* c, char* json_out, size_t cap, int reset) {
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     for (auto& e : c->kpending) {
         float ms = 0;
-        if (hipEventElapsedTime(&ms, e.e0, e.e1) == hipSuccess) { auto& st = c->kstats[e.name]; st.launches++; st.ms += ms; st.bytes += e.bytes; }
+        if (hipEventElapsedTime(&ms, e.e0, e.e1) == hipSuccess) { auto& st = c->kstats[e.name]; st.launches++; st.ms += ms; st.bytes += e.bytes; st.mads += e.mads; }
         c->event_pool.push_back(e.e0); c->event_pool.push_back(e.e1);
     }
     c->kpending.clear();
@@ -647,8 +690,8 @@ int dst_kernel_stats(dst_ctx* c, char* json_out, size_t cap, int reset) {
     bool first = true;
     for (auto& kv : c->kstats) {
         char buf[256];
-        snprintf(buf, sizeof(buf), "%s\"%s\": {\"launches\": %llu, \"ms\": %.6f, \"bytes\": %.0f}", first ? "" : ", ", kv.first.c_str(),
-                 (unsigned long long)kv.second.launches, kv.second.ms, kv.second.bytes);
+        snprintf(buf, sizeof(buf), "%s\"%s\": {\"launches\": %llu, \"ms\": %.6f, \"bytes\": %.0f, \"mads\": %.0f}", first ? "" : ", ", kv.first.c_str(),
+                 (unsigned long long)kv.second.launches, kv.second.ms, kv.second.bytes, kv.second.mads);
         js += buf; first = false;
     }
     js += "}";
@@ -662,6 +705,11 @@ int dst_bench_mulmod(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms) {
     if (!c || !ms) return DST_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     return k_bench_mulmod(c, lanes, iters, ms);
+}
+int dst_bench_mad(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms) {
+    if (!c || !ms) return DST_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return k_bench_mad(c, lanes, iters, ms);
 }
 
 }  // extern "C"

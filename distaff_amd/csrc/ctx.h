@@ -124,24 +124,30 @@ struct dst_ctx {
     uint64_t op_count = 0;
     fe program_hash[2] = {};
     bool have_trace = false, committed = false, constraints_done = false, composed = false;
+    // asynchronous upload (dst_trace_upload_async): column group g is complete when upload_done[g] has fired on upload_stream
+    hipStream_t upload_stream = nullptr;
+    std::vector<hipEvent_t> upload_done;
+    size_t upload_group = 0;            // registers per group
+    bool upload_pending = false;
     double phase_ms[9] = {0};
 
     // optional per-kernel timing with HIP events recorded on `stream` (dst_set_profiling / dst_kernel_stats)
     int profile = 0;                       // dst_set_profiling: 0 off, 1 every kernel launch, 2 only the heavy kernels (NTT passes, constraint kernel, leaf hashing)
-    struct KEvent { hipEvent_t e0, e1; std::string name; double bytes; };
+    struct KEvent { hipEvent_t e0, e1; std::string name; double bytes, mads; };
     std::vector<KEvent> kpending;
     std::vector<hipEvent_t> event_pool;    // recycled profiling events
-    struct KStat { uint64_t launches = 0; double ms = 0, bytes = 0; };
+    struct KStat { uint64_t launches = 0; double ms = 0, bytes = 0, mads = 0; };
     std::map<std::string, KStat> kstats;
 };
 
-// brackets one kernel launch with events when profiling is on; `bytes` = algorithmic HBM bytes of that launch
+// brackets one kernel launch with events when profiling is on; `bytes` = algorithmic HBM bytes of that launch, `mads` = 32x32+64
+// multiply-adds (v_mad_u64_u32) the launch executes per the kernel's arithmetic (0 where not counted)
 struct KScope {
     dst_ctx* c; bool on;
     dst_ctx::KEvent ev;
-    KScope(dst_ctx* ctx, const char* name, double bytes, bool heavy = false) : c(ctx), on(ctx->profile == 1 || (ctx->profile == 2 && heavy)) {
+    KScope(dst_ctx* ctx, const char* name, double bytes, bool heavy = false, double mads = 0.0) : c(ctx), on(ctx->profile == 1 || (ctx->profile == 2 && heavy)) {
         if (!on) return;
-        ev.name = name; ev.bytes = bytes;
+        ev.name = name; ev.bytes = bytes; ev.mads = mads;
         // events come from a pool that dst_kernel_stats refills: creating two per launch would be host time inside the timed region
         if (c->event_pool.size() >= 2) { ev.e0 = c->event_pool.back(); c->event_pool.pop_back(); ev.e1 = c->event_pool.back(); c->event_pool.pop_back(); }
         else if (hipEventCreate(&ev.e0) != hipSuccess || hipEventCreate(&ev.e1) != hipSuccess) { on = false; return; }
@@ -199,6 +205,7 @@ int k_pow(dst_ctx* c, const uint8_t seed[32], uint32_t grinding, uint64_t* nonce
 void k_gather(dst_ctx* c, const void* src, size_t item_bytes, const uint64_t* idx_dev, size_t count, void* dst);
 void k_gather_rows(dst_ctx* c, const uint64_t* positions_dev, size_t count, fe* out);
 int k_bench_mulmod(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms);
+int k_bench_mad(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms);
 // coset-sharded (multi-GPU) helpers
 void k_merkle_local_levels(dst_ctx* c, digest* nodes, size_t count, size_t stop_count);
 void k_merkle_levels_to(dst_ctx* c, const digest* leaves, digest* nodes, size_t num_leaves, size_t stop_count);

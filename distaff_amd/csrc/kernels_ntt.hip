@@ -424,7 +424,13 @@ static void ntt_launch(dst_ctx* c, bool pass_b, NttArgs& a, size_t groups, size_
     a.groups = (uint32_t)groups; a.cosets = (uint32_t)cosets; a.cols = (uint32_t)cols;
     const dim3 grid((unsigned)(groups * cosets * cols));
     if (a.debug & 1u) ntt_report_occupancy(name, pass_b, lds <= NTT_LDS_TWO_PER_CU ? 512 : 1024, lds);
-    KScope ks_(c, name, bytes, true);
+    // multiply-adds of the launch: 18 per table-pair multiplication (fe_mul_tw); multiplications per element: every DIT stage 1/2, DIF
+    // two-stage rounds 1 each except the last (1/4: the distance-1 stage has no twiddles), plus four-step twiddle / pre-scale / 1/n
+    const uint32_t stages = pass_b ? a.log_n2 : a.log_n1;
+    double mults = (!pass_b && a.dit) ? 0.5 * stages : ((stages & 1u) ? 0.5 * (stages - 1) : (stages >= 2 ? 0.5 * stages - 0.75 : 0.0));
+    if (!pass_b) mults += 1.0 + ((!a.dit && a.prescale != nullptr) ? 1.0 : 0.0); else if (a.has_scale) mults += 1.0;
+    const double elements = (double)groups * a.tiles_per_block * ((size_t)1 << a.tile) * ((size_t)1 << stages) * cosets * cols;
+    KScope ks_(c, name, bytes, true, 18.0 * mults * elements);
     if (lds <= NTT_LDS_TWO_PER_CU) {
         if (pass_b) hipLaunchKernelGGL(ntt_pass_b<512>, grid, dim3(512), lds, c->stream, a, a.src, a.dst);
         else hipLaunchKernelGGL(ntt_pass_a<512>, grid, dim3(512), lds, c->stream, a, a.src, a.dst);
@@ -589,8 +595,9 @@ void k_intt_columns(dst_ctx* c, const fe* src, fe* dst, size_t ncols) {
 void k_lde_columns(dst_ctx* c, const fe* polys, fe* lde, size_t ncols) {
     // coset 0 of the extension is the trace itself (T(w_n^k) for the interpolant T): when this rank owns it and the polynomials are
     // the interpolated trace, it is copied instead of transformed (1/B of the extension work)
-    const uint32_t skip = (c->j0 == 0 && polys == c->polys && c->Bc > 1) ? 1u : 0u;
-    if (skip) (void)hipMemcpy2DAsync(lde, c->Bc * c->n * sizeof(fe), c->trace, c->n * sizeof(fe), c->n * sizeof(fe), ncols, hipMemcpyDeviceToDevice, c->stream);
+    const bool of_trace = polys >= c->polys && polys < c->polys + c->W * c->n;          // a group of the interpolated trace registers
+    const uint32_t skip = (c->j0 == 0 && of_trace && c->Bc > 1) ? 1u : 0u;
+    if (skip) (void)hipMemcpy2DAsync(lde, c->Bc * c->n * sizeof(fe), c->trace + (polys - c->polys), c->n * sizeof(fe), c->n * sizeof(fe), ncols, hipMemcpyDeviceToDevice, c->stream);
     // launch granularity: `bcols` registers x `bcos` cosets per pair of passes (the staging buffer holds tmp_capacity_arrays arrays)
     size_t bcols = tmp_capacity_arrays(c) / c->Bc, bcos = c->Bc - skip;
     if (const char* e = getenv("DISTAFF_LDE_BATCH")) { unsigned x = 0, y = 0; if (sscanf(e, "%u,%u", &x, &y) == 2 && x >= 1 && y >= 1 && (size_t)x * y <= tmp_capacity_arrays(c)) { bcols = x; bcos = y; } }

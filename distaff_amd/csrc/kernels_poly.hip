@@ -385,6 +385,38 @@ int k_bench_mulmod(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms) {
     return DST_OK;
 }
 
+// ---- peak of the 32x32+64 multiply-add (v_mad_u64_u32): eight accumulators per lane, 32 mads per iteration, nothing else in the loop.
+// The integer-multiplier roofline of the path: every modular multiplication is 18 or 21 of these plus carry handling.
+#define MAD_PEAK_PER_ITER 32
+__global__ void __launch_bounds__(PT) mad_peak_kernel(uint64_t* out, uint32_t iters) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t a0 = tid, a1 = tid + 1, a2 = tid + 2, a3 = tid + 3, a4 = tid + 4, a5 = tid + 5, a6 = tid + 6, a7 = tid + 7;
+    const uint32_t x = tid * 2654435761u + 12345u, y = tid ^ 0xDEADBEEFu;
+    for (uint32_t i = 0; i < iters; i++) {
+#pragma unroll
+        for (int u = 0; u < MAD_PEAK_PER_ITER / 8; u++) {
+            a0 = (uint64_t)x * (uint32_t)a7 + a0; a1 = (uint64_t)y * (uint32_t)a0 + a1; a2 = (uint64_t)x * (uint32_t)a1 + a2; a3 = (uint64_t)y * (uint32_t)a2 + a3;
+            a4 = (uint64_t)x * (uint32_t)a3 + a4; a5 = (uint64_t)y * (uint32_t)a4 + a5; a6 = (uint64_t)x * (uint32_t)a5 + a6; a7 = (uint64_t)y * (uint32_t)a6 + a7;
+        }
+    }
+    out[tid] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+}
+int k_bench_mad(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms) {
+    if (lanes > c->scratch_elems * 2 || lanes < PT) { c->err = "dst_bench_mad: lanes must be in [256, 2^22]"; return DST_ERR_ARG; }
+    lanes = lanes / PT * PT;
+    hipEvent_t e0, e1;
+    HIP_TRY(c, hipEventCreate(&e0)); HIP_TRY(c, hipEventCreate(&e1));
+    hipLaunchKernelGGL(mad_peak_kernel, dim3((unsigned)(lanes / PT)), dim3(PT), 0, c->stream, (uint64_t*)c->scratch, 4u);
+    HIP_TRY(c, hipEventRecord(e0, c->stream));
+    hipLaunchKernelGGL(mad_peak_kernel, dim3((unsigned)(lanes / PT)), dim3(PT), 0, c->stream, (uint64_t*)c->scratch, iters);
+    HIP_TRY(c, hipEventRecord(e1, c->stream));
+    HIP_TRY(c, hipEventSynchronize(e1));
+    float f = 0; HIP_TRY(c, hipEventElapsedTime(&f, e0, e1));
+    *ms = f;
+    hipEventDestroy(e0); hipEventDestroy(e1);
+    return DST_OK;
+}
+
 // ---- element-wise field operations on caller data (test hook behind dst_field_op) ---------------------------------------------------------
 __global__ void field_op_kernel(int op, const fe* a, const fe* b, fe* out, size_t count) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;

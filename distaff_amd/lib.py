@@ -21,7 +21,7 @@ BUF = {"polys": 0, "lde": 1, "trace_leaves": 2, "trace_nodes": 3, "ceval_i": 4, 
 EXPORTS = ["dst_ctx_create", "dst_ctx_destroy", "dst_last_error", "dst_phase_ms", "dst_trace_upload", "dst_trace_upload_contiguous",
            "dst_commit_trace", "dst_eval_constraints", "dst_compose", "dst_fri_commit_layer", "dst_fri_fold", "dst_pow_grind",
            "dst_build_proof", "dst_prove", "dst_prng_vector", "dst_query_positions", "dst_blake3", "dst_fibonacci_trace",
-           "dst_read_buffer", "dst_bench_mulmod", "dst_set_profiling", "dst_kernel_stats", "dst_field_op",
+           "dst_read_buffer", "dst_bench_mulmod", "dst_bench_mad", "dst_trace_upload_async", "dst_pinned_alloc", "dst_pinned_free", "dst_set_profiling", "dst_kernel_stats", "dst_field_op",
            "dst_shard_commit_trace", "dst_shard_eval_constraints", "dst_shard_combine", "dst_shard_fri_layer", "dst_shard_fri_fold",
            "dst_shard_export_size", "dst_shard_export", "dst_shard_import", "dst_shard_read", "dst_shard_fri_begin", "dst_shard_fri_end", "dst_shard_fri_roots", "dst_shard_open", "dst_shard_assemble", "dst_shard_info"]
 
@@ -174,6 +174,25 @@ class Context:
         cols = np.ascontiguousarray(columns, dtype=np.uint64)
         assert cols.shape == (self.W, self.n, 2), cols.shape
         self._check(self.lib.dst_trace_upload_contiguous(self._h, _ptr(cols)))
+
+    def pinned_trace(self, columns):
+        """Copies the trace into page-locked host memory owned by the library and returns (pointer table, keep-alive handle) for
+        upload_async: the host-resident TraceTable of the reference, placed where asynchronous DMA can read it."""
+        cols = np.ascontiguousarray(columns, dtype=np.uint64)
+        assert cols.shape == (self.W, self.n, 2), cols.shape
+        p = ctypes.c_void_p()
+        if self.lib.dst_pinned_alloc(ctypes.c_size_t(cols.nbytes), ctypes.byref(p)) != DST_OK:
+            raise DistaffError(DST_ERR_HIP, "dst_pinned_alloc failed")
+        ctypes.memmove(p, cols.ctypes.data, cols.nbytes)
+        table = (ctypes.c_void_p * self.W)(*[p.value + i * self.n * 16 for i in range(self.W)])
+        return table, p
+
+    def release_pinned(self, handle):
+        self.lib.dst_pinned_free(handle)
+
+    def upload_async(self, table):
+        """dst_trace_upload_async: returns at once, the next commit_trace() / prove() consumes the registers as they arrive"""
+        self._check(self.lib.dst_trace_upload_async(self._h, table))
 
     def commit_trace(self):
         root = ctypes.create_string_buffer(32)
@@ -353,6 +372,12 @@ class Context:
         out = np.zeros_like(a)
         self._check(self.lib.dst_field_op(self._h, ops[op], _ptr(a), _ptr(b), _ptr(out), ctypes.c_size_t(a.shape[0])))
         return out
+
+    def bench_mad(self, lanes=1 << 21, iters=2048):
+        """milliseconds for lanes * iters * 32 multiply-adds v_mad_u64_u32 (the integer-multiplier peak of the device)"""
+        ms = ctypes.c_double(0)
+        self._check(self.lib.dst_bench_mad(self._h, ctypes.c_uint64(lanes), ctypes.c_uint32(iters), ctypes.byref(ms)))
+        return ms.value
 
     def bench_mulmod(self, lanes=1 << 20, iters=256, portable=False):
         ms = ctypes.c_double(0)

@@ -68,6 +68,13 @@ int dst_phase_ms(const dst_ctx* ctx, double out_ms[9]);
 int dst_trace_upload(dst_ctx* ctx, const uint8_t* const* cols);
 /* same, from one contiguous [W][n] buffer */
 int dst_trace_upload_contiguous(dst_ctx* ctx, const uint8_t* cols);
+/* Asynchronous form for a host-resident trace (what stark::prove receives: prover.rs:17, trace_table.rs:10).  Starts the copies of
+ * the W columns on a copy stream and returns at once; the next dst_commit_trace / dst_prove interpolates and extends the registers
+ * group by group as their copies land, so that all but the first group's transfer overlaps with the extension.  The host buffers
+ * must stay valid until that call returns; for real overlap they must be page-locked (dst_pinned_alloc or the host's own pinning). */
+int dst_trace_upload_async(dst_ctx* ctx, const uint8_t* const* cols);
+int dst_pinned_alloc(size_t bytes, void** out);
+int dst_pinned_free(void* p);
 
 /* ---- steps 1-2: TraceTable::extend + build_merkle_tree (prover.rs:22-35; trace_table.rs:143,174) ---------------------- */
 int dst_commit_trace(dst_ctx* ctx, uint8_t trace_root[32]);
@@ -153,6 +160,9 @@ int dst_read_buffer(dst_ctx* ctx, uint32_t what, uint32_t arg, uint8_t* out, siz
 /* micro-benchmark hook used by bench.py's roofline section: runs `iters` dependent modular multiplications per lane
  * on `lanes` lanes and returns the elapsed milliseconds. */
 int dst_bench_mulmod(dst_ctx* ctx, uint64_t lanes, uint32_t iters, double* ms);
+/* peak of the 32x32+64 multiply-add (v_mad_u64_u32) on this device: `iters` iterations of 32 independent-enough mads per lane on
+ * `lanes` lanes; returns the elapsed milliseconds (rate = lanes * iters * 32 / time).  The integer-multiplier roofline of the path. */
+int dst_bench_mad(dst_ctx* ctx, uint64_t lanes, uint32_t iters, double* ms);
 /* element-wise device field arithmetic on caller data (tests): op 0 add, 1 sub, 2 mul, 3 mul (portable formulation), 4 inv(a), 5 a^b */
 int dst_field_op(dst_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t count);
 /* per-kernel timing with HIP events on the context's stream.  level 0: off; 1: every kernel launch is bracketed (costs ~5 % of a

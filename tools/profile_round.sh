@@ -16,4 +16,18 @@ rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST
 cd $R
 grep -h metric $OUT/stats.log > $OUT/bench_under_rocprof.json
 python tools/summarize_profile.py $OUT $R/gpurun_out/profiles_$TAG $TAG
+# stamp: the kernel sources these numbers were measured on (bench.py refuses a PMC summary whose stamp differs from the sources it runs)
+python - <<PY
+import json, os, sys
+sys.path.insert(0, "$R")
+import bench
+info = {}
+try:
+    info = json.load(open(os.path.join("$R", "distaff_amd", "_build_info.json")))
+except Exception:
+    pass
+json.dump({"tag": "$TAG", "csrc_sha16": bench.csrc_digest(), "git_head": info.get("git_head"), "command": "$CMD",
+           "note": "git_head is the commit the shared library was built at (the GPU box has no .git); csrc_sha16 is the digest of distaff_amd/csrc at the time of the run"},
+          open(os.path.join("$R", "gpurun_out", "profiles_$TAG", "${TAG}_meta.json"), "w"), indent=1)
+PY
 ls -la $R/gpurun_out/profiles_$TAG
