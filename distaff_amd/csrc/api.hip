@@ -97,7 +97,7 @@ static void free_all(dst_ctx* c) {
 
 static int ctx_init(dst_ctx* c) {
     const dst_params& p = c->prm;
-    if (p.log_trace_length < 6 || p.log_trace_length > 24) { c->err = "log_trace_length must be in [6, 24]"; return DST_ERR_ARG; }
+    if (p.log_trace_length < 4 || p.log_trace_length > 24) { c->err = "log_trace_length must be in [4, 24]"; return DST_ERR_ARG; }      // lib.rs:82 MIN_TRACE_LENGTH = 16
     if (p.log_blowup < 4 || p.log_blowup > 8) { c->err = "extension factor must be in [16, 256]"; return DST_ERR_ARG; }
     if (p.ctx_depth > 16 || p.loop_depth > 8) { c->err = "context / loop depth out of range"; return DST_ERR_ARG; }
     if (p.width >= 128 || p.width <= 15 + p.ctx_depth + p.loop_depth) { c->err = "register count out of range"; return DST_ERR_ARG; }
@@ -608,6 +608,8 @@ void dst_prng_vector(const uint8_t seed[32], uint32_t count, uint8_t* out) {
     memcpy(out, v.data(), (size_t)count * 16);
 }
 int dst_query_positions(const uint8_t seed[32], uint64_t domain_size, uint32_t blowup, uint32_t num_queries, uint64_t* out) {
+    // an error code, never an abort: a zero domain or extension factor would divide by zero, and the caller's buffer holds at most 128 positions
+    if (!seed || !out || domain_size == 0 || blowup == 0 || num_queries == 0 || num_queries > 128) return DST_ERR_ARG;
     std::vector<uint64_t> p;
     if (query_positions(seed, domain_size, blowup, num_queries, p)) return DST_ERR_ARG;
     memcpy(out, p.data(), p.size() * 8);

@@ -59,7 +59,7 @@ __device__ __forceinline__ void hash_elements(Get get, uint32_t count, uint32_t*
 __global__ void __launch_bounds__(HASH_THREADS) trace_leaves_kernel(const fe* __restrict__ lde, digest* __restrict__ leaves,
                                                                    uint32_t W, size_t n, uint32_t Bc, uint32_t log_jt) {
     __shared__ digest tile[HASH_THREADS];
-    const uint32_t JT = 1u << log_jt, KT = HASH_THREADS >> log_jt;
+    const uint32_t JT = 1u << log_jt, KT = blockDim.x >> log_jt;          // the launcher shrinks the block for tiny traces
     const uint32_t kk = threadIdx.x % KT, jj = threadIdx.x / KT;
     const size_t k = (size_t)blockIdx.x * KT + kk;
     const uint32_t j = blockIdx.y * JT + jj;
@@ -74,12 +74,19 @@ __global__ void __launch_bounds__(HASH_THREADS) trace_leaves_kernel(const fe* __
     leaves[out] = tile[kk2 * JT + jj2];
 }
 
+// block size of the tile-transposing kernels: HASH_THREADS lanes = (HASH_THREADS >> log_t) indices k x 2^log_t cosets, fewer lanes when
+// the array has fewer than that many k (tiny traces, or many ranks at a small blowup): the grid never comes out empty
+static uint32_t tile_threads(size_t extent, uint32_t log_t) {
+    const size_t want = extent << log_t;
+    return (uint32_t)(want < HASH_THREADS ? want : HASH_THREADS);
+}
+
 void k_trace_leaves(dst_ctx* c) {
     uint32_t jt = c->Bc < 32 ? (uint32_t)c->Bc : 32u, log_jt = 0;
     while ((1u << log_jt) < jt) log_jt++;
-    uint32_t KT = HASH_THREADS >> log_jt;
+    const uint32_t threads = tile_threads(c->n, log_jt), KT = threads >> log_jt;
     dim3 g((unsigned)(c->n / KT), (unsigned)(c->Bc >> log_jt));
-    { KScope ks_(c, "trace_leaves_kernel", (16.0 * c->W + 32.0) * c->Bc * c->n, true); hipLaunchKernelGGL(trace_leaves_kernel, g, dim3(HASH_THREADS), 0, c->stream, (const fe*)c->lde, c->trace_leaves, (uint32_t)c->W, c->n, (uint32_t)c->Bc, log_jt); }
+    { KScope ks_(c, "trace_leaves_kernel", (16.0 * c->W + 32.0) * c->Bc * c->n, true); hipLaunchKernelGGL(trace_leaves_kernel, g, dim3(threads), 0, c->stream, (const fe*)c->lde, c->trace_leaves, (uint32_t)c->W, c->n, (uint32_t)c->Bc, log_jt); }
 }
 
 // ---- generic Merkle levels: out[i] = H(children[2i] || children[2i+1]) -------------------------------------------------------
@@ -134,7 +141,7 @@ void k_merkle_levels(dst_ctx* c, const digest* leaves, digest* nodes, size_t num
 __global__ void __launch_bounds__(HASH_THREADS) constraint_level1_kernel(const fe* __restrict__ cevals, digest* __restrict__ out,
                                                                         size_t n, uint32_t Bc, uint32_t log_qt) {
     __shared__ digest tile[HASH_THREADS];
-    const uint32_t QT = 1u << log_qt, KT = HASH_THREADS >> log_qt;
+    const uint32_t QT = 1u << log_qt, KT = blockDim.x >> log_qt;
     const uint32_t kk = threadIdx.x % KT, qq = threadIdx.x / KT;
     const size_t k = (size_t)blockIdx.x * KT + kk;
     const uint32_t q = blockIdx.y * QT + qq;
@@ -157,10 +164,10 @@ void k_constraint_tree(dst_ctx* c) {
     uint32_t qn = (uint32_t)(c->Bc / 4);
     uint32_t qt = qn < 32 ? qn : 32u, log_qt = 0;
     while ((1u << log_qt) < qt) log_qt++;
-    uint32_t KT = HASH_THREADS >> log_qt;
+    const uint32_t threads = tile_threads(c->n, log_qt), KT = threads >> log_qt;
     size_t level1 = c->N / 4;          // leaves = N/2, first node level = N/4 entries at nodes[N/4 ..)
     dim3 g((unsigned)(c->n / KT), (unsigned)(qn >> log_qt));
-    { KScope ks_(c, "constraint_level1_kernel", 96.0 * level1); hipLaunchKernelGGL(constraint_level1_kernel, g, dim3(HASH_THREADS), 0, c->stream, (const fe*)c->cevals, c->cnodes + level1, c->n, (uint32_t)c->Bc, log_qt); }
+    { KScope ks_(c, "constraint_level1_kernel", 96.0 * level1); hipLaunchKernelGGL(constraint_level1_kernel, g, dim3(threads), 0, c->stream, (const fe*)c->cevals, c->cnodes + level1, c->n, (uint32_t)c->Bc, log_qt); }
     merkle_upper_levels(c, c->cnodes, level1);
 }
 
@@ -169,7 +176,7 @@ void k_constraint_tree(dst_ctx* c) {
 __global__ void __launch_bounds__(HASH_THREADS) fri_leaves0_kernel(const fe* __restrict__ comp, digest* __restrict__ leaves,
                                                                   size_t n, uint32_t Bc, uint32_t log_jt) {
     __shared__ digest tile[HASH_THREADS];
-    const uint32_t JT = 1u << log_jt, KT = HASH_THREADS >> log_jt;
+    const uint32_t JT = 1u << log_jt, KT = blockDim.x >> log_jt;          // the launcher shrinks the block for tiny traces
     const uint32_t kk = threadIdx.x % KT, jj = threadIdx.x / KT;
     const size_t k = (size_t)blockIdx.x * KT + kk;
     const uint32_t j = blockIdx.y * JT + jj;
@@ -192,14 +199,10 @@ __global__ void __launch_bounds__(HASH_THREADS) fri_leaves0_kernel(const fe* __r
 void k_fri_leaves_layer0(dst_ctx* c) {
     uint32_t jt = c->Bc < 32 ? (uint32_t)c->Bc : 32u, log_jt = 0;
     while ((1u << log_jt) < jt) log_jt++;
-    uint32_t KT = HASH_THREADS >> log_jt;
     size_t kq = c->n / 4;
-    if (kq < KT) {   // tiny traces: shrink the tile along k by growing it along j is not possible; fall back to one k per block row
-        KT = (uint32_t)kq;
-    }
+    const uint32_t threads = tile_threads(kq, log_jt), KT = threads >> log_jt;
     dim3 g((unsigned)(kq / KT), (unsigned)(c->Bc >> log_jt));
-    // note: when KT was reduced the kernel still derives KT from HASH_THREADS >> log_jt, so tiny sizes use the natural-order path instead
-    { KScope ks_(c, "fri_leaves0_kernel", 96.0 * kq * c->Bc); hipLaunchKernelGGL(fri_leaves0_kernel, g, dim3(HASH_THREADS), 0, c->stream, (const fe*)c->comp, c->fri_leaves[0], c->n, (uint32_t)c->Bc, log_jt); }
+    { KScope ks_(c, "fri_leaves0_kernel", 96.0 * kq * c->Bc); hipLaunchKernelGGL(fri_leaves0_kernel, g, dim3(threads), 0, c->stream, (const fe*)c->comp, c->fri_leaves[0], c->n, (uint32_t)c->Bc, log_jt); }
 }
 
 __global__ void __launch_bounds__(HASH_THREADS) fri_leaves_kernel(const fe* __restrict__ e, digest* __restrict__ leaves, size_t R) {
@@ -255,10 +258,10 @@ void k_constraint_level1(dst_ctx* c) {
     uint32_t qn = (uint32_t)(c->Bc / 4);
     uint32_t qt = qn < 32 ? qn : 32u, log_qt = 0;
     while ((1u << log_qt) < qt) log_qt++;
-    uint32_t KT = HASH_THREADS >> log_qt;
+    const uint32_t threads = tile_threads(c->n, log_qt), KT = threads >> log_qt;
     size_t level1 = c->Bc * c->n / 4;
     dim3 g((unsigned)(c->n / KT), (unsigned)(qn >> log_qt));
-    { KScope ks_(c, "constraint_level1_kernel", 96.0 * level1); hipLaunchKernelGGL(constraint_level1_kernel, g, dim3(HASH_THREADS), 0, c->stream, (const fe*)c->cevals, c->cnodes + level1, c->n, (uint32_t)c->Bc, log_qt); }
+    { KScope ks_(c, "constraint_level1_kernel", 96.0 * level1); hipLaunchKernelGGL(constraint_level1_kernel, g, dim3(threads), 0, c->stream, (const fe*)c->cevals, c->cnodes + level1, c->n, (uint32_t)c->Bc, log_qt); }
 }
 // FRI leaves of a coset-major layer e[Bc][nd]: leaf (k, jl), k < nd/4, local index k*Bc + jl
 __global__ void __launch_bounds__(HASH_THREADS) fri_leaves_cm_kernel(const fe* __restrict__ e, digest* __restrict__ leaves, size_t nd, uint32_t Bc) {

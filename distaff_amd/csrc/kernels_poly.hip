@@ -258,7 +258,7 @@ __device__ __forceinline__ fe fold_row(const FoldArgs& a, const fe& y0, const fe
 __global__ void __launch_bounds__(PT) fri_fold0_kernel(const fe* __restrict__ comp, fe* __restrict__ out, size_t n, uint32_t Bc, uint32_t log_b,
                                                       uint32_t log_jt, uint32_t j0, FoldArgs a) {
     __shared__ fe tile[PT];
-    const uint32_t JT = 1u << log_jt, KT = PT >> log_jt;
+    const uint32_t JT = 1u << log_jt, KT = blockDim.x >> log_jt;          // the launcher shrinks the block for tiny traces
     const uint32_t kk = threadIdx.x % KT, jj = threadIdx.x / KT;
     const size_t k = (size_t)blockIdx.x * KT + kk;
     const uint32_t j = blockIdx.y * JT + jj;
@@ -283,9 +283,10 @@ void k_fri_fold(dst_ctx* c, int layer, fe special_x) {
     if (layer == 0) {
         uint32_t jt = c->Bc < 32 ? (uint32_t)c->Bc : 32u, log_jt = 0;
         while ((1u << log_jt) < jt) log_jt++;
-        uint32_t KT = PT >> log_jt;
+        const size_t want = (c->n / 4) << log_jt;
+        const uint32_t threads = (uint32_t)(want < PT ? want : PT), KT = threads >> log_jt;      // never an empty grid (tiny traces, many ranks)
         dim3 g((unsigned)((c->n / 4) / KT), (unsigned)(c->Bc >> log_jt));
-        { KScope ks_(c, "fri_fold0_kernel", 80.0 * (c->n / 4) * c->Bc); hipLaunchKernelGGL(fri_fold0_kernel, g, dim3(PT), 0, c->stream, (const fe*)c->comp, c->fri_e[1], c->n, (uint32_t)c->Bc, c->log_b, log_jt, (uint32_t)c->j0, a); }
+        { KScope ks_(c, "fri_fold0_kernel", 80.0 * (c->n / 4) * c->Bc); hipLaunchKernelGGL(fri_fold0_kernel, g, dim3(threads), 0, c->stream, (const fe*)c->comp, c->fri_e[1], c->n, (uint32_t)c->Bc, c->log_b, log_jt, (uint32_t)c->j0, a); }
     } else {
         { KScope ks_(c, "fri_fold_kernel", 80.0 * R); hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((R + PT - 1) / PT)), dim3(PT), 0, c->stream, (const fe*)c->fri_e[layer], c->fri_e[layer + 1], R,
                            (uint32_t)(2 * layer), a); }

@@ -151,7 +151,7 @@ Pool* pool() {
 void emu_launch(dim3 grid, dim3 block, size_t dynamic_lds, emu_launch_fn fn) {
     if (dynamic_lds > sizeof(ntt_smem)) { fprintf(stderr, "emu: %zu bytes of dynamic LDS\n", dynamic_lds); abort(); }
     const size_t groups = (size_t)grid.x * grid.y * grid.z;
-    if (groups == 0) return;
+    if (groups == 0 || block.x * block.y * block.z == 0) { fprintf(stderr, "emu: launch with an empty grid or block (the device would reject it)\n"); abort(); }
     std::atomic<size_t> next{0};
     auto work = [&]() {
         Worker& w = tl_worker;

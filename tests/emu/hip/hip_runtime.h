@@ -84,7 +84,6 @@ template <class T> static inline hipError_t hipMalloc(T** p, size_t bytes) { ret
 hipError_t hipFree(void* p);
 hipError_t hipHostMalloc(void** p, size_t bytes, unsigned flags = 0);
 template <class T> static inline hipError_t hipHostMalloc(T** p, size_t bytes, unsigned flags = 0) { return hipHostMalloc((void**)p, bytes, flags); }
-hipError_t hipHostFree(void* p);
 hipError_t hipMemGetInfo(size_t* free_b, size_t* total_b);
 hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind kind);
 hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s = nullptr);
@@ -103,6 +102,11 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b);
 template <class F> static inline hipError_t hipFuncSetAttribute(F, hipFuncAttribute, int) { return hipSuccess; }
 template <class F> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, F, int, size_t) { *n = 1; return hipSuccess; }
 #define hipStreamNonBlocking 1u
+#define hipHostMallocDefault 0u
+#define hipEventDisableTiming 2u
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return hipSuccess; }     /* every emulated operation is synchronous */
+hipError_t hipHostFree(void* p);
 
 // ---- launches -----------------------------------------------------------------------------------------------------------------
 struct emu_launch_fn { void (*call)(void*); void* closure; };

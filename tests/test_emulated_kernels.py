@@ -25,8 +25,9 @@ SELECTION = [
     "test_program_shapes_with_stack_depth_5_to_8",
     "test_blowup_16_and_64",
     "test_blowup_128_and_256[128-7]",
-    "test_config2_random_columns_lde_and_merkle",
+    "test_config2_random_columns_lde_and_merkle[12]",
     "test_invalid_trace_reports_air_error",
+    "test_tiny_traces_of_32_and_16_rows",
     "test_wide_rows_two_chunk_leaves",
     "test_sharded_prover_equals_single_gpu[2]",
     "test_sharded_prover_equals_single_gpu[8]",

@@ -147,11 +147,13 @@ def test_blowup_16_and_64(oracle):
     _check_all_phases(oracle, D, oracle.fibonacci_trace(128), log_blowup=6, num_queries=30)
 
 
-def test_config2_random_columns_lde_and_merkle(oracle):
-    """BASELINE config 2 shape at a size the oracle finishes in seconds: 20 uniform columns, LDE + Merkle commit only."""
+@pytest.mark.parametrize("log_n", [12, 16])
+def test_config2_random_columns_lde_and_merkle(oracle, log_n):
+    """BASELINE config 2 (2^16-step trace, LDE + Merkle commit only, bit-exact against the CPU): 20 uniform columns from splitmix64 as
+    SURVEY.md section 8(d) specifies, at the stated size and at 2^12 (the size the CPU run of this test on the emulated build uses)."""
     import distaff_amd as D
     O = oracle
-    n, W = 1 << 12, 20
+    n, W = 1 << log_n, 20
     P = O.P
     def splitmix(seed):
         x = seed
@@ -173,7 +175,7 @@ def test_config2_random_columns_lde_and_merkle(oracle):
     columns = O.to_arr(cols)
     op = O.Prover(columns, 1, 0, [], [], ext=32)
     op.step(1); op.step(2)
-    ctx = D.Context(12, W, 1, 0)
+    ctx = D.Context(log_n, W, 1, 0)
     ctx.upload(columns)
     root = ctx.commit_trace()
     assert root == op.get_bytes("roots")[:32]
@@ -182,6 +184,31 @@ def test_config2_random_columns_lde_and_merkle(oracle):
     for c in (0, 7, 19):
         assert (ctx.read_elements("lde", c) == regs[c]).all()
     ctx.close()
+
+
+def test_tiny_traces_of_32_and_16_rows(oracle):
+    """The reference starts traces at MIN_TRACE_LENGTH = 16 rows (src/lib.rs:82); the shortest programs the VM can run fill 32 rows
+    (root span + closing block).  Those go through every phase; a 16-row table (no program produces one) through extension + commitment."""
+    import distaff_amd as D
+    O = oracle
+    for src, inputs in [("begin noop end", [1]), ("begin add end", [1, 2]), ("begin push.3 mul end", [2])]:
+        t = O.Trace(src, inputs)
+        assert t.columns.shape[1] == 32
+        _check_all_phases(O, D, t, num_outputs=1)
+    rng = np.random.default_rng(16)
+    W, n = 17, 16
+    cols = rng.integers(0, 2**62, size=(W, n, 2), dtype=np.uint64)
+    for log_blowup in (5, 4):
+        op = O.Prover(cols, 0, 0, [], [], ext=1 << log_blowup)
+        op.step(1); op.step(2)
+        ctx = D.Context(4, W, 0, 0, log_blowup=log_blowup)
+        ctx.upload(cols)
+        assert ctx.commit_trace() == op.get_bytes("roots")[:32]
+        assert ctx.read("trace_leaves").tobytes() == op.get_bytes("trace_leaves")
+        regs = op.get("registers")
+        for c in (0, 16):
+            assert (ctx.read_elements("lde", c) == regs[c]).all()
+        ctx.close()
 
 
 def test_invalid_trace_reports_air_error(oracle):
@@ -403,7 +430,7 @@ def test_config3_full_size_proof_is_accepted_and_tamper_evident(oracle):
     right public data, and rejects it for a wrong output, a wrong program hash and a flipped byte, with the reference's error strings."""
     import distaff_amd as D
     O = oracle
-    cols, program_hash, result = D.fibonacci_trace(20)
+    cols, program_hash, result = _fib(20)
     ctx = D.Context(20, 20, 1, 0)
     ctx.upload(cols)
     proof = ctx.prove([1, 0], [result])
@@ -419,6 +446,69 @@ def test_config3_full_size_proof_is_accepted_and_tamper_evident(oracle):
     bad = bytearray(proof); bad[40] ^= 1
     ok, err = O.verify(bytes(bad), program_hash, [1, 0], [result])
     assert not ok
+
+
+_FIB_CACHE = {}
+
+
+def _fib(log_n):
+    """the library's host-side trace generator, once per size and test session (14 s at 2^20, one thread: the sponge is a chain)"""
+    import distaff_amd as D
+    if log_n not in _FIB_CACHE:
+        if log_n >= 22:
+            _FIB_CACHE.clear()                                        # 1.3 GiB at 2^22: keep one
+        _FIB_CACHE[log_n] = D.fibonacci_trace(log_n)
+    return _FIB_CACHE[log_n]
+
+
+def _accepts_and_rejects(O, proof, program_hash, result):
+    ok, err = O.verify(proof, program_hash, [1, 0], [result])
+    assert ok, err
+    ok, err = O.verify(proof, program_hash, [1, 0], [result + 1])
+    assert not ok and "verification of low-degree proof failed" in err
+    bad = bytearray(proof); bad[len(proof) // 2] ^= 1
+    ok, err = O.verify(bytes(bad), program_hash, [1, 0], [result])
+    assert not ok
+
+
+def test_config4_trace_full_size_on_one_gpu(oracle):
+    """BASELINE config 4's trace (2^22 steps, default ProofOptions) on ONE GPU: three-pass transforms, 40 GiB of extension; the
+    oracle's restatement of the reference verifier accepts the proof and rejects a wrong output / a flipped byte."""
+    import distaff_amd as D
+    cols, program_hash, result = _fib(22)
+    ctx = D.Context(22, 20, 1, 0)
+    ctx.upload(cols)
+    proof = ctx.prove([1, 0], [result], cap=1 << 22)
+    ctx.close()
+    _accepts_and_rejects(oracle, proof, program_hash, result)
+
+
+def test_config5_full_size_on_one_gpu(oracle):
+    """BASELINE config 5 (2^24 steps, blowup 16, 100 queries = 120-bit security) on ONE GPU (~190 GiB of the 288): the proof is accepted
+    by the oracle's restatement of the reference verifier and rejected after tampering.  Most of the test's time is the host-side VM
+    that generates the 2^24-step trace."""
+    import distaff_amd as D
+    cols, program_hash, result = D.fibonacci_trace(24)
+    ctx = D.Context(24, 20, 1, 0, log_blowup=4, num_queries=100, grinding=20)
+    ctx.upload(cols)
+    del cols
+    proof = ctx.prove([1, 0], [result], cap=1 << 24)
+    ctx.close()
+    _accepts_and_rejects(oracle, proof, program_hash, result)
+
+
+def test_sharded_world8_at_bench_size_equals_single_context():
+    """Config 3's trace (2^20 steps, default options) through the sharded path with 8 thread-ranks sharing the GPU: every rank must
+    return the single-context proof (which the oracle's verifier accepts in test_config3_full_size_proof_is_accepted_and_tamper_evident)."""
+    import distaff_amd as D
+    from distaff_amd import sharded
+    cols, program_hash, result = _fib(20)
+    ctx = D.Context(20, 20, 1, 0)
+    ctx.upload(cols)
+    expected = ctx.prove([1, 0], [result])
+    ctx.close()
+    proofs = sharded.prove_local(cols, 20, 20, 1, 0, [1, 0], [result], 8)
+    assert all(p == expected for p in proofs)
 
 
 def test_fibonacci_2_16_proof_bytes_equal_oracle(oracle):
