@@ -114,31 +114,47 @@ def main():
             return ctx.prove([1, 0], [result])
         transport = "none"
     else:
-        # ONE proof sharded over the GPUs by cosets of the LDE domain (distaff_amd/sharded.py); RCCL all-gathers between phases
-        from distaff_amd import sharded
-        device_path = os.environ.get("DISTAFF_SHARD_TRANSPORT", "device") == "device"
-        comm = sharded.TorchComm(dist, torch.device("cuda", local_rank), device_path=device_path)
-        if device_path:
-            # self-check of the direct hand-off between the library's buffers and torch tensors; fall back to host staging
-            ok = True
-            try:
-                ctx.shard_commit_trace()
-                host = np.empty(ctx.shard_export_size(0), dtype=np.uint8)
-                ctx.shard_export(0, 0, host.ctypes.data, False)
-                big = torch.zeros(ctx.shard_export_size(0), dtype=torch.uint8, device=comm.device)
-                torch.cuda.synchronize()
-                ctx.shard_export(0, 0, big.data_ptr(), True)
-                ok = bool((big.cpu().numpy() == host).all())
-            except Exception:                                       # noqa: BLE001
-                ok = False
-            flags = comm.all_gather_object(ok)
-            if not all(flags):
-                comm.device_path = False
-        transport = "device" if comm.device_path else "host-staged"
-        prover = sharded.ShardedProver(ctx, comm)
+        # ONE proof sharded over the GPUs by cosets of the LDE domain.  Default: the whole exchange sequence behind the C-ABI
+        # (dst_prove_sharded: RCCL all-to-all / all-gather issued by the library; torch.distributed only carries the 128-byte unique id
+        # and the timing barrier).  DISTAFF_SHARD_ORCH=python keeps the host-orchestrated sequence of distaff_amd/sharded.py
+        # (torch.distributed collectives around dst_shard_*) as a cross-check.
+        if os.environ.get("DISTAFF_SHARD_ORCH", "c") != "python":
+            ids = [D.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(ids, src=0)
+            comm = D.Comm.rccl(ids[0], rank, world, local_rank)
+            transport = "dst_prove_sharded over RCCL"
 
-        def prove():
-            return prover.prove([1, 0], [result])
+            class _Stages:
+                stage_ms = {}
+            prover = _Stages()
+
+            def prove():
+                return ctx.prove_sharded(comm, [1, 0], [result])
+        else:
+            from distaff_amd import sharded
+            device_path = os.environ.get("DISTAFF_SHARD_TRANSPORT", "device") == "device"
+            comm = sharded.TorchComm(dist, torch.device("cuda", local_rank), device_path=device_path)
+            if device_path:
+                # self-check of the direct hand-off between the library's buffers and torch tensors; fall back to host staging
+                ok = True
+                try:
+                    ctx.shard_commit_trace()
+                    host = np.empty(ctx.shard_export_size(0), dtype=np.uint8)
+                    ctx.shard_export(0, 0, host.ctypes.data, False)
+                    big = torch.zeros(ctx.shard_export_size(0), dtype=torch.uint8, device=comm.device)
+                    torch.cuda.synchronize()
+                    ctx.shard_export(0, 0, big.data_ptr(), True)
+                    ok = bool((big.cpu().numpy() == host).all())
+                except Exception:                                       # noqa: BLE001
+                    ok = False
+                flags = comm.all_gather_object(ok)
+                if not all(flags):
+                    comm.device_path = False
+            transport = "torch.distributed, " + ("device" if comm.device_path else "host-staged")
+            prover = sharded.ShardedProver(ctx, comm)
+
+            def prove():
+                return prover.prove([1, 0], [result])
 
     proof = None
     for _ in range(args.warmup):
@@ -286,10 +302,10 @@ def main():
         "config": {"workload": "Fibonacci program (src/examples/fibonacci.rs), 2^%d-step trace, W=20 registers, full stark::prove with %s"
                                "ProofOptions (blowup %d, %d queries, grinding 20, blake3)" % (log_n, "default " if (blowup, args.queries) == (32, 50) else "", blowup, args.queries),
                    "trace_steps": n, "registers": W_FIB, "blowup": blowup, "queries": args.queries, "grinding": 20,
-                   "parallelism": "1 GPU" if world == 1 else "one proof sharded over %d GPUs by LDE cosets; RCCL all-gather of Merkle boundary nodes "
-                                  "and constraint evaluations; shard hand-off: %s" % (world, transport)},
+                   "parallelism": "1 GPU" if world == 1 else "one proof sharded over %d GPUs by LDE cosets; Merkle trees finished per k-range (all-to-all of boundary nodes, "
+                                  "all-gather of subtree roots), all-gather of constraint evaluations and of the first small FRI layer; %s" % (world, transport)},
         "prover_ms": ms_per_step,
-        "phase_ms": None if transport != "none" else {k: round(v / args.steps, 3) for k, v in zip(
+        "phase_ms": None if transport.startswith("torch") else {k: round(v / args.steps, 3) for k, v in zip(
             ["lde", "trace_merkle", "constraint_eval", "combine", "constraint_lde_merkle", "deep_composition", "fri", "pow_queries", "openings"], phase_sum)},
         "proof_bytes": len(proof),
         "shard_stage_ms_rank0": {k: round(v / args.steps, 3) for k, v in stage_sum.items()} or None,

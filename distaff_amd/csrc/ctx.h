@@ -112,6 +112,10 @@ struct dst_ctx {
     // coset-sharded mode (world > 1): replicated upper parts of the trees and the gather landing buffer
     digest *trace_upper = nullptr, *c_upper = nullptr, *fri_upper[DST_MAX_FRI_LAYERS] = {nullptr};
     uint8_t *gather_buf = nullptr; size_t gather_bytes = 0;
+    // dst_prove_sharded: trees whose upper part is partitioned by k-ranges (rank g finishes the subtree over k in [g*K/G, (g+1)*K/G) from
+    // an all-to-all of boundary nodes; `*_upper` then holds the replicated top heap [0, 2G) and this rank's subtree heap behind it)
+    // instead of being rebuilt from an all-gather on every rank (the host-orchestrated dst_shard_import).  Index 0 trace, 1 constraint, 2 + d FRI layer d.
+    bool tree_krange[2 + DST_MAX_FRI_LAYERS] = {false};
     uint64_t *d_u64 = nullptr;                        // small device scalars (pow result, AIR failure flag)
     uint8_t *d_stage = nullptr;                       // staging buffer for gathers
     size_t stage_bytes = 0;
@@ -210,6 +214,7 @@ int k_bench_mad(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms);
 void k_merkle_local_levels(dst_ctx* c, digest* nodes, size_t count, size_t stop_count);
 void k_merkle_levels_to(dst_ctx* c, const digest* leaves, digest* nodes, size_t num_leaves, size_t stop_count);
 void k_upper_tree(dst_ctx* c, const digest* gathered, digest* upper, size_t nb, uint32_t G);
+void k_merkle_upper(dst_ctx* c, digest* nodes, size_t count);       // nodes[1 .. count) from the filled level nodes[count .. 2*count)
 void k_constraint_level1(dst_ctx* c);
 void k_fri_leaves_cm(dst_ctx* c, const fe* e, digest* leaves, size_t nd);
 void k_fri_fold_cm(dst_ctx* c, const fe* e, fe* out, size_t nd, int layer, fe special_x);

@@ -253,6 +253,7 @@ void k_upper_tree(dst_ctx* c, const digest* gathered, digest* upper, size_t nb, 
     { KScope ks_(c, "interleave_boundary_kernel", 64.0 * count); hipLaunchKernelGGL(interleave_boundary_kernel, dim3((unsigned)((count + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream, gathered, upper + count, nb, G); }
     merkle_upper_levels(c, upper, count);
 }
+void k_merkle_upper(dst_ctx* c, digest* nodes, size_t count) { merkle_upper_levels(c, nodes, count); }
 // first node level of the constraint tree only (local), see k_constraint_tree
 void k_constraint_level1(dst_ctx* c) {
     uint32_t qn = (uint32_t)(c->Bc / 4);

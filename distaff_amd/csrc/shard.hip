@@ -4,7 +4,10 @@
 // boundary nodes and that the constraint evaluations are all-gathered before the cross-coset inverse transform.  The
 // collectives themselves are issued by the host (torch.distributed / RCCL in distaff_amd/sharded.py): this file only
 // exports and imports the shards.
+#include <chrono>
+#include <thread>
 #include "ctx.h"
+#include "comm.h"
 #include "host_util.h"
 #include "host_proof.h"
 
@@ -14,7 +17,8 @@ extern "C" void dst_internal_transition_coefficients(const dst_ctx* c, const fe*
 
 enum { SH_TRACE_TREE = 0, SH_CONSTRAINT_TREE = 1, SH_FRI_TREE = 2, SH_CEVAL = 3, SH_FRI_LAST = 4, SH_FRI_SEND_CAP = 5 };
 enum { RD_TRACE_LEAF = 0, RD_TRACE_NODE = 1, RD_TRACE_UPPER = 2, RD_CEVAL = 3, RD_C_NODE = 4, RD_C_UPPER = 5, RD_FRI_E = 6, RD_FRI_LEAF = 7,
-       RD_FRI_NODE = 8, RD_FRI_UPPER = 9, RD_LDE_ROW = 10 };
+       RD_FRI_NODE = 8, RD_FRI_UPPER = 9, RD_LDE_ROW = 10,
+       RD_MID_OFFSET = 32 };            // RD_*_UPPER + RD_MID_OFFSET: the rank's subtree heap of a k-range tree (behind the 2G entries of the top heap)
 
 static size_t fri_nd(const dst_ctx* c, int d) { return c->fri_size[d] / c->B; }     // elements per coset in layer d
 
@@ -52,7 +56,9 @@ static int ensure_shard_buffers(dst_ctx* c) {
     }
     return DST_OK;
 }
+static double wall_ms_shard() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static int copy_in(dst_ctx* c, void* dst, const void* src, size_t bytes, int src_is_device) {
+    if (src_is_device && dst == src) return DST_OK;              // dst_prove_sharded gathers straight into the landing buffer
     if (src_is_device) k_copy(c, dst, src, bytes);
     else HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
     return DST_OK;
@@ -74,6 +80,7 @@ int dst_shard_commit_trace(dst_ctx* c) {
     int r = ensure_shard_buffers(c);
     if (r) return r;
     c->sharded_layout = true;
+    for (bool& b : c->tree_krange) b = false;                  // dst_prove_sharded switches trees to k-ranges as it exchanges them
     k_intt_columns(c, c->trace, c->polys, c->W);
     k_lde_columns(c, c->polys, c->lde, c->W);
     k_trace_leaves(c);
@@ -111,6 +118,7 @@ int dst_shard_eval_constraints(dst_ctx* c, const dst_public* pub, const uint8_t*
 // cosets and the local levels of the constraint tree
 int dst_shard_combine(dst_ctx* c) {
     if (!c) return DST_ERR_ARG;
+    if (!c->committed || c->shard_draws.size() != 344) { c->err = "dst_shard_combine: constraints not evaluated (dst_shard_eval_constraints first)"; return DST_ERR_STATE; }
     HIP_TRY(c, hipSetDevice(c->device));
     const size_t n = c->n, D = 8 * n;
     fe* ip = c->cwork; fe* fp = c->cwork + D; fe* tp = c->cwork + 2 * D; fe* work = c->cwork + 3 * D;
@@ -380,12 +388,25 @@ struct OpenPlan { std::vector<OpenReq> reqs; std::vector<size_t> slot; Writer w;
 
 struct Geometry {                      // distaff_amd/sharded.py TreeGeometry: leaves Bt*k + j', columns j' split over G ranks
     uint64_t L, Bt, G, Bct, K;
-    Geometry(uint64_t leaves, uint64_t bt, uint64_t g) : L(leaves), Bt(bt), G(g), Bct(bt / g), K(leaves / bt) {}
+    bool krange;                       // levels between the rank-local ones and the top log2(G): owned by k-ranges (dst_prove_sharded) instead of replicated
+    Geometry(uint64_t leaves, uint64_t bt, uint64_t g, bool kr = false) : L(leaves), Bt(bt), G(g), Bct(bt / g), K(leaves / bt), krange(kr && g > 1) {}
     void leaf(uint64_t i, int& g, uint64_t& local) const { uint64_t k = i / Bt, j = i % Bt; g = (int)(j / Bct); local = k * Bct + (j - (uint64_t)g * Bct); }
-    void node(uint64_t heap, int& g, uint64_t& idx) const {
+    // zone: 0 rank-local heap, 1 replicated heap (global indices), 2 the owner's subtree heap (k-range mode)
+    void node(uint64_t heap, int& g, uint64_t& idx, int* zone = nullptr) const {
         uint64_t level = 1; while (level * 2 <= heap) level *= 2;              // nodes on this level
         uint64_t t = heap - level, span = L / level;
-        if (span >= Bct) { g = -1; idx = heap; return; }
+        if (zone) *zone = 0;
+        if (span >= Bct) {
+            if (krange && level > G) {                                         // subtree of the rank that owns k in [g*K/G, (g+1)*K/G): level/G nodes of this level each
+                const uint64_t per = level / G;
+                g = (int)(t / per); idx = per + t % per;
+                if (zone) *zone = 2;
+                return;
+            }
+            g = -1; idx = heap;
+            if (zone) *zone = 1;
+            return;
+        }
         uint64_t local_leaf; leaf(t * span, g, local_leaf);
         idx = L / (G * span) + local_leaf / span;                              // nodes of this level held by one rank = L / (G * span), also when L < Bt
     }
@@ -414,8 +435,9 @@ void plan_tree_nodes(const dst_ctx* c, OpenPlan& p, const BatchPlan& bp, const G
                 if (raw_pair_leaves) { plan_element(c, p, RD_CEVAL, 0, 2 * r.index, c->n); plan_element(c, p, RD_CEVAL, 0, 2 * r.index + 1, c->n); }
                 else { geo.leaf(r.index, g, idx); plan_item(p, g, leaf_buf, arg, idx, 32); }
             } else {
-                geo.node(r.index, g, idx);
-                plan_item(p, g, g < 0 ? upper_buf : node_buf, arg, idx, 32);
+                int zone = 0;
+                geo.node(r.index, g, idx, &zone);
+                plan_item(p, g, zone == 0 ? node_buf : zone == 1 ? upper_buf : upper_buf + RD_MID_OFFSET, arg, idx, 32);
             }
         }
     }
@@ -432,7 +454,7 @@ int build_open_plan(dst_ctx* c, const uint64_t* positions_in, uint32_t num_posit
     w.raw(c->trace_root, 32);
     w.u8((uint8_t)c->log_N); w.u8((uint8_t)c->prm.ctx_depth); w.u8((uint8_t)c->prm.loop_depth); w.u8((uint8_t)c->stack_depth); w.u32((uint32_t)c->op_count);
     BatchPlan tp = plan_batch(positions, N);
-    plan_tree_nodes(c, p, tp, Geometry(N, B, G), RD_TRACE_LEAF, RD_TRACE_NODE, RD_TRACE_UPPER, 0, false);
+    plan_tree_nodes(c, p, tp, Geometry(N, B, G, c->sharded_layout && c->tree_krange[0]), RD_TRACE_LEAF, RD_TRACE_NODE, RD_TRACE_UPPER, 0, false);
     w.u64(positions.size());
     for (uint64_t q : positions) { w.u64(W); plan_item(p, (int)((q % B) / c->Bc), RD_LDE_ROW, 0, q, (uint32_t)(W * 16)); }
     w.raw(c->constraint_root, 32);
@@ -441,7 +463,7 @@ int build_open_plan(dst_ctx* c, const uint64_t* positions_in, uint32_t num_posit
         BatchPlan cp = plan_batch(cpos, N / 2);
         w.u64(cp.values.size());
         for (uint64_t u : cp.values) { plan_element(c, p, RD_CEVAL, 0, 2 * u, n); plan_element(c, p, RD_CEVAL, 0, 2 * u + 1, n); }
-        plan_tree_nodes(c, p, cp, Geometry(N / 2, B / 2, G), 0, RD_C_NODE, RD_C_UPPER, 0, true);
+        plan_tree_nodes(c, p, cp, Geometry(N / 2, B / 2, G, c->sharded_layout && c->tree_krange[1]), 0, RD_C_NODE, RD_C_UPPER, 0, true);
         w.u8(cp.depth);
     }
     w.u64(W); w.raw(c->deep_z1.data(), W * 16);
@@ -455,7 +477,7 @@ int build_open_plan(dst_ctx* c, const uint64_t* positions_in, uint32_t num_posit
         w.raw(c->fri_roots[d].data(), 32);
         w.u64(pos.size());
         for (uint64_t r : pos) for (uint64_t s4 = 0; s4 < 4; s4++) plan_element(c, p, RD_FRI_E, (uint32_t)d, r + s4 * R, nd);
-        plan_tree_nodes(c, p, fp, Geometry(R, B, fri_layer_replicated(c, d) ? 1 : G), RD_FRI_LEAF, RD_FRI_NODE, RD_FRI_UPPER, (uint32_t)d, false);
+        plan_tree_nodes(c, p, fp, Geometry(R, B, fri_layer_replicated(c, d) ? 1 : G, c->sharded_layout && c->tree_krange[2 + d]), RD_FRI_LEAF, RD_FRI_NODE, RD_FRI_UPPER, (uint32_t)d, false);
         w.u8(fp.depth);
     }
     w.raw(c->fri_roots[L - 1].data(), 32);
@@ -479,6 +501,10 @@ const void* read_source(dst_ctx* c, uint32_t buffer, uint32_t arg) {
         case RD_FRI_LEAF: return (int)arg < c->num_fri_layers ? c->fri_leaves[arg] : nullptr;
         case RD_FRI_NODE: return (int)arg < c->num_fri_layers ? c->fri_nodes[arg] : nullptr;
         case RD_FRI_UPPER: return (int)arg < c->num_fri_layers ? (c->sharded_layout && !fri_layer_replicated(c, (int)arg) ? c->fri_upper[arg] : c->fri_nodes[arg]) : nullptr;
+        // subtree heaps of k-range trees sit behind the 2G entries of the replicated top heap
+        case RD_TRACE_UPPER + RD_MID_OFFSET: return c->trace_upper + 2 * c->prm.world;
+        case RD_C_UPPER + RD_MID_OFFSET: return c->c_upper + 2 * c->prm.world;
+        case RD_FRI_UPPER + RD_MID_OFFSET: return (int)arg < c->num_fri_layers ? c->fri_upper[arg] + 2 * c->prm.world : nullptr;
     }
     return nullptr;
 }
@@ -605,6 +631,212 @@ int dst_shard_info(dst_ctx* c, uint64_t* op_count, uint32_t* num_fri_layers, uin
     if (op_count) *op_count = c->op_count;
     if (num_fri_layers) *num_fri_layers = (uint32_t)c->num_fri_layers;
     if (stack_depth) *stack_depth = (uint32_t)c->stack_depth;
+    return DST_OK;
+}
+
+
+// ---- the whole sharded proof behind the C-ABI ------------------------------------------------------------------------------------------
+// dst_prove_sharded = stark::prove (prover.rs:17-168) across the ranks of a communicator: the same phases as the host-orchestrated
+// sequence above, with the collectives issued here (RCCL or the in-process transport, comm.hip).  Exchange points:
+//   * every Merkle tree: after the rank-local levels (one boundary node per k and rank) an ALL-TO-ALL moves the boundary nodes so that
+//     rank g holds those of k in [g*K/G, (g+1)*K/G) of every rank, builds the subtree above them (K - 1 hashes), the G subtree roots
+//     are all-gathered (G x 32 bytes) and only the top log2(G) levels are repeated on every rank.  Per rank and tree: 32*K*(G-1)/G bytes
+//     sent, K + G - 2 hashes above the local levels (the host-orchestrated path all-gathers 32*K*(G-1) bytes and repeats K*G - 1 hashes);
+//   * the transition-constraint evaluations (8n/G elements per rank): all-gather before the cross-coset inverse transform;
+//   * the first small FRI layer: all-gather of its evaluations, the commit phase then finishes replicated;
+//   * openings: every rank gathers what it owns; the blobs are all-gathered and every rank fills the same proof template.
+// A status word travels with every phase: when any rank fails, all ranks return an error instead of waiting in the next collective.
+namespace {
+struct Agree {
+    dst_ctx* c; dst_comm* comm;
+    // every rank contributes its status; returns the first failing rank's code on ALL ranks
+    int operator()(int rc, const char* phase) {
+        std::vector<int32_t> all(comm->world, 0);
+        int32_t mine = rc;
+        int r = comm->all_gather_host(&mine, all.data(), sizeof(int32_t));
+        if (r) { c->err = std::string(phase) + ": " + comm->err; return r; }
+        for (uint32_t g = 0; g < comm->world; g++)
+            if (all[g] != DST_OK) {
+                if (rc == DST_OK) c->err = std::string(phase) + ": rank " + std::to_string(g) + " reported error " + std::to_string(all[g]);
+                return all[g];
+            }
+        return DST_OK;
+    }
+};
+
+// this rank's boundary nodes of a tree (device pointer, K of them): the level at which nodes stop being rank-local
+int shard_boundary(dst_ctx* c, uint32_t what, uint32_t arg, const digest** src, size_t* K) {
+    switch (what) {
+        case SH_TRACE_TREE: *src = c->trace_nodes + c->n; *K = c->n; return DST_OK;
+        case SH_CONSTRAINT_TREE:
+            *K = c->n;
+            if (c->Bc == 2) {                                    // two cosets per rank: the raw leaf pairs are the boundary (see dst_shard_export)
+                k_coset_to_natural_len(c, c->cevals, 2, c->n, (fe*)c->cnodes);
+                *src = c->cnodes;
+            } else *src = c->cnodes + c->n;
+            return DST_OK;
+        case SH_FRI_TREE: *K = fri_nd(c, (int)arg) / 4; *src = c->fri_nodes[arg] + *K; return DST_OK;
+    }
+    c->err = "shard_boundary: bad item"; return DST_ERR_ARG;
+}
+
+// finishes a tree from the ranks' boundary nodes and returns its root (replicated)
+int tree_exchange(dst_ctx* c, dst_comm* comm, uint32_t what, uint32_t arg, uint8_t root[32]) {
+    const size_t G = comm->world;
+    const digest* src = nullptr; size_t K = 0;
+    int r = shard_boundary(c, what, arg, &src, &K);
+    if (r) return r;
+    digest* upper = what == SH_TRACE_TREE ? c->trace_upper : what == SH_CONSTRAINT_TREE ? c->c_upper : c->fri_upper[arg];
+    const int slot = what == SH_TRACE_TREE ? 0 : what == SH_CONSTRAINT_TREE ? 1 : 2 + (int)arg;
+    const bool krange = G > 1 && K >= G && K % G == 0 && !getenv("DISTAFF_SHARD_TREE_GATHER");
+    c->tree_krange[slot] = krange;
+    if (getenv("DISTAFF_SHARD_DEBUG") && comm->rank == 0) fprintf(stderr, "[distaff] tree %u/%u: %zu boundary nodes per rank, %s\n", what, arg, K, krange ? "k-range exchange (all-to-all + root all-gather)" : "all-gather of boundary nodes");
+    if (krange) {
+        const size_t chunk = K / G;                              // boundary nodes per (sender, owner) pair
+        if (K * 32 > c->gather_bytes) { c->err = "tree_exchange: gather buffer too small"; return DST_ERR_ARG; }
+        if ((r = comm->all_to_all(src, c->gather_buf, chunk * 32, c->stream))) { c->err = "tree_exchange: " + comm->err; return r; }
+        digest* mid = upper + 2 * G;                             // this rank's subtree heap: mid[1] = its root, mid[K + kl*G + r] = boundary node of rank r at k = g*K/G + kl
+        k_upper_tree(c, (const digest*)c->gather_buf, mid, chunk, (uint32_t)G);
+        if ((r = comm->all_gather(mid + 1, upper + G, 32, c->stream))) { c->err = "tree_exchange: " + comm->err; return r; }
+        k_merkle_upper(c, upper, G);                             // the top log2(G) levels, on every rank
+    } else {
+        if (K * 32 * G > c->gather_bytes) { c->err = "tree_exchange: gather buffer too small"; return DST_ERR_ARG; }
+        if ((r = comm->all_gather(src, c->gather_buf, K * 32, c->stream))) { c->err = "tree_exchange: " + comm->err; return r; }
+        k_upper_tree(c, (const digest*)c->gather_buf, upper, K, (uint32_t)G);
+    }
+    HIP_TRY(c, hipMemcpyAsync(root, upper + 1, 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    if (what == SH_TRACE_TREE) memcpy(c->trace_root, root, 32);
+    else if (what == SH_CONSTRAINT_TREE) memcpy(c->constraint_root, root, 32);
+    else { if (c->fri_roots.size() <= arg) c->fri_roots.resize(arg + 1); c->fri_roots[arg].assign(root, root + 32); }
+    return DST_OK;
+}
+}  // namespace
+
+int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t* proof_out, size_t cap, size_t* proof_len) {
+    if (!c || !comm || !pub || !proof_len) return DST_ERR_ARG;
+    if (comm->world != c->prm.world || comm->rank != c->prm.rank) { c->err = "dst_prove_sharded: the communicator's rank / world differ from the context's"; return DST_ERR_ARG; }
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t G = comm->world;
+    Agree agree{c, comm};
+    int rc;
+    double t0 = wall_ms_shard();
+    auto mark = [&](int i) { const double t = wall_ms_shard(); c->phase_ms[i] = t - t0; t0 = t; };
+    // steps 1-2
+    if ((rc = agree(dst_shard_commit_trace(c), "extension"))) return rc;
+    mark(0);
+    uint8_t trace_root[32], constraint_root[32];
+    if ((rc = agree(tree_exchange(c, comm, SH_TRACE_TREE, 0, trace_root), "trace tree"))) return rc;
+    mark(1);
+    // step 3
+    std::vector<fe> coef(344);
+    prng_vector(trace_root, 344, coef.data());
+    int64_t bad = -1;
+    rc = dst_shard_eval_constraints(c, pub, (const uint8_t*)coef.data(), &bad);
+    {
+        std::vector<int64_t> bads(G, -1);
+        int r2 = comm->all_gather_host(&bad, bads.data(), sizeof(int64_t));
+        if (r2) { c->err = "constraint evaluation: " + comm->err; return r2; }
+        int64_t first = -1;
+        for (int64_t b : bads) if (b >= 0 && (first < 0 || b < first)) first = b;
+        if (first >= 0) { c->err = "transition constraints were not satisfied at step " + std::to_string(first); return DST_ERR_AIR; }
+    }
+    if ((rc = agree(rc == DST_ERR_AIR ? DST_OK : rc, "constraint evaluation"))) return rc;
+    mark(2);
+    // steps 4-5: the transition evaluations of all ranks, then combination (replicated) and the constraint tree
+    {
+        size_t bytes = 0;
+        if ((rc = dst_shard_export_size(c, SH_CEVAL, 0, &bytes))) return rc;
+        const void* send = dst_internal_boundary_by_evaluation() ? (const void*)c->ceval : (const void*)(c->ceval + 2 * (c->Bc / (c->B / 8)) * c->n);
+        if (bytes * G > c->gather_bytes) { c->err = "dst_prove_sharded: gather buffer too small for the constraint evaluations"; return DST_ERR_ARG; }
+        int r2 = comm->all_gather(send, c->gather_buf, bytes, c->stream);        // the import below rewrites `ceval` only after the exchange has completed
+        if (r2) c->err = "constraint evaluations: " + comm->err;
+        if ((rc = agree(r2 ? r2 : dst_shard_import(c, SH_CEVAL, 0, c->gather_buf, 1, nullptr), "constraint evaluations"))) return rc;
+    }
+    if ((rc = agree(dst_shard_combine(c), "combination"))) return rc;
+    mark(3);
+    if ((rc = agree(tree_exchange(c, comm, SH_CONSTRAINT_TREE, 0, constraint_root), "constraint tree"))) return rc;
+    mark(4);
+    // step 6
+    std::vector<fe> draws(516);
+    prng_vector(constraint_root, 516, draws.data());
+    std::vector<uint8_t> z1(c->W * 16), z2(c->W * 16);
+    if ((rc = agree(dst_compose(c, (const uint8_t*)draws.data(), z1.data(), z2.data()), "composition"))) return rc;
+    mark(5);
+    // step 7: sharded layers (leaves + local levels | tree exchange | draw + fold), then the replicated tail from one all-gather of evaluations
+    for (;;) {
+        if (c->fri_committed == c->fri_rep_from) {
+            const int d = c->fri_rep_from;
+            const size_t bytes = c->Bc * fri_nd(c, d) * 16;
+            if (bytes * G > c->gather_bytes) { c->err = "dst_prove_sharded: gather buffer too small for the FRI layer"; return DST_ERR_ARG; }
+            // this rank's cosets of the layer (contiguous, coset-major) -> all cosets in the gather buffer -> natural order, then the rest
+            // of the commit phase on every rank (the natural-order layer overwrites fri_e[d] only after the exchange has completed)
+            uint8_t root[32];
+            int r2 = comm->all_gather(c->fri_e[d], c->gather_buf, bytes, c->stream);
+            if (r2) c->err = "FRI tail: " + comm->err;
+            c->fri_tail_pending = true;
+            if ((rc = agree(r2 ? r2 : fri_replicated_tail(c, c->gather_buf, 1, root), "FRI tail"))) return rc;
+            break;
+        }
+        int more = 0;
+        if ((rc = agree(dst_shard_fri_layer(c, &more), "FRI layer"))) return rc;
+        const uint32_t d = (uint32_t)c->fri_committed - 1;
+        uint8_t root[32];
+        if ((rc = agree(tree_exchange(c, comm, SH_FRI_TREE, d, root), "FRI tree"))) return rc;
+        fe x;
+        prng_vector(root, 1, &x);                                 // fri/prover.rs:40 field::prng(root)
+        if ((rc = agree(dst_shard_fri_fold(c, (const uint8_t*)&x), "FRI fold"))) return rc;
+    }
+    mark(6);
+    // step 8 (replicated: every rank grinds the same seed and finds the same first nonce)
+    std::vector<uint8_t> roots;
+    for (int d = 0; d < c->num_fri_layers; d++) roots.insert(roots.end(), c->fri_roots[d].begin(), c->fri_roots[d].end());
+    uint8_t seed0[32], seed1[32];
+    if (!blake3_short(roots.data(), roots.size(), seed0)) { c->err = "too many FRI roots"; return DST_ERR_ARG; }
+    uint64_t nonce = 0;
+    if ((rc = agree(dst_pow_grind(c, seed0, c->prm.grinding_factor, seed1, &nonce), "proof of work"))) return rc;
+    std::vector<uint64_t> positions;
+    if (query_positions(seed1, c->N, (uint32_t)c->B, c->prm.num_queries, positions)) { c->err = "could not generate enough query positions"; return DST_ERR_ARG; }
+    mark(7);
+    // step 9
+    std::vector<uint64_t> lens(G, 0);
+    size_t mine = 0;
+    if ((rc = agree(dst_shard_open(c, positions.data(), (uint32_t)positions.size(), nullptr, 0, &mine, lens.data()), "openings"))) return rc;
+    size_t width = 1;
+    for (uint64_t l : lens) if (l > width) width = (size_t)l;
+    std::vector<uint8_t> blob(width, 0), all(width * G);
+    rc = dst_shard_open(c, positions.data(), (uint32_t)positions.size(), blob.data(), width, &mine, nullptr);
+    {
+        int r2 = comm->all_gather_host(blob.data(), all.data(), width);
+        if (r2) { c->err = "openings: " + comm->err; return r2; }
+    }
+    if ((rc = agree(rc, "openings"))) return rc;
+    std::vector<uint8_t> packed;
+    for (size_t g = 0; g < G; g++) packed.insert(packed.end(), all.begin() + g * width, all.begin() + g * width + lens[g]);
+    rc = dst_shard_assemble(c, positions.data(), (uint32_t)positions.size(), nonce, packed.data(), lens.data(), proof_out, cap, proof_len);
+    mark(8);
+    return agree(rc, "proof assembly");
+}
+
+// One call for a single-process host that drives all GPUs of the node itself: `world` contexts (rank r of world, one per device, each
+// with the trace uploaded), one thread per context, in-process transport.  Every context's proof is identical; the first is returned.
+int dst_prove_sharded_local(dst_ctx** ctxs, uint32_t world, const dst_public* pub, uint8_t* proof_out, size_t cap, size_t* proof_len) {
+    if (!ctxs || !pub || !proof_len || world == 0 || world > 8) return DST_ERR_ARG;
+    std::vector<dst_comm*> comms(world, nullptr);
+    int rc = dst_comm_init_local(world, comms.data());
+    if (rc) return rc;
+    std::vector<int> codes(world, DST_OK);
+    std::vector<std::vector<uint8_t>> proofs(world, std::vector<uint8_t>(cap));
+    std::vector<size_t> lens(world, 0);
+    std::vector<std::thread> threads;
+    for (uint32_t r = 0; r < world; r++)
+        threads.emplace_back([&, r] { codes[r] = dst_prove_sharded(ctxs[r], comms[r], pub, proofs[r].data(), cap, &lens[r]); });
+    for (auto& t : threads) t.join();
+    for (dst_comm* cm : comms) dst_comm_destroy(cm);
+    for (uint32_t r = 0; r < world; r++) if (codes[r]) return codes[r];
+    *proof_len = lens[0];
+    if (proof_out) memcpy(proof_out, proofs[0].data(), lens[0]);
     return DST_OK;
 }
 

@@ -23,7 +23,8 @@ EXPORTS = ["dst_ctx_create", "dst_ctx_destroy", "dst_last_error", "dst_phase_ms"
            "dst_build_proof", "dst_prove", "dst_prng_vector", "dst_query_positions", "dst_blake3", "dst_fibonacci_trace",
            "dst_read_buffer", "dst_bench_mulmod", "dst_bench_mad", "dst_trace_upload_async", "dst_pinned_alloc", "dst_pinned_free", "dst_set_profiling", "dst_kernel_stats", "dst_field_op",
            "dst_shard_commit_trace", "dst_shard_eval_constraints", "dst_shard_combine", "dst_shard_fri_layer", "dst_shard_fri_fold",
-           "dst_shard_export_size", "dst_shard_export", "dst_shard_import", "dst_shard_read", "dst_shard_fri_begin", "dst_shard_fri_end", "dst_shard_fri_roots", "dst_shard_open", "dst_shard_assemble", "dst_shard_info"]
+           "dst_shard_export_size", "dst_shard_export", "dst_shard_import", "dst_shard_read", "dst_shard_fri_begin", "dst_shard_fri_end", "dst_shard_fri_roots", "dst_shard_open", "dst_shard_assemble", "dst_shard_info",
+           "dst_comm_unique_id", "dst_comm_init", "dst_comm_init_local", "dst_comm_init_callbacks", "dst_comm_destroy", "dst_comm_last_error", "dst_prove_sharded", "dst_prove_sharded_local"]
 
 
 class DistaffError(RuntimeError):
@@ -144,6 +145,84 @@ def fibonacci_trace(log_n):
     return cols, ph.raw, int.from_bytes(res.raw, "little")
 
 
+class Comm:
+    """One rank's communicator handle (``dst_comm``) for ``Context.prove_sharded``: RCCL over xGMI, the unique id created by
+    ``Comm.unique_id()`` on rank 0 and handed to the other ranks by the host's own channel."""
+
+    def __init__(self, handle):
+        self.lib, self._h = load(), handle
+
+    @staticmethod
+    def unique_id():
+        lib = load()
+        buf = ctypes.create_string_buffer(128)
+        if lib.dst_comm_unique_id(buf) != DST_OK:
+            lib.dst_comm_last_error.restype = ctypes.c_char_p
+            raise DistaffError(DST_ERR_HIP, lib.dst_comm_last_error(None).decode())
+        return buf.raw
+
+    @classmethod
+    def rccl(cls, unique_id, rank, world, device):
+        lib = load()
+        h = ctypes.c_void_p()
+        if lib.dst_comm_init(bytes(unique_id), ctypes.c_uint32(rank), ctypes.c_uint32(world), ctypes.c_int(device), ctypes.byref(h)) != DST_OK:
+            lib.dst_comm_last_error.restype = ctypes.c_char_p
+            raise DistaffError(DST_ERR_HIP, lib.dst_comm_last_error(None).decode())
+        return cls(h)
+
+    @classmethod
+    def local(cls, world):
+        """`world` handles whose ranks are threads of this process"""
+        lib = load()
+        arr = (ctypes.c_void_p * world)()
+        if lib.dst_comm_init_local(ctypes.c_uint32(world), arr) != DST_OK:
+            raise DistaffError(DST_ERR_ARG, "dst_comm_init_local failed")
+        return [cls(ctypes.c_void_p(arr[r])) for r in range(world)]
+
+    @classmethod
+    def callbacks(cls, rank, world, fn):
+        """The host's own transport: fn(kind, send_address, recv_address, bytes) -> 0 performs kind 0 = all-gather, 1 = all-to-all (device
+        buffers), 2 = all-gather of host values."""
+        lib = load()
+        proto = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+
+        def tramp(user, kind, send, recv, nbytes):
+            try:
+                return int(fn(kind, send, recv, nbytes))
+            except Exception:                                         # noqa: BLE001 -- reported as a failed collective
+                import traceback
+                traceback.print_exc()
+                return 1
+        cb = proto(tramp)
+        h = ctypes.c_void_p()
+        if lib.dst_comm_init_callbacks(ctypes.c_uint32(rank), ctypes.c_uint32(world), cb, None, ctypes.byref(h)) != DST_OK:
+            raise DistaffError(DST_ERR_ARG, "dst_comm_init_callbacks failed")
+        c = cls(h)
+        c._keep = cb                                                  # the trampoline must outlive the handle
+        return c
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self.lib.dst_comm_destroy(self._h)
+            self._h = None
+
+
+def prove_sharded_local(contexts, inputs, outputs, cap=1 << 22):
+    """dst_prove_sharded_local: one proof over `len(contexts)` contexts (rank r of world, trace uploaded on each), one thread per
+    context inside the library, in-process transport."""
+    lib = load()
+    world = len(contexts)
+    arr = (ctypes.c_void_p * world)(*[c._h.value for c in contexts])
+    pub = make_public(inputs, outputs)
+    buf = ctypes.create_string_buffer(cap)
+    ln = ctypes.c_size_t(0)
+    r = lib.dst_prove_sharded_local(arr, ctypes.c_uint32(world), ctypes.byref(pub), buf, ctypes.c_size_t(cap), ctypes.byref(ln))
+    if r != DST_OK:
+        msgs = [lib.dst_last_error(c._h).decode() for c in contexts]
+        raise DistaffError(r, "; ".join("rank %d: %s" % (i, m) for i, m in enumerate(msgs) if m))
+    return buf.raw[:ln.value]
+
+
 class Context:
     """One proving job on one GPU (``dst_ctx``): owns the device buffers; phases mirror stark::prove (prover.rs:17-168)."""
 
@@ -193,6 +272,14 @@ class Context:
     def upload_async(self, table):
         """dst_trace_upload_async: returns at once, the next commit_trace() / prove() consumes the registers as they arrive"""
         self._check(self.lib.dst_trace_upload_async(self._h, table))
+
+    def prove_sharded(self, comm, inputs, outputs, cap=1 << 22):
+        """dst_prove_sharded: this rank's part of one proof over the communicator's ranks (every rank calls it, every rank gets the proof)"""
+        pub = make_public(inputs, outputs)
+        buf = ctypes.create_string_buffer(cap)
+        ln = ctypes.c_size_t(0)
+        self._check(self.lib.dst_prove_sharded(self._h, comm._h, ctypes.byref(pub), buf, ctypes.c_size_t(cap), ctypes.byref(ln)))
+        return buf.raw[:ln.value]
 
     def commit_trace(self):
         root = ctypes.create_string_buffer(32)

@@ -172,6 +172,33 @@ int dst_field_op(dst_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8
 int dst_set_profiling(dst_ctx* ctx, int level);
 int dst_kernel_stats(dst_ctx* ctx, char* json_out, size_t cap, int reset);
 
+/* ---- one proof over several GPUs, collectives behind the C-ABI -------------------------------------------------------------------
+ * The reference has no multi-device path (src/math/polynom.rs:36-37); the partitioning follows SURVEY.md 8(e): rank g of `world` owns
+ * the cosets [g*B/world, (g+1)*B/world) of every extension, Merkle trees are finished from an all-to-all of boundary nodes (rank g
+ * builds the subtree over the trace indices k in [g*n/world, (g+1)*n/world)), an all-gather of the `world` subtree roots and the top
+ * log2(world) levels; constraint evaluations and the first small FRI layer are all-gathered.  No all-reduce anywhere.
+ *
+ * One communicator handle per rank.  RCCL transport (one process per GPU, xGMI): the rank-0 host calls dst_comm_unique_id and hands
+ * the 128 bytes to the other ranks through its own channel; every rank then calls dst_comm_init with the device it created its
+ * context on.  librccl.so is bound at run time, a single-GPU host never needs it.  In-process transport (dst_comm_init_local fills
+ * `world` handles): the ranks are threads of one process, e.g. a host that drives all GPUs of a node itself, or tests.
+ * dst_prove_sharded is stark::prove on context `ctx` (created with rank / world in dst_params, trace uploaded on EVERY rank): all ranks
+ * call it, all ranks receive the same proof bytes; when any rank fails every rank returns an error.  dst_prove_sharded_local is the
+ * one-call form for a single-process host: `world` contexts, one thread each. */
+typedef struct dst_comm dst_comm;
+int dst_comm_unique_id(uint8_t id[128]);
+int dst_comm_init(const uint8_t id[128], uint32_t rank, uint32_t world, int device, dst_comm** out);
+int dst_comm_init_local(uint32_t world, dst_comm** out /* [world] */);
+/* the host's own transport (MPI, its process launcher's channel, ...): `fn` is called for every collective with kind 0 = all-gather of
+ * `bytes` per rank, 1 = all-to-all with chunks of `bytes` (both on DEVICE buffers, complete when fn returns), 2 = all-gather of host values;
+ * it returns 0 on success */
+typedef int (*dst_comm_fn)(void* user, int kind, const void* send, void* recv, size_t bytes);
+int dst_comm_init_callbacks(uint32_t rank, uint32_t world, dst_comm_fn fn, void* user, dst_comm** out);
+void dst_comm_destroy(dst_comm* comm);
+const char* dst_comm_last_error(const dst_comm* comm);   /* comm may be NULL: the creation-time error */
+int dst_prove_sharded(dst_ctx* ctx, dst_comm* comm, const dst_public* pub, uint8_t* proof, size_t cap, size_t* len);
+int dst_prove_sharded_local(dst_ctx** ctxs, uint32_t world, const dst_public* pub, uint8_t* proof, size_t cap, size_t* len);
+
 #ifdef __cplusplus
 }
 #endif

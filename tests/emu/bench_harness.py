@@ -38,7 +38,36 @@ dist.init_process_group = _init_gloo
 import distaff_amd as D
 from distaff_amd import sharded
 
-D.Context.bench_mulmod = lambda self, lanes, iters: 1.0          # the ALU calibration kernel would take minutes on the host
+D.Context.bench_mulmod = lambda self, lanes, iters: 1.0          # the ALU calibration kernels would take minutes on the host
+D.Context.bench_mad = lambda self, lanes, iters: 1.0
+
+
+def _gloo_comm(unique_id, rank, world, device):
+    """stands in for the RCCL communicator of dst_prove_sharded: the library's collectives through the callback transport, carried by
+    gloo on the host pointers of the emulated build"""
+    import ctypes
+    import numpy as np
+
+    def view(addr, nbytes):
+        return np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(addr))
+
+    def fn(kind, send, recv, nbytes):
+        if kind == 1:                                                # all-to-all: gloo has none on CPU tensors, gather and slice
+            mine = torch.from_numpy(view(send, nbytes * world).copy())
+            out = [torch.empty(nbytes * world, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(out, mine)
+            view(recv, nbytes * world)[:] = np.concatenate([o.numpy()[rank * nbytes:(rank + 1) * nbytes] for o in out])
+        else:
+            mine = torch.from_numpy(view(send, nbytes).copy())
+            out = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(out, mine)
+            view(recv, nbytes * world)[:] = np.concatenate([o.numpy() for o in out])
+        return 0
+    return D.Comm.callbacks(rank, world, fn)
+
+
+D.Comm.unique_id = staticmethod(lambda: bytes(128))
+D.Comm.rccl = staticmethod(_gloo_comm)
 _comm_init = sharded.TorchComm.__init__
 
 

@@ -33,6 +33,10 @@ SELECTION = [
     "test_sharded_prover_equals_single_gpu[8]",
     "test_sharded_prover_reports_invalid_trace",
     "test_sharded_fri_protocol_state_errors",
+    "test_prove_sharded_behind_the_c_abi[2-8-None-False]",
+    "test_prove_sharded_behind_the_c_abi[8-8-9-False]",
+    "test_prove_sharded_behind_the_c_abi[4-10-9-True]",
+    "test_prove_sharded_reports_an_invalid_trace_on_every_rank",
     "test_deep_stacks_and_nested_blocks[]",
     "test_deep_stacks_and_nested_blocks[generic]",
     "test_general_constraint_instances_on_the_fibonacci_trace[small]",
@@ -120,15 +124,17 @@ def test_tensor_hand_off_path_over_gloo(emulated_library, tmp_path, world, repli
     assert all("ok" in o for o in outs)
 
 
-@pytest.mark.parametrize("ranks", [1, 2])
-def test_bench_control_flow_on_cpu_stand_ins(emulated_library, ranks):
+@pytest.mark.parametrize("ranks,orch", [(1, "c"), (2, "c"), (2, "python")])
+def test_bench_control_flow_on_cpu_stand_ins(emulated_library, ranks, orch):
     """bench.py's own main() launched exactly as the driver launches it for N > 1 (`python -m torch.distributed.run ...`), with gloo,
     CPU tensors and the emulated build standing in for RCCL, device tensors and the GPU (tests/emu/bench_harness.py): one JSON line
-    from rank 0 with the contract's fields, the sharded prover with the tensor hand-off for N = 2.  The numbers mean nothing here."""
+    from rank 0 with the contract's fields.  For N = 2 both orchestrations: dst_prove_sharded with its collectives carried by gloo
+    through the callback transport (two real processes), and the host-orchestrated sequence of distaff_amd/sharded.py with the
+    tensor hand-off.  The numbers mean nothing here."""
     import json
     import socket
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
-    env = dict(os.environ, DISTAFF_HIP_LIB=emulated_library, DISTAFF_HIP_RUNTIME="none", DISTAFF_EMU_THREADS="2")
+    env = dict(os.environ, DISTAFF_HIP_LIB=emulated_library, DISTAFF_HIP_RUNTIME="none", DISTAFF_EMU_THREADS="2", DISTAFF_SHARD_ORCH=orch)
     harness = os.path.join(EMU_DIR, "bench_harness.py")
     args = ["--gpus", str(ranks), "--steps", "1", "--warmup", "1", "--log-n", "8", "--cpu-log-n", "7"]
     if ranks == 1:
@@ -146,8 +152,13 @@ def test_bench_control_flow_on_cpu_stand_ins(emulated_library, ranks):
     assert out["n_gpus"] == ranks and out["steps"] == 1 and out["vs_baseline"] is None and "workload" in out["config"]
     assert out["scaling"] == ("weak" if ranks == 1 else "strong")
     assert ("cpu_baseline" in out) == (ranks == 1)
-    if ranks > 1:
-        assert "hand-off: device" in out["config"]["parallelism"] and out["shard_stage_ms_rank0"]
+    assert out["proof_verified"]
+    if ranks > 1 and orch == "python":
+        assert "torch.distributed, device" in out["config"]["parallelism"] and out["shard_stage_ms_rank0"]
+    if ranks > 1 and orch == "c":
+        assert "dst_prove_sharded" in out["config"]["parallelism"] and out["phase_ms"]
+    if ranks == 1:
+        assert out["prover_ms_incl_upload"] and out["phase_hbm"] and "frac" in out["alu_roofline"]
 
 
 THREE_PASS_WORKER = r'''

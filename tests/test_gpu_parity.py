@@ -539,6 +539,71 @@ def test_sharded_world8_at_2_16_equals_single_context():
     assert all(p == expected for p in proofs)
 
 
+@pytest.mark.parametrize("world,log_n,replicate_log,gather", [(2, 8, None, False), (4, 8, 9, False), (8, 8, 9, False), (8, 10, 9, False), (4, 10, 9, True), (8, 7, None, False)])
+def test_prove_sharded_behind_the_c_abi(oracle, monkeypatch, world, log_n, replicate_log, gather):
+    """dst_prove_sharded_local: the whole sharded proof inside the library (collectives included, in-process transport, one thread per
+    rank): k-range Merkle exchange (all-to-all of boundary nodes, subtree per rank, all-gather of the subtree roots), all-gathers of the
+    constraint evaluations and of the first small FRI layer, openings from three kinds of owners.  Every variant must return the
+    oracle's proof bytes; `gather` forces the all-gather form of the tree exchange instead."""
+    import distaff_amd as D
+    O = oracle
+    if replicate_log is None:
+        monkeypatch.delenv("DISTAFF_FRI_REPLICATE_LOG", raising=False)
+    else:
+        monkeypatch.setenv("DISTAFF_FRI_REPLICATE_LOG", str(replicate_log))
+    if gather:
+        monkeypatch.setenv("DISTAFF_SHARD_TREE_GATHER", "1")
+    else:
+        monkeypatch.delenv("DISTAFF_SHARD_TREE_GATHER", raising=False)
+    t = O.fibonacci_trace(1 << log_n)
+    op = O.Prover.from_trace(t, 1, grinding=8)
+    expected = op.prove()
+    ctxs = []
+    for r in range(world):
+        ctx = D.Context(log_n, t.width, t.ctx_depth, t.loop_depth, rank=r, world=world, grinding=8)
+        ctx.upload(t.columns)
+        ctxs.append(ctx)
+    for _ in range(2):                                                # twice: the buffers of the first proof are reused
+        assert D.prove_sharded_local(ctxs, t.public_inputs, op.outputs) == expected
+    for ctx in ctxs:
+        ctx.close()
+
+
+def test_prove_sharded_over_rccl_with_one_rank(oracle):
+    """The RCCL transport of dst_prove_sharded (librccl.so bound at run time: ncclCommInitRank, all-gathers of host values and of the
+    constraint evaluations / FRI layer, the all-to-all as grouped send / receive) with the one rank a single-GPU box offers; more
+    ranks run the same calls (the in-process transport covers the partitioning, the driver's 8-GPU run the links)."""
+    import distaff_amd as D
+    O = oracle
+    t = O.fibonacci_trace(1 << 10)
+    op = O.Prover.from_trace(t, 1, grinding=8)
+    comm = D.Comm.rccl(D.Comm.unique_id(), 0, 1, 0)
+    ctx = D.Context(10, t.width, t.ctx_depth, t.loop_depth, grinding=8)
+    ctx.upload(t.columns)
+    assert ctx.prove_sharded(comm, t.public_inputs, op.outputs) == op.prove()
+    ctx.close()
+    comm.close()
+
+
+def test_prove_sharded_reports_an_invalid_trace_on_every_rank(oracle):
+    import distaff_amd as D
+    O = oracle
+    t = O.fibonacci_trace(128)
+    cols = t.columns.copy()
+    cols[16, 40, 0] += 1
+    op = O.Prover.from_trace(t, 1, grinding=8)
+    ctxs = []
+    for r in range(4):
+        ctx = D.Context(7, t.width, t.ctx_depth, t.loop_depth, rank=r, world=4, grinding=8)
+        ctx.upload(cols)
+        ctxs.append(ctx)
+    with pytest.raises(D.DistaffError) as e:
+        D.prove_sharded_local(ctxs, t.public_inputs, op.outputs)
+    assert e.value.code == -3 and "step" in str(e.value)
+    for ctx in ctxs:
+        ctx.close()
+
+
 def test_plain_c_host_produces_the_oracle_proof(oracle, tmp_path):
     """examples/prove_fibonacci.c (C99, only include/distaff_hip.h and the shared library) writes the same bytes as the oracle."""
     import subprocess

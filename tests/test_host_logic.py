@@ -44,7 +44,7 @@ def test_context_creation_validates_and_fails_loudly_without_gpu():
     """The product path has no CPU fallback: bad parameters are argument errors; on a box without a GPU a valid request is a HIP error."""
     import torch
     import distaff_amd as D
-    for kw in (dict(log_n=5), dict(log_n=25), dict(log_blowup=3), dict(log_blowup=9), dict(width=15), dict(width=128), dict(num_queries=0),
+    for kw in (dict(log_n=3), dict(log_n=25), dict(log_blowup=3), dict(log_blowup=9), dict(width=15), dict(width=128), dict(num_queries=0),
                dict(world=3), dict(world=16), dict(rank=2, world=2)):
         args = dict(log_n=8, width=20, ctx_depth=1, loop_depth=0, log_blowup=5, num_queries=50, grinding=20, rank=0, world=1)
         args.update(kw)
