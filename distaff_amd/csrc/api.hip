@@ -75,7 +75,7 @@ static std::vector<fe> build_periodic_table() {
 }
 
 static void free_all(dst_ctx* c) {
-    void* ptrs[] = {c->tw_lo, c->tw_hi, c->itw_lo, c->itw_hi, c->w1f, c->w2f, c->w1i, c->w2i, c->prescale, c->tw4_lde, c->tw4_fwd, c->tw4_inv, c->tw4_row_fwd, c->tw4_row_inv, c->w3f, c->w3i, c->tmp2, c->periodic, c->trace, c->polys, c->lde, c->tmp,
+    void* ptrs[] = {c->tw_lo, c->tw_hi, c->itw_lo, c->itw_hi, c->w1f, c->w2f, c->w1i, c->w2i, c->prescale, c->dit_last, c->tw4_lde, c->tw4_fwd, c->tw4_inv, c->tw4_row_fwd, c->tw4_row_inv, c->w3f, c->w3i, c->tmp2, c->periodic, c->trace, c->polys, c->lde, c->tmp,
                     c->trace_leaves, c->trace_nodes, c->air_consts, c->ceval, c->cwork, c->cpoly, c->cevals, c->cnodes, c->comp_poly, c->comp, c->scratch, c->d_u64, c->d_stage};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& e : c->kpending) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
@@ -174,7 +174,14 @@ static int ctx_init(dst_ctx* c) {
         if ((r = dev_alloc(c, &c->tw4_row_fwd, (size_t)1 << pl.log_n2))) return r;
         if ((r = dev_alloc(c, &c->tw4_row_inv, (size_t)1 << pl.log_n2))) return r;
     }
-    if ((r = dev_upload(c, &c->prescale, h_powers_tw(h_root_of_unity(c->log_b + pl.log_n1), (size_t)1 << (c->log_b + pl.log_n1))))) return r;
+    {
+        const std::vector<fe_tw> pre = h_powers_tw(h_root_of_unity(c->log_b + pl.log_n1), (size_t)1 << (c->log_b + pl.log_n1));
+        if ((r = dev_upload(c, &c->prescale, pre))) return r;
+        const size_t half = (size_t)1 << (pl.log_n1 - 1);
+        std::vector<fe_tw> last(c->B * half);
+        for (size_t j = 0; j < c->B; j++) for (size_t k = 0; k < half; k++) last[j * half + k] = pre[j + c->B * k];
+        if ((r = dev_upload(c, &c->dit_last, last))) return r;
+    }
     if ((r = dev_alloc(c, &c->tw4_lde, c->Bc * c->n))) return r;
     if ((r = dev_alloc(c, &c->tw4_fwd, c->n))) return r;
     if ((r = dev_alloc(c, &c->tw4_inv, c->n))) return r;

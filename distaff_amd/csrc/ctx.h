@@ -79,6 +79,7 @@ struct dst_ctx {
     // every twiddle of the LDS-family transforms is a table pair (w, w * 2^64 mod p), see fe_mul_tw (fe.h)
     fe_tw *w1f = nullptr, *w2f = nullptr, *w1i = nullptr, *w2i = nullptr;   // stage twiddles w_{n1}^t, w_{n2}^t and inverses
     fe_tw *prescale = nullptr;                   // w_{B*n1}^t, t < B*n1
+    fe_tw *dit_last = nullptr;                   // [B][n1/2]: last-stage twiddles of every coset's DIT, w_{B*n1}^(j + B*k) (the pre-scale table regrouped per coset)
     // four-step twiddles of pass A as full tables in output order [k1][m2] (one multiplication per element instead of a two-level
     // lookup + two; the extra 16 B/element read is free: the pass runs at a tenth of the HBM bandwidth)
     fe_tw *tw4_lde = nullptr;                    // [Bc][n]: w_N^(m2 * (B*k1 + j)), local cosets j

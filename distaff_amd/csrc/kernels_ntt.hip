@@ -29,6 +29,7 @@ struct NttArgs {
     size_t dst_col_stride, dst_coset_stride;
     const fe_tw* stage_tw;     // w_len^t, t < len/2 (forward or inverse), as table pairs
     const fe_tw* prescale;     // w_{B*n1}^t or nullptr
+    const fe_tw* dit_last;     // coset DIT whose last-stage twiddles stay in global memory: [B][n1/2] pairs w_{B*n1}^(j + B*k), else nullptr
     const fe_tw* tw4;          // four-step twiddles in output order [coset][k1][m2] (coset stride tw4_coset_stride)
     size_t tw4_coset_stride;
     uint32_t log_n1, log_n2, tile /* log2 of the tile width */, log_N, log_b;
@@ -88,7 +89,8 @@ __global__ void __launch_bounds__(THREADS, 4) ntt_pass_a(NttArgs a, const fe* __
     const uint32_t pmask = (1u << (a.log_b + a.log_n1)) - 1u;
     if (a.dit) {
         // stage twiddles of this coset: g^(n1/B) * w_B^k = w_{B_lde*n1}^((j + B_lde*k) * n1/B) straight from the pre-scale table
-        for (uint32_t i = threadIdx.x; i + 1 < n1; i += THREADS) {
+        const uint32_t in_lds = a.dit_last ? n1 / 2 : n1;                                     // entries + 1
+        for (uint32_t i = threadIdx.x; i + 1 < in_lds; i += THREADS) {
             const uint32_t lb = 31u - (uint32_t)__clz(i + 1), k = i + 1 - (1u << lb);         // entry i: block size B = 2^(lb+1), index k
             TW[i] = a.prescale[((jg + (k << a.log_b)) << (a.log_n1 - lb - 1)) & pmask];
         }
@@ -114,7 +116,8 @@ __global__ void __launch_bounds__(THREADS, 4) ntt_pass_a(NttArgs a, const fe* __
 #undef NTT_PUT_A
         __syncthreads();
         if (it + 1 < a.tiles_per_block) NTT_FETCH_A(tile0 + it + 1)
-        if (a.dit) lds_ntt_dit<THREADS>(L, TW, a.log_n1, log_t, 1u, a.log_n1 + 1u); else lds_ntt_dif<THREADS>(L, TW, a.log_n1, log_t, 1u, a.log_n1 + 1u);
+        if (a.dit) lds_ntt_dit<THREADS>(L, TW, a.log_n1, log_t, 1u, a.log_n1 + 1u, a.dit_last ? a.dit_last + (size_t)jg * (n1 / 2) : nullptr);
+        else lds_ntt_dif<THREADS>(L, TW, a.log_n1, log_t, 1u, a.log_n1 + 1u);
         // read-out in batches of RB elements per lane: the twiddle loads of a batch are in flight together (the 512-lane instance also
         // holds eight prefetched elements: a batch of four would spill).  Measured alternatives that did not pay: requesting the
         // twiddles before the last round (spills), a bank-conflict-free permutation of the LDS slots, rounds without workgroup barriers.
@@ -443,9 +446,13 @@ static void ntt_launch(dst_ctx* c, bool pass_b, NttArgs& a, size_t groups, size_
 // tile + pairs fit the 80 KiB that let two workgroups share a CU; otherwise pre-scale + DIF with the n1/2 shared stage twiddles (one
 // more multiplication per element, two workgroups per CU: measured 14.5 against 15.0 ms per proof for the 1024-point tiles of n = 2^20).
 // DISTAFF_NTT_DIF=1 / 0 forces one or the other (the tests run both).
-static bool ntt_first_pass_dit(size_t n1, size_t tile) {
-    if (const char* e = getenv("DISTAFF_NTT_DIF")) return e[0] == '0';
-    return n1 * tile * sizeof(fe) + n1 * sizeof(fe_tw) <= NTT_LDS_TWO_PER_CU;
+// returns 0: pre-scale + DIF, 1: coset DIT with the whole table in LDS, 2: coset DIT whose last-stage twiddles (half of the table) are read
+// from global memory (tile + the other half fit 80 KiB)
+static int ntt_first_pass_mode(size_t n1, size_t tile) {
+    if (const char* e = getenv("DISTAFF_NTT_DIF")) return e[0] == '0' ? 1 : e[0] == '2' ? 2 : 0;
+    if (n1 * tile * sizeof(fe) + n1 * sizeof(fe_tw) <= NTT_LDS_TWO_PER_CU) return 1;
+    if (n1 * tile * sizeof(fe) + (n1 / 2) * sizeof(fe_tw) <= NTT_LDS_TWO_PER_CU) return 2;
+    return 0;
 }
 static NttArgs ntt_common_args(dst_ctx* c, bool inverse, bool lde, uint32_t skip) {
     NttArgs a{};
@@ -469,8 +476,9 @@ static void launch_pass_lds(dst_ctx* c, bool pass_b, const fe* src, size_t src_c
         a.tw4 = lde ? c->tw4_lde + (size_t)skip * c->n : (inverse ? c->tw4_inv : c->tw4_fwd); a.tw4_coset_stride = lde ? c->n : 0;
         a.stage_tw = inverse ? c->w1i : c->w1f; a.tile = (uint32_t)__builtin_ctz(p.tile_a);
         const size_t n1 = (size_t)1 << p.log_n1;
-        a.dit = (lde && ntt_first_pass_dit(n1, p.tile_a)) ? 1u : 0u;
-        const size_t lds_a = n1 * p.tile_a * sizeof(fe) + (a.dit ? n1 : n1 / 2) * sizeof(fe_tw);
+        const int mode = lde ? ntt_first_pass_mode(n1, p.tile_a) : 0;
+        a.dit = mode ? 1u : 0u; a.dit_last = mode == 2 ? c->dit_last : nullptr;
+        const size_t lds_a = n1 * p.tile_a * sizeof(fe) + (mode == 1 ? n1 : n1 / 2) * sizeof(fe_tw);
         const uint32_t tiles = (1u << p.log_n2) / p.tile_a;
         a.tiles_per_block = ntt_tiles_per_block(tiles, cosets * cols);
         ntt_launch(c, false, a, tiles / a.tiles_per_block, cosets, cols, lds_a, "ntt_pass_a", 16.0 * c->n * cols * (lde ? (1 + cosets) : 2 * cosets));
@@ -501,13 +509,14 @@ static void launch_three_pass(dst_ctx* c, const fe* src, size_t src_col_stride, 
     a.prescale = lde ? c->prescale : nullptr; a.has_scale = 0;
     a.tw4 = lde ? c->tw4_lde + (size_t)skip * n : (inverse ? c->tw4_inv : c->tw4_fwd); a.tw4_coset_stride = lde ? n : 0;
     a.stage_tw = inverse ? c->w1i : c->w1f;
-    a.dit = (lde && ntt_first_pass_dit(n1, p.tile_a)) ? 1u : 0u;
+    const int mode = lde ? ntt_first_pass_mode(n1, p.tile_a) : 0;
+    a.dit = mode ? 1u : 0u; a.dit_last = mode == 2 ? c->dit_last : nullptr;
     a.src = src; a.src_col_stride = src_col_stride; a.src_coset_stride = src_coset_stride;
     a.dst = c->tmp; a.dst_col_stride = n * cosets; a.dst_coset_stride = n;
     {
         const uint32_t tiles = (uint32_t)(nrow / p.tile_a);
         a.tiles_per_block = ntt_tiles_per_block(tiles, cosets * cols);
-        const size_t lds = n1 * p.tile_a * sizeof(fe) + (a.dit ? n1 : n1 / 2) * sizeof(fe_tw);
+        const size_t lds = n1 * p.tile_a * sizeof(fe) + (mode == 1 ? n1 : n1 / 2) * sizeof(fe_tw);
         ntt_launch(c, false, a, tiles / a.tiles_per_block, cosets, cols, lds, "ntt_pass_a", 16.0 * n * cols * (lde ? (1 + cosets) : 2 * cosets));
     }
     // pass 2: tmp -> tmp2, every (coset, k1) row of nrow points is an array of shape 2^log_mid x n3

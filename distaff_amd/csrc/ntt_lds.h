@@ -77,8 +77,10 @@ __device__ __forceinline__ void lds_ntt_dif(fe* L, const fe_tw* W, uint32_t log_
 // odd indices are coset transforms with g^2, so the stage that merges blocks of size B multiplies by g^(len/B) * w_B^k: the
 // pre-scale by g^m costs nothing -- it is part of twiddles that had to be applied anyway.  W holds them per stage at offset
 // B/2 - 1 (len - 1 entries for the workgroup's coset).  Two stages per LDS round trip, as in lds_ntt_dif.
+// `Wlast` != nullptr: the len/2 twiddles of the LAST stage (half of the coset's table) are not in LDS but read from this global array
+// (contiguous per coset, L2-resident): tile + the other len/2 - 1 pairs then fit the 80 KiB that let two workgroups share a CU.
 template <int THREADS>
-__device__ __forceinline__ void lds_ntt_dit(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s_from, uint32_t s_to) {
+__device__ __forceinline__ void lds_ntt_dit(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s_from, uint32_t s_to, const fe_tw* __restrict__ Wlast = nullptr) {
     const uint32_t T = 1u << log_t;
     uint32_t s = s_from;                             // stages [s_from, s_to), s_from odd
     for (; s + 1 <= log_len && s < s_to; s += 2) {
@@ -90,7 +92,9 @@ __device__ __forceinline__ void lds_ntt_dit(fe* L, const fe_tw* W, uint32_t log_
             const fe_tw tb = W[half - 1 + k];
             const fe x0 = *p0, x1 = fe_mul_tw(*p1, tb), x2 = *p2, x3 = fe_mul_tw(*p3, tb);
             const fe a0 = fe_add(x0, x1), a1 = fe_sub(x0, x1);
-            const fe a2 = fe_mul_tw(fe_add(x2, x3), W[B - 1 + k]), a3 = fe_mul_tw(fe_sub(x2, x3), W[B - 1 + k + half]);
+            const bool from_global = Wlast != nullptr && s + 1 == log_len;        // the second stage of this round is the last stage
+            const fe_tw t2 = from_global ? Wlast[k] : W[B - 1 + k], t3 = from_global ? Wlast[k + half] : W[B - 1 + k + half];
+            const fe a2 = fe_mul_tw(fe_add(x2, x3), t2), a3 = fe_mul_tw(fe_sub(x2, x3), t3);
             *p0 = fe_add(a0, a2); *p2 = fe_sub(a0, a2);
             *p1 = fe_add(a1, a3); *p3 = fe_sub(a1, a3);
         }
@@ -101,7 +105,7 @@ __device__ __forceinline__ void lds_ntt_dit(fe* L, const fe_tw* W, uint32_t log_
         for (uint32_t w = threadIdx.x; w < half * T; w += THREADS) {
             const uint32_t t = w & (T - 1), k = w >> log_t;
             fe* p0 = L + lds_slot(k, t, log_t); fe* p1 = L + lds_slot(k + half, t, log_t);
-            const fe u = *p0, v = fe_mul_tw(*p1, W[half - 1 + k]);
+            const fe u = *p0, v = fe_mul_tw(*p1, Wlast != nullptr ? Wlast[k] : W[half - 1 + k]);
             *p0 = fe_add(u, v); *p1 = fe_sub(u, v);
         }
         __syncthreads();

@@ -44,6 +44,7 @@ SELECTION = [
     "test_general_constraint_instances_on_the_fibonacci_trace[generic]",
     "test_lde_every_tile_length[reg-13-5]",
     "test_lde_every_tile_length[lds-13-5]",
+    "test_lde_every_tile_length[dit2-13-5]",
 ]
 
 

@@ -388,7 +388,7 @@ def _random_columns(W, n, seed):
 
 @pytest.mark.parametrize("family,log_n,log_blowup", [("reg", 13, 5), ("reg", 14, 5), ("reg", 15, 4), ("reg", 16, 5), ("reg", 17, 4), ("reg", 18, 4),
                                                       ("reg", 19, 4), ("reg", 20, 4), ("reg", 21, 4), ("reg", 22, 4), ("reg", 23, 4), ("reg", 24, 4),
-                                                      ("lds", 13, 5), ("lds", 16, 5), ("lds", 19, 4), ("lds", 22, 4), ("auto", 21, 4), ("auto", 22, 4), ("auto", 23, 4), ("auto", 24, 4), ("3pass", 20, 5), ("dif", 16, 5), ("dif", 21, 4), ("dit", 16, 5), ("dit", 20, 5)])
+                                                      ("lds", 13, 5), ("lds", 16, 5), ("lds", 19, 4), ("lds", 22, 4), ("auto", 21, 4), ("auto", 22, 4), ("auto", 23, 4), ("auto", 24, 4), ("3pass", 20, 5), ("dif", 16, 5), ("dif", 21, 4), ("dit", 16, 5), ("dit", 20, 5), ("dit2", 13, 5), ("dit2", 20, 5)])
 def test_lde_every_tile_length(oracle, monkeypatch, family, log_n, log_blowup):
     """Both NTT kernel families (register-radix: every tile length 2^6 .. 2^12 in both passes; LDS radix-2) and the default per-pass
     choice at the largest size, through size-independent properties that pin the
@@ -399,9 +399,9 @@ def test_lde_every_tile_length(oracle, monkeypatch, family, log_n, log_blowup):
     n, B, W = 1 << log_n, 1 << log_blowup, 16
     cols = _random_columns(W, n, 1000 + log_n)
     monkeypatch.delenv("DISTAFF_NTT_DIF", raising=False)
-    if family in ("dif", "dit"):                                         # first pass forced to pre-scale + DIF / to the coset DIT (1024-lane instance at 2^20)
-        monkeypatch.delenv("DISTAFF_NTT", raising=False)
-        monkeypatch.setenv("DISTAFF_NTT_DIF", "1" if family == "dif" else "0")
+    if family in ("dif", "dit", "dit2"):                                 # first pass forced to pre-scale + DIF / to the coset DIT with its table in LDS
+        monkeypatch.delenv("DISTAFF_NTT", raising=False)                # (1024-lane instance at 2^20) / to the DIT whose last-stage twiddles stay in global memory
+        monkeypatch.setenv("DISTAFF_NTT_DIF", {"dif": "1", "dit": "0", "dit2": "2"}[family])
     elif family == "auto":
         monkeypatch.delenv("DISTAFF_NTT", raising=False)
     else:
@@ -613,6 +613,21 @@ def test_plain_c_host_produces_the_oracle_proof(oracle, tmp_path):
     subprocess.check_call([exe, "10", str(out)])
     t = oracle.fibonacci_trace(1 << 10)
     assert out.read_bytes() == oracle.Prover.from_trace(t, 1).prove()
+
+
+def test_plain_c_multi_gpu_host_produces_the_oracle_proof(oracle, tmp_path):
+    """examples/prove_sharded.c: one process with four thread-ranks on the one GPU of this box (in-process transport), and one process
+    per rank over RCCL with the single rank the box offers; both write the oracle's bytes."""
+    import subprocess
+    from test_host_logic import _compile_c_host
+    exe = _compile_c_host(tmp_path, "prove_sharded")
+    expected = oracle.Prover.from_trace(oracle.fibonacci_trace(1 << 10), 1).prove()
+    out = tmp_path / "local.bin"
+    subprocess.check_call([exe, "local", "4", "10", "1", str(out)])
+    assert out.read_bytes() == expected
+    out = tmp_path / "rccl.bin"
+    subprocess.check_call([exe, "rccl", "0", "1", "10", str(tmp_path / "unique.id"), str(out)])
+    assert out.read_bytes() == expected
 
 
 def test_gpu_proofs_match_golden_digests():

@@ -57,12 +57,12 @@ def test_context_creation_validates_and_fails_loudly_without_gpu():
         assert e.value.code == D.DST_ERR_HIP
 
 
-def _compile_c_host(tmp_path):
+def _compile_c_host(tmp_path, name="prove_fibonacci"):
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    exe = str(tmp_path / "prove_fibonacci")
-    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", "prove_fibonacci.c"),
+    exe = str(tmp_path / name)
+    subprocess.check_call(["gcc", "-std=gnu99", "-O2", "-Wall", "-Werror", "-I" + os.path.join(root, "include"), os.path.join(root, "examples", name + ".c"),
                            "-L" + os.path.join(root, "distaff_amd"), "-ldistaff_hip", "-Wl,-rpath," + os.path.join(root, "distaff_amd"), "-o", exe])
     return exe
 
@@ -72,6 +72,7 @@ def test_c_abi_header_is_plain_c_and_links(tmp_path):
     import subprocess
     import torch
     exe = _compile_c_host(tmp_path)
+    _compile_c_host(tmp_path, "prove_sharded")             # the multi-GPU host links against the same library, nothing else
     if not torch.cuda.is_available():                      # without a GPU the host fails loudly at context creation (no CPU fallback)
         r = subprocess.run([exe, "8"], capture_output=True, text=True)
         assert r.returncode == 1 and "dst_ctx_create" in r.stderr
