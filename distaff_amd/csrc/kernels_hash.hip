@@ -118,9 +118,50 @@ __global__ void __launch_bounds__(HASH_THREADS) merkle_top_kernel(digest* nodes,
     if (threadIdx.x < 8) nodes[0].w[threadIdx.x] = 0;          // merkle.rs:275
 }
 
+// nine levels in one launch: workgroup b hashes the 512 nodes nodes[count + 512 b ..) down to ONE node, keeping the intermediate levels
+// in LDS and writing every level to its place in the heap.  Replaces nine launch-bound level kernels in the middle of a tree (between
+// the wide levels, which are work-bound and keep one launch each, and the single-workgroup top).
+__global__ void __launch_bounds__(HASH_THREADS) merkle_subtree_kernel(digest* nodes, size_t count) {
+    __shared__ digest lvl[HASH_THREADS];
+    const size_t b = blockIdx.x;
+    uint32_t h[8];
+    {
+        const uint4* p = reinterpret_cast<const uint4*>(nodes + count + 512 * b + 2 * threadIdx.x);
+        uint4 a = p[0], bb = p[1], cc = p[2], d = p[3];
+        uint32_t m[16] = {a.x, a.y, a.z, a.w, bb.x, bb.y, bb.z, bb.w, cc.x, cc.y, cc.z, cc.w, d.x, d.y, d.z, d.w};
+        b3_hash64(m, h);
+        store_digest(nodes + (count >> 1) + 256 * b + threadIdx.x, h);
+        store_digest(&lvl[threadIdx.x], h);
+    }
+    __syncthreads();
+    size_t level = count >> 1;
+    for (uint32_t width = 128; width >= 1; width >>= 1) {          // nodes of this workgroup on the level being built
+        level >>= 1;
+        uint32_t m[16];
+        const bool active = threadIdx.x < width;
+        if (active) {
+            const uint4* p = reinterpret_cast<const uint4*>(&lvl[2 * threadIdx.x]);
+            uint4 a = p[0], bb = p[1], cc = p[2], d = p[3];
+            m[0] = a.x; m[1] = a.y; m[2] = a.z; m[3] = a.w; m[4] = bb.x; m[5] = bb.y; m[6] = bb.z; m[7] = bb.w;
+            m[8] = cc.x; m[9] = cc.y; m[10] = cc.z; m[11] = cc.w; m[12] = d.x; m[13] = d.y; m[14] = d.z; m[15] = d.w;
+            b3_hash64(m, h);
+            store_digest(nodes + level + (size_t)width * b + threadIdx.x, h);
+        }
+        __syncthreads();                                            // everyone has read its pair
+        if (active) store_digest(&lvl[threadIdx.x], h);
+        __syncthreads();
+    }
+}
+#define MERKLE_SUBTREE_MAX ((size_t)1 << 19)       // wider levels are work-bound: one launch each
+
 // builds nodes[1 .. count) from an already filled level nodes[count .. 2*count)
 static void merkle_upper_levels(dst_ctx* c, digest* nodes, size_t count) {
     while (count > 1024) {
+        if (count <= MERKLE_SUBTREE_MAX && count % 512 == 0 && !getenv("DISTAFF_MERKLE_LEVELS")) {
+            { KScope ks_(c, "merkle_subtree_kernel", 64.0 * count); hipLaunchKernelGGL(merkle_subtree_kernel, dim3((unsigned)(count / 512)), dim3(HASH_THREADS), 0, c->stream, nodes, count); }
+            count /= 512;
+            continue;
+        }
         size_t cnt = count >> 1;
         { KScope ks_(c, "merkle_level_kernel", 96.0 * cnt); hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((cnt + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream,
                            (const digest*)(nodes + count), nodes + cnt, cnt); }
