@@ -23,6 +23,19 @@
 
 struct __attribute__((aligned(16))) digest { uint32_t w[8]; };
 
+// Four-step twiddles are streamed from HBM once per element of every first pass: as plain elements (16 bytes, general multiplication,
+// 71 VALU instructions) or as table pairs (32 bytes, fe_mul_tw, 55).  Measured on the 2^20 proof: first passes 13.1 ms with plain
+// elements, 13.4 ms with pairs (the table is re-fetched per register: the four workgroups that share it drift apart by more than the
+// 4 MiB L2 of their XCD holds), and half the table memory: plain elements are the default.
+#ifndef NTT_TW4_PAIRS
+#define NTT_TW4_PAIRS 0
+#endif
+#if NTT_TW4_PAIRS
+typedef fe_tw tw4_t;
+#else
+typedef fe tw4_t;
+#endif
+
 #define DST_MAX_FRI_LAYERS 24
 
 // ids for dst_read_buffer
@@ -82,9 +95,9 @@ struct dst_ctx {
     fe_tw *dit_last = nullptr;                   // [B][n1/2]: last-stage twiddles of every coset's DIT, w_{B*n1}^(j + B*k) (the pre-scale table regrouped per coset)
     // four-step twiddles of pass A as full tables in output order [k1][m2] (one multiplication per element instead of a two-level
     // lookup + two; the extra 16 B/element read is free: the pass runs at a tenth of the HBM bandwidth)
-    fe_tw *tw4_lde = nullptr;                    // [Bc][n]: w_N^(m2 * (B*k1 + j)), local cosets j
-    fe_tw *tw4_fwd = nullptr, *tw4_inv = nullptr;   // [n]: w_n^(m2*k1) and its inverse
-    fe_tw *tw4_row_fwd = nullptr, *tw4_row_inv = nullptr;   // three-pass plans: [n2] twiddles w_{n2}^(k2*m3) of the middle pass and inverse
+    tw4_t *tw4_lde = nullptr;                    // [Bc][n]: w_N^(m2 * (B*k1 + j)), local cosets j
+    tw4_t *tw4_fwd = nullptr, *tw4_inv = nullptr;   // [n]: w_n^(m2*k1) and its inverse
+    tw4_t *tw4_row_fwd = nullptr, *tw4_row_inv = nullptr;   // three-pass plans: [n2] twiddles w_{n2}^(k2*m3) of the middle pass and inverse
     fe_tw *w3f = nullptr, *w3i = nullptr;        // three-pass plans: stage twiddles of the last pass (length n3)
     fe *tmp2 = nullptr;                          // three-pass plans: second staging buffer
     fe *periodic = nullptr;                      // [128][23] extended Rescue round constants + cycle masks

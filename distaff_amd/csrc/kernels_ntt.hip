@@ -30,7 +30,7 @@ struct NttArgs {
     const fe_tw* stage_tw;     // w_len^t, t < len/2 (forward or inverse), as table pairs
     const fe_tw* prescale;     // w_{B*n1}^t or nullptr
     const fe_tw* dit_last;     // coset DIT whose last-stage twiddles stay in global memory: [B][n1/2] pairs w_{B*n1}^(j + B*k), else nullptr
-    const fe_tw* tw4;          // four-step twiddles in output order [coset][k1][m2] (coset stride tw4_coset_stride)
+    const tw4_t* tw4;          // four-step twiddles in output order [coset][k1][m2] (coset stride tw4_coset_stride)
     size_t tw4_coset_stride;
     uint32_t log_n1, log_n2, tile /* log2 of the tile width */, log_N, log_b;
     uint32_t j0;               // global index of the first local coset
@@ -104,7 +104,7 @@ __global__ void __launch_bounds__(THREADS, 4) ntt_pass_a(NttArgs a, const fe* __
 #define NTT_EACH(M) { M(0, pre0) M(1, pre1) M(2, pre2) M(3, pre3) M(4, pre4) M(5, pre5) M(6, pre6) M(7, pre7) }
 #define NTT_FETCH_A1(e, var) if constexpr ((e) < EPT) { uint32_t idx = threadIdx.x + (e) * THREADS; idx = idx < count ? idx : 0u; var = src[((size_t)(idx >> log_t) << a.log_n2) + f0 + (idx & (T - 1))]; }
 #define NTT_FETCH_A(tile) { const uint32_t f0 = (tile) * T; NTT_EACH(NTT_FETCH_A1) }
-    const fe_tw* __restrict__ tw4 = a.tw4 + (size_t)jl * a.tw4_coset_stride;
+    const tw4_t* __restrict__ tw4 = a.tw4 + (size_t)jl * a.tw4_coset_stride;
     const uint32_t tile0 = group * a.tiles_per_block;
     NTT_FETCH_A(tile0)
     for (uint32_t it = 0; it < a.tiles_per_block; it++) {
@@ -123,7 +123,7 @@ __global__ void __launch_bounds__(THREADS, 4) ntt_pass_a(NttArgs a, const fe* __
         // twiddles before the last round (spills), a bank-conflict-free permutation of the LDS slots, rounds without workgroup barriers.
         constexpr int RB = THREADS == 512 ? 2 : 4;
         for (uint32_t base = 0; base < count; base += RB * THREADS) {
-            fe v[RB]; fe_tw w[RB]; uint32_t k1s[RB], m2s[RB]; bool ok[RB];
+            fe v[RB]; tw4_t w[RB]; uint32_t k1s[RB], m2s[RB]; bool ok[RB];
             static_for<0, RB>([&](auto q_) {
                 constexpr int q = decltype(q_)::value;
                 uint32_t idx = base + q * THREADS + threadIdx.x;
@@ -137,7 +137,11 @@ __global__ void __launch_bounds__(THREADS, 4) ntt_pass_a(NttArgs a, const fe* __
             });
             static_for<0, RB>([&](auto q_) {
                 constexpr int q = decltype(q_)::value;
+#if NTT_TW4_PAIRS
                 if (ok[q]) dst[((size_t)k1s[q] << a.log_n2) + m2s[q]] = (a.debug & 2u) ? v[q] : fe_mul_tw(v[q], w[q]);
+#else
+                if (ok[q]) dst[((size_t)k1s[q] << a.log_n2) + m2s[q]] = (a.debug & 2u) ? v[q] : fe_mul(v[q], w[q]);
+#endif
             });
         }
     }
@@ -431,7 +435,7 @@ static void ntt_launch(dst_ctx* c, bool pass_b, NttArgs& a, size_t groups, size_
     // two-stage rounds 1 each except the last (1/4: the distance-1 stage has no twiddles), plus four-step twiddle / pre-scale / 1/n
     const uint32_t stages = pass_b ? a.log_n2 : a.log_n1;
     double mults = (!pass_b && a.dit) ? 0.5 * stages : ((stages & 1u) ? 0.5 * (stages - 1) : (stages >= 2 ? 0.5 * stages - 0.75 : 0.0));
-    if (!pass_b) mults += 1.0 + ((!a.dit && a.prescale != nullptr) ? 1.0 : 0.0); else if (a.has_scale) mults += 1.0;
+    if (!pass_b) mults += ((!a.dit && a.prescale != nullptr) ? 1.0 : 0.0) + (NTT_TW4_PAIRS ? 1.0 : 21.0 / 18.0); else if (a.has_scale) mults += 1.0;     // the four-step product: 18 or 21 mads
     const double elements = (double)groups * a.tiles_per_block * ((size_t)1 << a.tile) * ((size_t)1 << stages) * cosets * cols;
     KScope ks_(c, name, bytes, true, 18.0 * mults * elements);
     if (lds <= NTT_LDS_TWO_PER_CU) {
@@ -562,7 +566,7 @@ static void launch_two_pass(dst_ctx* c, const fe* src, size_t src_col_stride, si
 // ---- four-step twiddle tables -------------------------------------------------------------------------------------------------------
 // out[coset][k1][m2] = w_N^(m2 * ((k1 << log_b) + j)) for a transform of 2^log_n points whose inner dimension has 2^log_n2 points;
 // a sub-transform of length n' = n / 2^s is expressed with log_b + s (its root is w_N^(B * 2^s))
-__global__ void twiddle_table_kernel(fe_tw* out, const fe* tw_lo, const fe* tw_hi, uint32_t lo_bits, uint32_t log_n2, uint32_t log_n, uint32_t log_b,
+__global__ void twiddle_table_kernel(tw4_t* out, const fe* tw_lo, const fe* tw_hi, uint32_t lo_bits, uint32_t log_n2, uint32_t log_n, uint32_t log_b,
                                      uint32_t log_N, uint32_t j0, uint32_t coset_twiddle) {
     const size_t n = (size_t)1 << log_n;
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -570,7 +574,11 @@ __global__ void twiddle_table_kernel(fe_tw* out, const fe* tw_lo, const fe* tw_h
     const uint64_t k1 = i >> log_n2, m2 = i & (((size_t)1 << log_n2) - 1);
     const uint64_t jg = coset_twiddle ? j0 + blockIdx.y : 0;
     const uint64_t e = (m2 * ((k1 << log_b) + jg)) & (((uint64_t)1 << log_N) - 1);
+#if NTT_TW4_PAIRS
     out[(size_t)blockIdx.y * n + i] = fe_tw_make(dom_pow(tw_lo, tw_hi, lo_bits, e));
+#else
+    out[(size_t)blockIdx.y * n + i] = dom_pow(tw_lo, tw_hi, lo_bits, e);
+#endif
 }
 int k_build_twiddle_tables(dst_ctx* c) {
     const NttPlan& p = c->plan;

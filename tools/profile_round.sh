@@ -7,7 +7,7 @@ R=$PWD
 OUT=$R/gpurun_out/prof_$TAG
 rm -rf $OUT; mkdir -p $OUT
 cd /tmp
-CMD="python $R/bench.py --steps $STEPS --warmup 1 --no-cpu-baseline"
+CMD="python $R/bench.py --steps $STEPS --warmup 1 --no-cpu-baseline --no-upload-leg"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o p -- $CMD > $OUT/stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/fetch -o p -- $CMD > $OUT/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/write -o p -- $CMD > $OUT/write.log 2>&1
