@@ -67,6 +67,18 @@ __device__ __forceinline__ void ntt_block(const NttArgs& a, uint32_t& group, uin
     jl = u / a.groups; group = u % a.groups;
 }
 
+// consumer of the last butterfly round of the second passes (ntt_lds.h): the results leave for HBM without another pass over LDS
+struct OutB {                                          // natural-order store X[k1 + n1 * k2] from the last round, 1/n of inverse transforms on the way
+    static constexpr bool active = true;
+    fe* __restrict__ dst; size_t k_stride; uint32_t log_n2, k1_0; bool scale; fe_tw s;
+    struct Tok {};
+    __device__ __forceinline__ Tok pre(uint32_t, uint32_t) const { return Tok{}; }
+    __device__ __forceinline__ void put(uint32_t row, uint32_t t, const fe& v, const Tok&) const {
+        const uint32_t k2 = log_n2 ? (__brev(row) >> (32 - log_n2)) : 0u;
+        dst[(size_t)k2 * k_stride + k1_0 + t] = scale ? fe_mul_tw(v, s) : v;
+    }
+};
+
 extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
 
 // Both passes are persistent over `tiles_per_block` adjacent tiles: the tile's elements for the NEXT iteration are fetched from HBM
@@ -119,8 +131,9 @@ __global__ void __launch_bounds__(THREADS, 4) ntt_pass_a(NttArgs a, const fe* __
         if (a.dit) lds_ntt_dit<THREADS>(L, TW, a.log_n1, log_t, 1u, a.log_n1 + 1u, a.dit_last ? a.dit_last + (size_t)jg * (n1 / 2) : nullptr);
         else lds_ntt_dif<THREADS>(L, TW, a.log_n1, log_t, 1u, a.log_n1 + 1u);
         // read-out in batches of RB elements per lane: the twiddle loads of a batch are in flight together (the 512-lane instance also
-        // holds eight prefetched elements: a batch of four would spill).  Measured alternatives that did not pay: requesting the
-        // twiddles before the last round (spills), a bank-conflict-free permutation of the LDS slots, rounds without workgroup barriers.
+        // holds eight prefetched elements: a batch of four would spill).  The second passes store from their last butterfly round instead
+        // (OutB); here that costs more than it saves: with the four-step twiddles (and the last-stage pairs from global memory) live in
+        // the last round the kernel spills (measured 13.15 / 13.3 against 13.05 ms).
         constexpr int RB = THREADS == 512 ? 2 : 4;
         for (uint32_t base = 0; base < count; base += RB * THREADS) {
             fe v[RB]; tw4_t w[RB]; uint32_t k1s[RB], m2s[RB]; bool ok[RB];
@@ -174,14 +187,8 @@ __global__ void __launch_bounds__(THREADS, 4) ntt_pass_b(NttArgs a, const fe* __
 #undef NTT_PUT_B
         __syncthreads();
         if (it + 1 < a.tiles_per_block) NTT_FETCH_B(tile0 + it + 1)
-        lds_ntt_dif<THREADS>(L, TW, a.log_n2, log_t, 1u, a.log_n2 + 1u);
-        for (uint32_t idx = threadIdx.x; idx < n2 * T; idx += THREADS) {
-            const uint32_t t = idx & (T - 1), r = idx >> log_t;
-            const uint32_t k2 = a.log_n2 ? (__brev(r) >> (32 - a.log_n2)) : 0u;
-            fe v = L[idx];
-            if (a.has_scale) v = fe_mul_tw(v, a.scale);
-            dst[(size_t)k2 * a.dst_k_stride + k1_0 + t] = v;
-        }
+        const OutB out{dst, a.dst_k_stride, a.log_n2, k1_0, a.has_scale != 0, a.scale};
+        lds_ntt_dif<THREADS, OutB>(L, TW, a.log_n2, log_t, 1u, a.log_n2 + 1u, out);
     }
 }
 

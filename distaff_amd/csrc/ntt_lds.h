@@ -31,21 +31,35 @@ __device__ __forceinline__ uint32_t dif_tw_slot(uint32_t e) {
 #endif
 }
 
+// Consumer of the LAST round's results.  With the default the rounds leave the transformed tile in LDS.  A pass hands in an object
+// whose `pre(row, t)` may start a global load for the element (row, t) before the butterfly's arithmetic (the four-step twiddle: its
+// latency hides behind ~300 instructions) and whose `put(row, t, value, token)` finishes and stores the element: the last round then
+// writes straight to HBM -- one LDS write + read per element, one barrier and the read-out's index arithmetic less per tile.
+struct NttKeepInLds {
+    static constexpr bool active = false;
+    struct Tok {};
+    __device__ __forceinline__ Tok pre(uint32_t, uint32_t) const { return Tok{}; }
+    __device__ __forceinline__ void put(uint32_t, uint32_t, const fe&, const Tok&) const {}
+};
+
 // in-LDS DIF over the first index of L[len][T]; output position r holds frequency bitrev(r).  W: stage twiddles w_len^t in LDS.
 // Two radix-2 stages are fused into one radix-4 round (one LDS round trip, one barrier and one index computation per two
 // stages; the arithmetic is exactly the two radix-2 stages); an odd stage count ends with a plain radix-2 stage.
-template <int THREADS>
-__device__ __forceinline__ void lds_ntt_dif(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s_from, uint32_t s_to) {
+template <int THREADS, class Out = NttKeepInLds>
+__device__ __forceinline__ void lds_ntt_dif(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s_from, uint32_t s_to, const Out& out = Out()) {
     const uint32_t T = 1u << log_t;
     uint32_t s = s_from;                             // stages [s_from, s_to), s_from odd
     for (; s + 1 <= log_len && s < s_to; s += 2) {
         const uint32_t ld = log_len - s;             // log2 of the first stage's butterfly distance d
         const uint32_t d = 1u << ld, hd = d >> 1;
         const bool last = (s + 1 == log_len);        // second stage has distance 1: its twiddles are 1
+        const bool fin = Out::active && last;        // the results of this round leave through `out`
         for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 2) * T; w += THREADS) {
             const uint32_t t = w & (T - 1), q = w >> log_t;
             const uint32_t pos = q & (hd - 1), blk = q >> (ld - 1);
             const uint32_t i0 = (blk << (ld + 1)) + pos;
+            typename Out::Tok k0, k1, k2, k3;
+            if (fin) { k0 = out.pre(i0, t); k1 = out.pre(i0 + hd, t); k2 = out.pre(i0 + d, t); k3 = out.pre(i0 + d + hd, t); }
             fe* p0 = L + lds_slot(i0, t, log_t); fe* p1 = L + lds_slot(i0 + hd, t, log_t); fe* p2 = L + lds_slot(i0 + d, t, log_t); fe* p3 = L + lds_slot(i0 + d + hd, t, log_t);
             const fe x0 = *p0, x1 = *p1, x2 = *p2, x3 = *p3;
             // stage s: (x0, x2) with w_2d^pos, (x1, x3) with w_2d^(pos + d/2)
@@ -57,18 +71,22 @@ __device__ __forceinline__ void lds_ntt_dif(fe* L, const fe_tw* W, uint32_t log_
             fe y0 = fe_add(a0, a1), y1 = fe_sub(a0, a1);
             fe y2 = fe_add(a2, a3), y3 = fe_sub(a2, a3);
             if (!last && hd != 1) { const fe_tw tw = W[dif_tw_slot(pos << s)]; y1 = fe_mul_tw(y1, tw); y3 = fe_mul_tw(y3, tw); }
-            *p0 = y0; *p1 = y1; *p2 = y2; *p3 = y3;
+            if (fin) { out.put(i0, t, y0, k0); out.put(i0 + hd, t, y1, k1); out.put(i0 + d, t, y2, k2); out.put(i0 + d + hd, t, y3, k3); }
+            else { *p0 = y0; *p1 = y1; *p2 = y2; *p3 = y3; }
         }
-        __syncthreads();
+        if (!fin) __syncthreads();
     }
     if (s == log_len && s < s_to) {                  // distance-1 stage, no twiddles
         for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 1) * T; w += THREADS) {
             const uint32_t t = w & (T - 1), q = w >> log_t;
+            typename Out::Tok k0, k1;
+            if (Out::active) { k0 = out.pre(q << 1, t); k1 = out.pre((q << 1) + 1, t); }
             fe* p0 = L + lds_slot(q << 1, t, log_t); fe* p1 = L + lds_slot((q << 1) + 1, t, log_t);
             const fe a = *p0, b = *p1;
-            *p0 = fe_add(a, b); *p1 = fe_sub(a, b);
+            if (Out::active) { out.put(q << 1, t, fe_add(a, b), k0); out.put((q << 1) + 1, t, fe_sub(a, b), k1); }
+            else { *p0 = fe_add(a, b); *p1 = fe_sub(a, b); }
         }
-        __syncthreads();
+        if (!Out::active) __syncthreads();
     }
 }
 
@@ -79,15 +97,18 @@ __device__ __forceinline__ void lds_ntt_dif(fe* L, const fe_tw* W, uint32_t log_
 // B/2 - 1 (len - 1 entries for the workgroup's coset).  Two stages per LDS round trip, as in lds_ntt_dif.
 // `Wlast` != nullptr: the len/2 twiddles of the LAST stage (half of the coset's table) are not in LDS but read from this global array
 // (contiguous per coset, L2-resident): tile + the other len/2 - 1 pairs then fit the 80 KiB that let two workgroups share a CU.
-template <int THREADS>
-__device__ __forceinline__ void lds_ntt_dit(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s_from, uint32_t s_to, const fe_tw* __restrict__ Wlast = nullptr) {
+template <int THREADS, class Out = NttKeepInLds>
+__device__ __forceinline__ void lds_ntt_dit(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s_from, uint32_t s_to, const fe_tw* __restrict__ Wlast = nullptr, const Out& out = Out()) {
     const uint32_t T = 1u << log_t;
     uint32_t s = s_from;                             // stages [s_from, s_to), s_from odd
     for (; s + 1 <= log_len && s < s_to; s += 2) {
         const uint32_t B = 1u << s, half = B >> 1;                     // first stage merges blocks of size B / 2 into B, second B into 2B
+        const bool fin = Out::active && s + 1 == log_len;              // the results of this round leave through `out`
         for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 2) * T; w += THREADS) {
             const uint32_t t = w & (T - 1), q = w >> log_t;
             const uint32_t k = q & (half - 1), base = (q >> (s - 1)) << (s + 1);
+            typename Out::Tok k0, k1, k2, k3;
+            if (fin) { k0 = out.pre(base + k, t); k1 = out.pre(base + k + half, t); k2 = out.pre(base + k + B, t); k3 = out.pre(base + k + B + half, t); }
             fe* p0 = L + lds_slot(base + k, t, log_t); fe* p1 = L + lds_slot(base + k + half, t, log_t); fe* p2 = L + lds_slot(base + k + B, t, log_t); fe* p3 = L + lds_slot(base + k + B + half, t, log_t);
             const fe_tw tb = W[half - 1 + k];
             const fe x0 = *p0, x1 = fe_mul_tw(*p1, tb), x2 = *p2, x3 = fe_mul_tw(*p3, tb);
@@ -95,20 +116,28 @@ __device__ __forceinline__ void lds_ntt_dit(fe* L, const fe_tw* W, uint32_t log_
             const bool from_global = Wlast != nullptr && s + 1 == log_len;        // the second stage of this round is the last stage
             const fe_tw t2 = from_global ? Wlast[k] : W[B - 1 + k], t3 = from_global ? Wlast[k + half] : W[B - 1 + k + half];
             const fe a2 = fe_mul_tw(fe_add(x2, x3), t2), a3 = fe_mul_tw(fe_sub(x2, x3), t3);
-            *p0 = fe_add(a0, a2); *p2 = fe_sub(a0, a2);
-            *p1 = fe_add(a1, a3); *p3 = fe_sub(a1, a3);
+            if (fin) {
+                out.put(base + k, t, fe_add(a0, a2), k0); out.put(base + k + B, t, fe_sub(a0, a2), k2);
+                out.put(base + k + half, t, fe_add(a1, a3), k1); out.put(base + k + B + half, t, fe_sub(a1, a3), k3);
+            } else {
+                *p0 = fe_add(a0, a2); *p2 = fe_sub(a0, a2);
+                *p1 = fe_add(a1, a3); *p3 = fe_sub(a1, a3);
+            }
         }
-        __syncthreads();
+        if (!fin) __syncthreads();
     }
     if (s == log_len && s < s_to) {                  // last single stage: blocks of len / 2 into len
         const uint32_t half = 1u << (log_len - 1);
         for (uint32_t w = threadIdx.x; w < half * T; w += THREADS) {
             const uint32_t t = w & (T - 1), k = w >> log_t;
+            typename Out::Tok k0, k1;
+            if (Out::active) { k0 = out.pre(k, t); k1 = out.pre(k + half, t); }
             fe* p0 = L + lds_slot(k, t, log_t); fe* p1 = L + lds_slot(k + half, t, log_t);
             const fe u = *p0, v = fe_mul_tw(*p1, Wlast != nullptr ? Wlast[k] : W[half - 1 + k]);
-            *p0 = fe_add(u, v); *p1 = fe_sub(u, v);
+            if (Out::active) { out.put(k, t, fe_add(u, v), k0); out.put(k + half, t, fe_sub(u, v), k1); }
+            else { *p0 = fe_add(u, v); *p1 = fe_sub(u, v); }
         }
-        __syncthreads();
+        if (!Out::active) __syncthreads();
     }
 }
 
