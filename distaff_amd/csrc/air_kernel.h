@@ -20,6 +20,17 @@
 #ifndef AIR_WAVES_PER_SIMD
 #define AIR_WAVES_PER_SIMD 2      // caps the kernel at 256 registers per lane
 #endif
+// Waves per SIMD the compiler must make room for.  Two = 256 registers per lane, no scratch.  Three (168 registers, 50-300 bytes of scratch
+// per lane) is faster all the same for every launch but the op-bit one: the third wave fills the carry-chain wait states two waves leave
+// open.  Measured at 2^20 (ms, two -> three waves): Fibonacci shape 4.51 -> 4.31 (stack), 1.76 -> 1.59 (sponge / context), 1.28 -> 1.39
+// (op bits: stays at two); any-shape instance 4.65 -> 4.46, 3.22 -> 3.08, 2.19 -> 2.07; depth <= 8 instance 4.51 -> 4.46, 1.75 -> 1.64,
+// 2.25 -> 2.27 (stays at two).  The per-operation formulation (SLCAP 32) keeps two.
+constexpr int air_waves_per_simd(int sd, int slcap, int sect) {
+    if (AIR_WAVES_PER_SIMD != 2) return AIR_WAVES_PER_SIMD;                    // forced at compile time
+    if (sect == 2 || sect == 3 || slcap == 32) return 2;
+    if (sd == 0 && slcap == 8 && sect == 80) return 2;
+    return 3;
+}
 
 // Rescue matrices (utils/sponge.rs:72-83, utils/hasher.rs:97-113), uploaded once per context to device memory
 struct AirConsts { fe sponge_mds[16], sponge_inv_mds[16], hasher_mds[36], hasher_inv_mds[36]; };
@@ -268,7 +279,7 @@ struct Acc {
 // not FIRST starts from the partial sums (res, adj[6]) left by the previous launch and one that is not LAST stores them;
 // splitting the evaluation this way keeps the live state of each launch within the register budget.
 template <int CL, int LL, int SD, int SLCAP, int SECT, bool FIRST, bool LAST>
-__global__ void __launch_bounds__(AIR_THREADS, AIR_WAVES_PER_SIMD) air_kernel(AirArgs a) {
+__global__ void __launch_bounds__(AIR_THREADS, air_waves_per_simd(SD, SLCAP, SECT)) air_kernel(AirArgs a) {
     constexpr int SL = SD ? (SD > 8 ? SD : 8) : SLCAP;
     // SLCAP == 12 is the deep instance: any stack depth; slots 0..7 as nested sums from 12 register-resident items of the current
     // row, slots 8.. from memory as seven flag sums times shifted differences (see the stack section)
