@@ -80,6 +80,7 @@ struct dst_ctx {
     std::vector<fe> shard_draws;       // shard.hip: the 344 constraint coefficients of the current proof
     std::shared_ptr<void> open_plan;   // shard.hip: plan of the last dst_shard_open, reused by dst_shard_assemble for the same positions
     std::vector<uint64_t> open_plan_positions;
+    uint8_t open_plan_root[32] = {0};   // trace root the cached plan was built for
     int fri_rep_from = 0;               // sharded phases: FRI layers >= this one are replicated (natural order, full heaps on every rank), see shard.hip
     bool fri_tail_pending = false;      // dst_shard_fri_begin exported the evaluations of layer fri_rep_from; dst_shard_fri_end finishes the commit phase
     fe* fri_nat0 = nullptr;             // natural-order layer 0 when fri_rep_from == 0 (fri_e[0] is the rank's coset-major piece)

@@ -5,6 +5,7 @@
 // collectives themselves are issued by the host (torch.distributed / RCCL in distaff_amd/sharded.py): this file only
 // exports and imports the shards.
 #include <chrono>
+#include <set>
 #include <thread>
 #include "ctx.h"
 #include "comm.h"
@@ -448,6 +449,10 @@ int build_open_plan(dst_ctx* c, const uint64_t* positions_in, uint32_t num_posit
     const uint64_t G = c->prm.world, B = c->B, N = c->N, n = c->n, W = c->W;
     std::vector<uint64_t> positions(positions_in, positions_in + num_positions);
     for (uint64_t q : positions) if (q >= N) { c->err = "query position out of range"; return DST_ERR_ARG; }
+    {   // MerkleTree::prove_batch asserts this (merkle.rs:69): a repeated position would silently drop an opening from the batch proof
+        std::set<uint64_t> seen(positions.begin(), positions.end());
+        if (seen.size() != positions.size()) { c->err = "repeating indexes detected"; return DST_ERR_ARG; }
+    }
     const int L = c->num_fri_layers;
     if ((int)c->fri_roots.size() < L) { c->err = "dst_shard_open: FRI commit phase not finished"; return DST_ERR_STATE; }
     Writer& w = p.w;
@@ -571,12 +576,13 @@ int dst_shard_open(dst_ctx* c, const uint64_t* positions, uint32_t num_positions
     HIP_TRY(c, hipSetDevice(c->device));
     std::shared_ptr<OpenPlan> sp;
     const std::vector<uint64_t> key(positions, positions + num_positions);
-    if (c->open_plan && c->open_plan_positions == key) sp = std::static_pointer_cast<OpenPlan>(c->open_plan);   // the size query just before
+    // the size query just before -- for the same positions AND the same commitments (the template embeds the roots and the values at z)
+    if (c->open_plan && c->open_plan_positions == key && !memcmp(c->open_plan_root, c->trace_root, 32)) sp = std::static_pointer_cast<OpenPlan>(c->open_plan);
     int rc = DST_OK;
     if (!sp) {
         sp = std::make_shared<OpenPlan>();
         if ((rc = build_open_plan(c, positions, num_positions, 0, *sp))) return rc;
-        c->open_plan = sp; c->open_plan_positions = key;
+        c->open_plan = sp; c->open_plan_positions = key; memcpy(c->open_plan_root, c->trace_root, 32);
     }
     OpenPlan& p = *sp;
     const int me = (int)c->prm.rank;
@@ -604,10 +610,11 @@ int dst_shard_assemble(dst_ctx* c, const uint64_t* positions, uint32_t num_posit
     OpenPlan p;
     int rc = DST_OK;
     const std::vector<uint64_t> key(positions, positions + num_positions);
-    if (c->open_plan && c->open_plan_positions == key) {
+    const bool cached = c->open_plan && c->open_plan_positions == key && !memcmp(c->open_plan_root, c->trace_root, 32);
+    if (cached) {
         p = *std::static_pointer_cast<OpenPlan>(c->open_plan);
         for (int i = 0; i < 8; i++) p.w.b[p.w.b.size() - 12 + i] = (uint8_t)(pow_nonce >> (8 * i));
-        c->open_plan.reset(); c->open_plan_positions.clear();
+        if (out) { c->open_plan.reset(); c->open_plan_positions.clear(); }      // a size query (out == NULL) keeps the plan for the call that follows
     } else if ((rc = build_open_plan(c, positions, num_positions, pow_nonce, p))) return rc;
     const size_t G = c->prm.world;
     std::vector<size_t> cursor(G, 0), base(G, 0);

@@ -203,6 +203,21 @@ class ShardedProver:
         self.stage_ms[name] = self.stage_ms.get(name, 0.0) + (now - self._t) * 1e3
         self._t = now
 
+    # -- failures: a rank-local exception (out of memory, a refused argument, a staging buffer that is too small) must not leave the other
+    #    ranks waiting in the next collective: every phase's outcome is agreed on before anyone goes on
+    def _agreed(self, phase, fn, *args):
+        err, out = None, None
+        try:
+            out = fn(*args)
+        except L.DistaffError as e:
+            err = (e.code, str(e))
+        states = self.comm.all_gather_object(err)
+        bad = [(g, st) for g, st in enumerate(states) if st is not None]
+        if bad:
+            g, (code, msg) = bad[0]
+            raise L.DistaffError(code, "%s failed on rank %d: %s" % (phase, g, msg))
+        return out
+
     # -- exchanges
     def _exchange(self, what, arg=0):
         ctx, comm = self.ctx, self.comm
@@ -264,7 +279,7 @@ class ShardedProver:
         p = ctx.params
         self.stage_ms, self._t = {}, time.perf_counter()
         # steps 1-2
-        ctx.shard_commit_trace()
+        self._agreed("extension", ctx.shard_commit_trace)
         self._mark("lde_trace_leaves")
         trace_root = self._exchange(SH_TRACE_TREE)
         self._mark("trace_tree_exchange")
@@ -277,13 +292,13 @@ class ShardedProver:
             raise L.DistaffError(L.DST_ERR_AIR, "transition constraints were not satisfied at step %d" % min(bads))
         self._exchange(SH_CEVAL)
         self._mark("ceval_exchange")
-        ctx.shard_combine()
+        self._agreed("combination", ctx.shard_combine)
         self._mark("combine_constraint_lde")
         constraint_root = self._exchange(SH_CONSTRAINT_TREE)
         self._mark("constraint_tree_exchange")
         # step 6
         draws = L.prng_vector(constraint_root, 516)
-        z1, z2 = ctx.compose(draws)
+        z1, z2 = self._agreed("composition", ctx.compose, draws)
         self._mark("deep_composition")
         # step 7: per exchange two library calls around one all-gather.  Sharded layers: leaves + local levels + export of the
         # boundary nodes | upper tree + draw + fold; then once the evaluations of the first small layer | the rest of the commit phase
@@ -313,13 +328,13 @@ class ShardedProver:
         self._mark("fri")
         # step 8
         seed0 = L.blake3(b"".join(fri_roots))
-        seed1, nonce = ctx.pow_grind(seed0, p.grinding_factor)
+        seed1, nonce = self._agreed("proof of work", ctx.pow_grind, seed0, p.grinding_factor)
         positions = L.query_positions(seed1, N, B, p.num_queries)
         self._mark("pow_queries")
         if not self.python_openings:
             # step 9 behind the C-ABI: every rank plans the same openings, gathers the items it owns (one device gather), the blobs
             # are all-gathered (padded to the longest; the lengths follow from the plan) and every rank fills the same proof
-            blob, lens = ctx.shard_open(positions)
+            blob, lens = self._agreed("openings", ctx.shard_open, positions)
             width = max(max(lens), 1)
             padded = np.zeros(width, dtype=np.uint8)
             padded[:len(blob)] = blob

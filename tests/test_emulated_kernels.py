@@ -27,6 +27,7 @@ SELECTION = [
     "test_blowup_128_and_256[128-7]",
     "test_config2_random_columns_lde_and_merkle[12]",
     "test_invalid_trace_reports_air_error",
+    "test_repeated_query_positions_are_refused",
     "test_tiny_traces_of_32_and_16_rows",
     "test_wide_rows_two_chunk_leaves",
     "test_sharded_prover_equals_single_gpu[2]",

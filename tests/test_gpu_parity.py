@@ -211,6 +211,19 @@ def test_tiny_traces_of_32_and_16_rows(oracle):
         ctx.close()
 
 
+def test_repeated_query_positions_are_refused(oracle):
+    """MerkleTree::prove_batch asserts 'repeating indexes detected' (merkle.rs:69); the C-ABI returns an argument error instead"""
+    import distaff_amd as D
+    t = oracle.fibonacci_trace(128)
+    ctx = _ctx(D, t, grinding=8)
+    ctx.upload(t.columns)
+    ctx.prove(t.public_inputs, [int(oracle.to_ints(t.columns[16, -1:])[0])])
+    with pytest.raises(D.DistaffError) as e:
+        ctx.build_proof([5, 9, 5], 0)
+    assert e.value.code == D.DST_ERR_ARG and "repeating indexes" in str(e.value)
+    ctx.close()
+
+
 def test_invalid_trace_reports_air_error(oracle):
     import distaff_amd as D
     O = oracle

@@ -40,6 +40,16 @@ def test_blake3_lengths(oracle):
         assert D.blake3(data[:n]) == oracle.blake3(data[:n])
 
 
+def test_query_positions_argument_checks():
+    """dst_query_positions returns an error code for a zero domain / extension factor / query count instead of dividing by zero"""
+    import distaff_amd as D
+    seed = bytes(range(32))
+    assert len(D.query_positions(seed, 1 << 12, 32, 50)) == 50
+    for args in ((0, 32, 50), (1 << 12, 0, 50), (1 << 12, 32, 0), (1 << 12, 32, 129)):
+        with pytest.raises(D.DistaffError):
+            D.query_positions(seed, *args)
+
+
 def test_context_creation_validates_and_fails_loudly_without_gpu():
     """The product path has no CPU fallback: bad parameters are argument errors; on a box without a GPU a valid request is a HIP error."""
     import torch
