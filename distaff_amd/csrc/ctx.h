@@ -223,6 +223,7 @@ int k_pow(dst_ctx* c, const uint8_t seed[32], uint32_t grinding, uint64_t* nonce
 // gathers for openings
 void k_gather(dst_ctx* c, const void* src, size_t item_bytes, const uint64_t* idx_dev, size_t count, void* dst);
 void k_gather_rows(dst_ctx* c, const uint64_t* positions_dev, size_t count, fe* out);
+void k_gather_pieces(dst_ctx* c, const uint64_t* addr_dev, size_t count, void* dst);          // dst[t] = the 16 bytes at device address addr[t]
 int k_bench_mulmod(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms);
 int k_bench_mad(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms);
 // coset-sharded (multi-GPU) helpers

@@ -112,6 +112,7 @@ void k_syn_div(dst_ctx* c, fe* a, size_t len, fe b) {
         hipMemcpyAsync(a, scr, len * sizeof(fe), hipMemcpyDeviceToDevice, c->stream);
         return;
     }
+    if (fe_eq(b, fe_one())) { suffix_scan(c, a, len, scr); return; }     // division by (x - 1): q_i = sum_{t > i} a_t, the exclusive scan itself (first-step boundary polynomial)
     size_t te = pow_table_elems(len + 1);
     PowTab fw = build_pow_table(c, scr, b, len + 1);
     PowTab bw = build_pow_table(c, scr + te, fe_inv(b), len + 1);
@@ -336,6 +337,17 @@ void k_gather(dst_ctx* c, const void* src, size_t item_bytes, const uint64_t* id
     size_t total = count * vp;
     if (!total) return;
     { KScope ks_(c, "gather_kernel", 0.0); hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((total + PT - 1) / PT)), dim3(PT), 0, c->stream, (const uint4*)src, vp, idx_dev, count, (uint4*)dst); }
+}
+// every 16-byte piece of every opened item in ONE launch: addr[t] is the device address of piece t (the openings touch a dozen trees and
+// layers; one gather launch per source buffer was 41 launches of a few microseconds each)
+__global__ void gather_pieces_kernel(const uint64_t* __restrict__ addr, size_t count, uint4* __restrict__ dst) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= count) return;
+    dst[t] = *reinterpret_cast<const uint4*>(addr[t]);
+}
+void k_gather_pieces(dst_ctx* c, const uint64_t* addr_dev, size_t count, void* dst) {
+    if (!count) return;
+    { KScope ks_(c, "gather_pieces_kernel", 0.0); hipLaunchKernelGGL(gather_pieces_kernel, dim3((unsigned)((count + PT - 1) / PT)), dim3(PT), 0, c->stream, addr_dev, count, (uint4*)dst); }
 }
 // gather of one trace row per position from the coset-major LDE: out[p][c] = lde[c][j][k] with position = B*k + j
 __global__ void gather_rows_kernel(const fe* __restrict__ lde, size_t n, uint32_t Bc, uint32_t log_b, uint32_t j0, uint32_t W,

@@ -518,42 +518,38 @@ const void* read_source(dst_ctx* c, uint32_t buffer, uint32_t arg) {
 // gathers the requests selected by `mine` (one staging upload, one gather launch per source buffer, one copy back) into `blob`,
 // concatenated in request order
 static int gather_requests(dst_ctx* c, const OpenPlan& p, int me, bool everything, std::vector<uint8_t>& blob) {
-    struct Group { uint32_t buffer, arg, bytes; std::vector<uint64_t> idx; std::vector<size_t> dst; };
-    std::vector<Group> groups;
+    // two launches: the trace rows (W elements each, one per register array) and every other item as 16-byte pieces by address
+    std::vector<uint64_t> rows, addr;               // row positions; device address of every piece
+    std::vector<size_t> row_dst, piece_dst;         // where each row / piece goes in the blob
     size_t total = 0;
     for (auto& r : p.reqs) {
         if (!(everything || r.owner == me || (r.owner < 0 && me == 0))) continue;
-        Group* g = nullptr;
-        for (auto& q : groups) if (q.buffer == r.buffer && q.arg == r.arg) { g = &q; break; }
-        if (!g) { groups.push_back({r.buffer, r.arg, r.bytes, {}, {}}); g = &groups.back(); }
-        g->idx.push_back(r.index); g->dst.push_back(total);
+        if (r.buffer == RD_LDE_ROW) { rows.push_back(r.index); row_dst.push_back(total); }
+        else {
+            const uint8_t* src = (const uint8_t*)read_source(c, r.buffer, r.arg);
+            if (!src) { c->err = "openings: buffer not allocated"; return DST_ERR_STATE; }
+            for (uint32_t o = 0; o < r.bytes; o += 16) { addr.push_back((uint64_t)(uintptr_t)(src + r.index * r.bytes + o)); piece_dst.push_back(total + o); }
+        }
         total += r.bytes;
     }
     blob.resize(total);
-    size_t idx_bytes = 0, out_bytes = 0;
-    for (auto& g : groups) { idx_bytes += (g.idx.size() * 8 + 15) / 16 * 16; out_bytes += g.idx.size() * (size_t)g.bytes; }
+    const size_t row_bytes = c->W * 16;
+    const size_t idx_bytes = ((rows.size() + addr.size()) * 8 + 15) / 16 * 16, out_bytes = rows.size() * row_bytes + addr.size() * 16;
     if (idx_bytes + out_bytes > c->stage_bytes) { c->err = "openings: staging buffer too small"; return DST_ERR_ARG; }
-    std::vector<uint8_t> hidx(idx_bytes), hout(out_bytes);
-    size_t io = 0;
-    for (auto& g : groups) { memcpy(hidx.data() + io, g.idx.data(), g.idx.size() * 8); io += (g.idx.size() * 8 + 15) / 16 * 16; }
-    if (idx_bytes) HIP_TRY(c, hipMemcpyAsync(c->d_stage, hidx.data(), idx_bytes, hipMemcpyHostToDevice, c->stream));
-    io = 0; size_t oo = 0;
-    for (auto& g : groups) {
-        const uint64_t* d_idx = (const uint64_t*)(c->d_stage + io);
-        uint8_t* d_out = c->d_stage + idx_bytes + oo;
-        if (g.buffer == RD_LDE_ROW) k_gather_rows(c, d_idx, g.idx.size(), (fe*)d_out);
-        else {
-            const void* src = read_source(c, g.buffer, g.arg);
-            if (!src) { c->err = "openings: buffer not allocated"; return DST_ERR_STATE; }
-            k_gather(c, src, g.bytes, d_idx, g.idx.size(), d_out);
-        }
-        io += (g.idx.size() * 8 + 15) / 16 * 16; oo += g.idx.size() * (size_t)g.bytes;
-    }
-    if (out_bytes) HIP_TRY(c, hipMemcpyAsync(hout.data(), c->d_stage + idx_bytes, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    std::vector<uint64_t> hidx(rows);
+    hidx.insert(hidx.end(), addr.begin(), addr.end());
+    std::vector<uint8_t> hout(out_bytes);
+    if (!hidx.empty()) HIP_TRY(c, hipMemcpyAsync(c->d_stage, hidx.data(), hidx.size() * 8, hipMemcpyHostToDevice, c->stream));
+    const uint64_t* d_idx = (const uint64_t*)c->d_stage;
+    uint8_t* d_out = c->d_stage + idx_bytes;
+    if (!rows.empty()) k_gather_rows(c, d_idx, rows.size(), (fe*)d_out);
+    k_gather_pieces(c, d_idx + rows.size(), addr.size(), d_out + rows.size() * row_bytes);
+    if (out_bytes) HIP_TRY(c, hipMemcpyAsync(hout.data(), d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
-    oo = 0;
-    for (auto& g : groups) for (size_t i = 0; i < g.idx.size(); i++) { memcpy(blob.data() + g.dst[i], hout.data() + oo, g.bytes); oo += g.bytes; }
+    for (size_t i = 0; i < rows.size(); i++) memcpy(blob.data() + row_dst[i], hout.data() + i * row_bytes, row_bytes);
+    const uint8_t* pieces = hout.data() + rows.size() * row_bytes;
+    for (size_t i = 0; i < addr.size(); i++) memcpy(blob.data() + piece_dst[i], pieces + i * 16, 16);
     return DST_OK;
 }
 
