@@ -104,6 +104,90 @@ __global__ void shift_down_kernel(const fe* src, fe* dst, size_t len) {      // 
     if (i >= len) return;
     dst[i] = i + 1 < len ? src[i + 1] : fe_zero();
 }
+// Blocked form: chunks of SD_CHUNK elements, one workgroup each.  With E_c = sum_{t in chunk c} a_t b^(t - c*C) the contribution of everything to
+// the right of chunk c is R_c = sum_{u > c} E_u (b^C)^(u - c - 1) -- the same division one level up, on 1/2048 of the data -- and inside a
+// chunk a lane owns eight consecutive elements (Horner), the lanes are combined by a suffix scan whose step k multiplies by b^(8 * 2^k).  Three
+// passes over the data (read, read + write) and no power tables, against eight passes + two tables for scale / scan / scale; every power of b
+// is a kernel argument in table-pair form (fe_mul_tw).
+#define SD_CHUNK 2048
+struct SynDivArgs { fe_tw b; fe_tw step[9]; };       // b, and b^(8 * 2^k) for k = 0 .. 8
+// lane value e = sum_j v[j] b^j, then Y_lane = sum_{u >= lane} e_u b^(8 (u - lane)) over the 256 lanes plus a 257th entry `right`
+__device__ __forceinline__ fe sd_lane_scan(fe* sh, const SynDivArgs& p, fe e, fe right) {
+    sh[threadIdx.x] = e;
+    if (threadIdx.x == 0) sh[PT] = right;
+    __syncthreads();
+    fe y = e;
+    for (int k = 0; k < 9; k++) {
+        const uint32_t other = threadIdx.x + (1u << k);
+        const bool has = other <= PT;
+        const fe o = has ? sh[other] : fe_zero();
+        __syncthreads();
+        if (has) y = fe_add(y, fe_mul_tw(o, p.step[k]));
+        sh[threadIdx.x] = y;
+        __syncthreads();
+    }
+    return y;
+}
+// A lane owns eight CONSECUTIVE coefficients; global memory is touched in lane-consecutive order and the chunk is turned round in LDS
+// (one 16-byte pad per eight elements: the lanes of a wavefront then read 144 bytes apart).
+__device__ __forceinline__ uint32_t sd_slot(uint32_t i) { return i + (i >> 3); }
+#define SD_TILE (SD_CHUNK + SD_CHUNK / 8)
+__device__ __forceinline__ void sd_load_chunk(fe* tile, const fe* __restrict__ a, size_t len, fe (&v)[8]) {
+    const size_t base = (size_t)blockIdx.x * SD_CHUNK;
+#pragma unroll
+    for (int r = 0; r < 8; r++) { const uint32_t i = r * PT + threadIdx.x; tile[sd_slot(i)] = base + i < len ? a[base + i] : fe_zero(); }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = tile[sd_slot(threadIdx.x * 8 + j)];
+}
+__global__ void __launch_bounds__(PT) syn_div_chunk_sums_kernel(const fe* __restrict__ a, size_t len, SynDivArgs p, fe* __restrict__ sums) {
+    __shared__ fe tile[SD_TILE];
+    __shared__ fe sh[PT + 1];
+    fe v[8], e = fe_zero();
+    sd_load_chunk(tile, a, len, v);
+#pragma unroll
+    for (int j = 7; j >= 0; j--) e = fe_add(fe_mul_tw(e, p.b), v[j]);
+    const fe y = sd_lane_scan(sh, p, e, fe_zero());
+    if (threadIdx.x == 0) sums[blockIdx.x] = y;
+}
+__global__ void __launch_bounds__(PT) syn_div_chunk_kernel(fe* a, size_t len, SynDivArgs p, const fe* __restrict__ right) {
+    __shared__ fe tile[SD_TILE];
+    __shared__ fe sh[PT + 1];
+    fe v[8], q[8], e = fe_zero();
+    sd_load_chunk(tile, a, len, v);
+#pragma unroll
+    for (int j = 7; j >= 0; j--) { q[j] = e; e = fe_add(fe_mul_tw(e, p.b), v[j]); }   // q[j] = sum_{j' > j in lane} v[j'] b^(j'-j-1);  e = sum_j v[j] b^j
+    (void)sd_lane_scan(sh, p, e, right ? right[blockIdx.x] : fe_zero());
+    fe x = sh[threadIdx.x + 1];                      // everything to the right of this lane, relative to the lane's end
+#pragma unroll
+    for (int j = 7; j >= 0; j--) {                   // q_i += b^(7 - j) * x      (a lane reads and writes only its own eight tile slots)
+        tile[sd_slot(threadIdx.x * 8 + j)] = fe_add(q[j], x);
+        x = fe_mul_tw(x, p.b);
+    }
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * SD_CHUNK;
+#pragma unroll
+    for (int r = 0; r < 8; r++) { const uint32_t i = r * PT + threadIdx.x; if (base + i < len) a[base + i] = tile[sd_slot(i)]; }
+}
+static SynDivArgs syn_div_args(fe b) {
+    SynDivArgs p;
+    p.b = fe_tw_make(b);
+    fe s = b;
+    for (int i = 0; i < 3; i++) s = fe_mul(s, s);                          // b^8
+    for (int k = 0; k < 9; k++) { p.step[k] = fe_tw_make(s); s = fe_mul(s, s); }
+    return p;
+}
+static void syn_div_blocked(dst_ctx* c, fe* a, size_t len, fe b, fe* scratch) {
+    const size_t chunks = (len + SD_CHUNK - 1) / SD_CHUNK;
+    const SynDivArgs p = syn_div_args(b);
+    if (chunks > 1) {
+        { KScope ks_(c, "syn_div_chunk_sums_kernel", 16.0 * len); hipLaunchKernelGGL(syn_div_chunk_sums_kernel, dim3((unsigned)chunks), dim3(PT), 0, c->stream, (const fe*)a, len, p, scratch); }
+        fe bc = b;
+        for (int i = 0; i < 11; i++) bc = fe_mul(bc, bc);                   // b^2048
+        syn_div_blocked(c, scratch, chunks, bc, scratch + chunks);
+    }
+    { KScope ks_(c, "syn_div_chunk_kernel", 32.0 * len); hipLaunchKernelGGL(syn_div_chunk_kernel, dim3((unsigned)chunks), dim3(PT), 0, c->stream, a, len, p, chunks > 1 ? (const fe*)scratch : (const fe*)nullptr); }
+}
 void k_syn_div(dst_ctx* c, fe* a, size_t len, fe b) {
     unsigned g = (unsigned)((len + PT - 1) / PT);
     fe* scr = c->scratch;
@@ -113,6 +197,8 @@ void k_syn_div(dst_ctx* c, fe* a, size_t len, fe b) {
         return;
     }
     if (fe_eq(b, fe_one())) { suffix_scan(c, a, len, scr); return; }     // division by (x - 1): q_i = sum_{t > i} a_t, the exclusive scan itself (first-step boundary polynomial)
+    if (!getenv("DISTAFF_SYN_DIV_TABLES")) { syn_div_blocked(c, a, len, b, scr); return; }
+    // the first formulation, kept as an independent statement (tests run both): scale by b^t, additive suffix scan, scale by b^-(i+1)
     size_t te = pow_table_elems(len + 1);
     PowTab fw = build_pow_table(c, scr, b, len + 1);
     PowTab bw = build_pow_table(c, scr + te, fe_inv(b), len + 1);

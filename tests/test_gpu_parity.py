@@ -88,6 +88,14 @@ def test_fibonacci_all_phases(oracle, log_n):
     _check_all_phases(oracle, D, oracle.fibonacci_trace(1 << log_n))
 
 
+def test_synthetic_division_by_power_tables(oracle, monkeypatch):
+    """k_syn_div's first formulation (scale by b^t, additive suffix scan, scale by b^-(i+1)) is kept beside the blocked one; both give the
+    oracle's quotients (polynom.rs:190) -- at 2^12 steps the blocked form recurses once (16 chunks of 2048 coefficients)."""
+    import distaff_amd as D
+    monkeypatch.setenv("DISTAFF_SYN_DIV_TABLES", "1")
+    _check_all_phases(oracle, D, oracle.fibonacci_trace(1 << 12))
+
+
 @pytest.mark.parametrize("instance", ["", "small", "deep", "generic"])
 def test_boundary_constraints_by_evaluation(oracle, monkeypatch, instance):
     """The evaluate-and-interpolate route of the two boundary combinations (the reference's own, constraint_table.rs:54-62): its
