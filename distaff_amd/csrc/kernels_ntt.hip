@@ -70,12 +70,12 @@ __device__ __forceinline__ void ntt_block(const NttArgs& a, uint32_t& group, uin
 // consumer of the last butterfly round of the second passes (ntt_lds.h): the results leave for HBM without another pass over LDS
 struct OutB {                                          // natural-order store X[k1 + n1 * k2] from the last round, 1/n of inverse transforms on the way
     static constexpr bool active = true;
-    fe* __restrict__ dst; size_t k_stride; uint32_t log_n2, k1_0; bool scale; fe_tw s;
+    fe* __restrict__ dst /* at the tile's first k1 */; uint32_t k_stride, log_n2; bool scale; fe_tw s;
     struct Tok {};
     __device__ __forceinline__ Tok pre(uint32_t, uint32_t) const { return Tok{}; }
     __device__ __forceinline__ void put(uint32_t row, uint32_t t, const fe& v, const Tok&) const {
         const uint32_t k2 = log_n2 ? (__brev(row) >> (32 - log_n2)) : 0u;
-        dst[(size_t)k2 * k_stride + k1_0 + t] = scale ? fe_mul_tw(v, s) : v;
+        dst[k2 * k_stride + t] = scale ? fe_mul_tw(v, s) : v;            // uniform base + 32-bit lane offset (at most 2^24 points)
     }
 };
 
@@ -87,8 +87,8 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
 // The stage twiddles live in LDS behind the tile as table pairs (32 bytes each), so the stages issue no global loads that would
 // have to wait behind the prefetch.  A 1024-point coset DIT needs 64 KiB of tile + 32 KiB of twiddles: that instance runs as ONE
 // workgroup of 1024 lanes per CU (4 elements per lane); everything that fits 80 KiB runs as two workgroups of 512 lanes (8 per lane).
-template <int THREADS>
-__global__ void __launch_bounds__(THREADS, 4) ntt_pass_a(NttArgs a, const fe* __restrict__ src_base, fe* __restrict__ dst_base) {
+template <int THREADS, int WPE = 4, bool PREFETCH = true>
+__global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* __restrict__ src_base, fe* __restrict__ dst_base) {
     constexpr int EPT = NTT_TILE_ELEMS / THREADS;
     fe* L = reinterpret_cast<fe*>(ntt_smem);
     const uint32_t log_t = a.tile, T = 1u << log_t, n1 = 1u << a.log_n1;
@@ -96,8 +96,8 @@ __global__ void __launch_bounds__(THREADS, 4) ntt_pass_a(NttArgs a, const fe* __
     uint32_t group, jl, col;
     ntt_block(a, group, jl, col);
     const uint32_t jg = a.j0 + jl;
-    const fe* __restrict__ src = src_base + (size_t)col * a.src_col_stride + (size_t)jl * a.src_coset_stride;
-    fe* __restrict__ dst = dst_base + (size_t)col * a.dst_col_stride + (size_t)jl * a.dst_coset_stride;
+    const fe* __restrict__ src0 = src_base + (size_t)col * a.src_col_stride + (size_t)jl * a.src_coset_stride;
+    fe* __restrict__ dst0 = dst_base + (size_t)col * a.dst_col_stride + (size_t)jl * a.dst_coset_stride;
     const uint32_t pmask = (1u << (a.log_b + a.log_n1)) - 1u;
     if (a.dit) {
         // stage twiddles of this coset: g^(n1/B) * w_B^k = w_{B_lde*n1}^((j + B_lde*k) * n1/B) straight from the pre-scale table
@@ -114,54 +114,59 @@ __global__ void __launch_bounds__(THREADS, 4) ntt_pass_a(NttArgs a, const fe* __
     // named registers, not an array: the prefetched elements must stay in VGPRs across the butterfly stages.  Branch-free fetch: a
     // lane past the tile re-reads element 0.
 #define NTT_EACH(M) { M(0, pre0) M(1, pre1) M(2, pre2) M(3, pre3) M(4, pre4) M(5, pre5) M(6, pre6) M(7, pre7) }
-#define NTT_FETCH_A1(e, var) if constexpr ((e) < EPT) { uint32_t idx = threadIdx.x + (e) * THREADS; idx = idx < count ? idx : 0u; var = src[((size_t)(idx >> log_t) << a.log_n2) + f0 + (idx & (T - 1))]; }
-#define NTT_FETCH_A(tile) { const uint32_t f0 = (tile) * T; NTT_EACH(NTT_FETCH_A1) }
+    // uniform base (scalar registers) + 32-bit lane offset: the transform has at most 2^24 points
+#define NTT_FETCH_A1(e, var) if constexpr ((e) < EPT) { uint32_t idx = threadIdx.x + (e) * THREADS; idx = idx < count ? idx : 0u; var = src[((idx >> log_t) << a.log_n2) + (idx & (T - 1))]; }
+#define NTT_FETCH_A(tile) { const fe* __restrict__ src = src0 + (tile) * T; NTT_EACH(NTT_FETCH_A1) }
     const tw4_t* __restrict__ tw4 = a.tw4 + (size_t)jl * a.tw4_coset_stride;
     const uint32_t tile0 = group * a.tiles_per_block;
-    NTT_FETCH_A(tile0)
+    if (PREFETCH) NTT_FETCH_A(tile0)
     for (uint32_t it = 0; it < a.tiles_per_block; it++) {
-        const uint32_t m2_0 = (tile0 + it) * T;
+        const uint32_t tile = tile0 + it;
+        if (!PREFETCH) NTT_FETCH_A(tile)
         __syncthreads();                                   // the previous tile has left LDS (and TW is complete)
         // DISTAFF_NTT_DIF: pre-scale + DIF instead of the coset DIT
 #define NTT_PUT_A(e, var) if constexpr ((e) < EPT) { const uint32_t idx = threadIdx.x + (e) * THREADS; if (idx < count) { if (a.dit) L[lds_slot(__brev(idx >> log_t) >> (32 - a.log_n1), idx & (T - 1), log_t)] = var; else L[lds_slot(idx >> log_t, idx & (T - 1), log_t)] = scaled ? fe_mul_tw(var, a.prescale[(jg * (idx >> log_t)) & pmask]) : var; } }
         NTT_EACH(NTT_PUT_A)
 #undef NTT_PUT_A
         __syncthreads();
-        if (it + 1 < a.tiles_per_block) NTT_FETCH_A(tile0 + it + 1)
+        if (PREFETCH && it + 1 < a.tiles_per_block) NTT_FETCH_A(tile + 1)
         if (a.dit) lds_ntt_dit<THREADS>(L, TW, a.log_n1, log_t, 1u, a.log_n1 + 1u, a.dit_last ? a.dit_last + (size_t)jg * (n1 / 2) : nullptr);
         else lds_ntt_dif<THREADS>(L, TW, a.log_n1, log_t, 1u, a.log_n1 + 1u);
         // read-out in batches of RB elements per lane: the twiddle loads of a batch are in flight together (the 512-lane instance also
         // holds eight prefetched elements: a batch of four would spill).  The second passes store from their last butterfly round instead
         // (OutB); here that costs more than it saves: with the four-step twiddles (and the last-stage pairs from global memory) live in
         // the last round the kernel spills (measured 13.15 / 13.3 against 13.05 ms).
-        constexpr int RB = THREADS == 512 ? 2 : 4;
+        constexpr int RB = WPE > 4 ? 1 : THREADS == 512 ? 2 : 4;
+        fe* __restrict__ dst = dst0 + tile * T;          // uniform bases, 32-bit lane offsets
+        const tw4_t* __restrict__ tw = tw4 + tile * T;
         for (uint32_t base = 0; base < count; base += RB * THREADS) {
-            fe v[RB]; tw4_t w[RB]; uint32_t k1s[RB], m2s[RB]; bool ok[RB];
+            fe v[RB]; tw4_t w[RB]; uint32_t off[RB]; bool ok[RB];
             static_for<0, RB>([&](auto q_) {
                 constexpr int q = decltype(q_)::value;
                 uint32_t idx = base + q * THREADS + threadIdx.x;
                 ok[q] = idx < count;
                 idx = ok[q] ? idx : 0u;
                 const uint32_t t = idx & (T - 1), r = idx >> log_t;
-                k1s[q] = a.dit ? r : __brev(r) >> (32 - a.log_n1);        // DIT leaves the tile in natural order
-                m2s[q] = m2_0 + t;
+                const uint32_t k1 = a.dit ? r : __brev(r) >> (32 - a.log_n1);        // DIT leaves the tile in natural order
+                off[q] = (k1 << a.log_n2) + t;
                 v[q] = L[idx];
-                w[q] = tw4[((size_t)k1s[q] << a.log_n2) + m2s[q]];
+                w[q] = tw[off[q]];
             });
             static_for<0, RB>([&](auto q_) {
                 constexpr int q = decltype(q_)::value;
 #if NTT_TW4_PAIRS
-                if (ok[q]) dst[((size_t)k1s[q] << a.log_n2) + m2s[q]] = (a.debug & 2u) ? v[q] : fe_mul_tw(v[q], w[q]);
+                if (ok[q]) dst[off[q]] = (a.debug & 2u) ? v[q] : fe_mul_tw(v[q], w[q]);
 #else
-                if (ok[q]) dst[((size_t)k1s[q] << a.log_n2) + m2s[q]] = (a.debug & 2u) ? v[q] : fe_mul(v[q], w[q]);
+                if (ok[q]) dst[off[q]] = (a.debug & 2u) ? v[q] : fe_mul(v[q], w[q]);
 #endif
             });
         }
     }
 }
 
-template <int THREADS>
-__global__ void __launch_bounds__(THREADS, 4) ntt_pass_b(NttArgs a, const fe* __restrict__ src_base, fe* __restrict__ dst_base) {
+// WPE: waves per SIMD the instance is compiled for (its register budget); PREFETCH: the next tile travels in registers during the rounds
+template <int THREADS, int WPE = 4, bool PREFETCH = true>
+__global__ void __launch_bounds__(THREADS, WPE) ntt_pass_b(NttArgs a, const fe* __restrict__ src_base, fe* __restrict__ dst_base) {
     constexpr int EPT = NTT_TILE_ELEMS / THREADS;
     fe* L = reinterpret_cast<fe*>(ntt_smem);
     const uint32_t log_t = a.tile, T = 1u << log_t, n2 = 1u << a.log_n2;
@@ -175,19 +180,21 @@ __global__ void __launch_bounds__(THREADS, 4) ntt_pass_b(NttArgs a, const fe* __
     fe pre0 = fe_zero(), pre1 = fe_zero(), pre2 = fe_zero(), pre3 = fe_zero(), pre4 = fe_zero(), pre5 = fe_zero(), pre6 = fe_zero(), pre7 = fe_zero();
     const uint32_t count = n2 * T;
     // contiguous along m2
-#define NTT_FETCH_B1(e, var) if constexpr ((e) < EPT) { uint32_t idx = threadIdx.x + (e) * THREADS; idx = idx < count ? idx : 0u; var = src[(size_t)(f0 + (idx >> a.log_n2)) * a.src_row_stride + (idx & (n2 - 1))]; }
-#define NTT_FETCH_B(tile) { const uint32_t f0 = (tile) * T; NTT_EACH(NTT_FETCH_B1) }
+#define NTT_FETCH_B1(e, var) if constexpr ((e) < EPT) { uint32_t idx = threadIdx.x + (e) * THREADS; idx = idx < count ? idx : 0u; var = srct[(idx >> a.log_n2) * row_stride + (idx & (n2 - 1))]; }
+#define NTT_FETCH_B(tile) { const fe* __restrict__ srct = src + (size_t)((tile) * T) * a.src_row_stride; NTT_EACH(NTT_FETCH_B1) }
+    const uint32_t row_stride = (uint32_t)a.src_row_stride;
     const uint32_t tile0 = group * a.tiles_per_block;
-    NTT_FETCH_B(tile0)
+    if (PREFETCH) NTT_FETCH_B(tile0)
     for (uint32_t it = 0; it < a.tiles_per_block; it++) {
         const uint32_t k1_0 = (tile0 + it) * T;
+        if (!PREFETCH) NTT_FETCH_B(tile0 + it)
         __syncthreads();
 #define NTT_PUT_B(e, var) if constexpr ((e) < EPT) { const uint32_t idx = threadIdx.x + (e) * THREADS; if (idx < count) L[lds_slot(idx & (n2 - 1), idx >> a.log_n2, log_t)] = var; }
         NTT_EACH(NTT_PUT_B)
 #undef NTT_PUT_B
         __syncthreads();
-        if (it + 1 < a.tiles_per_block) NTT_FETCH_B(tile0 + it + 1)
-        const OutB out{dst, a.dst_k_stride, a.log_n2, k1_0, a.has_scale != 0, a.scale};
+        if (PREFETCH && it + 1 < a.tiles_per_block) NTT_FETCH_B(tile0 + it + 1)
+        const OutB out{dst + k1_0, (uint32_t)a.dst_k_stride, a.log_n2, a.has_scale != 0, a.scale};
         lds_ntt_dif<THREADS, OutB>(L, TW, a.log_n2, log_t, 1u, a.log_n2 + 1u, out);
     }
 }
@@ -418,16 +425,20 @@ static void ntt_raise_lds_limit(dst_ctx* c) {                  // tile + stage t
     (void)hipFuncSetAttribute((const void*)ntt_pass_a<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ntt_pass_b<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ntt_pass_b<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ntt_pass_a<1024, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ntt_pass_b<1024, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+
     raised[c->device] = true;
 }
 // DISTAFF_NTT_DEBUG=1 prints, once per distinct launch shape, how many workgroups of the instance are resident per CU
-static void ntt_report_occupancy(const char* name, bool pass_b, int threads, size_t lds) {
+static void ntt_report_occupancy(const char* name, bool pass_b, int threads, bool eight, size_t lds) {
     static std::map<std::string, bool> seen;
-    char key[128]; snprintf(key, sizeof key, "%s/%d/%zu", name, threads, lds);
+    char key[128]; snprintf(key, sizeof key, "%s/%d/%d/%zu", name, threads, (int)eight, lds);
     if (seen[key]) return; seen[key] = true;
     int nb = -1;
     hipError_t e;
-    if (threads == 512) e = pass_b ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ntt_pass_b<512>, 512, lds) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ntt_pass_a<512>, 512, lds);
+    if (eight) e = pass_b ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ntt_pass_b<1024, 8, false>, 1024, lds) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ntt_pass_a<1024, 8, false>, 1024, lds);
+    else if (threads == 512) e = pass_b ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ntt_pass_b<512>, 512, lds) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ntt_pass_a<512>, 512, lds);
     else e = pass_b ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ntt_pass_b<1024>, 1024, lds) : hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, ntt_pass_a<1024>, 1024, lds);
     fprintf(stderr, "[distaff] %s: %d lanes, %zu B LDS -> %d workgroups per CU (%s)\n", name, threads, lds, nb, hipGetErrorString(e));
 }
@@ -437,7 +448,6 @@ static void ntt_launch(dst_ctx* c, bool pass_b, NttArgs& a, size_t groups, size_
     ntt_raise_lds_limit(c);
     a.groups = (uint32_t)groups; a.cosets = (uint32_t)cosets; a.cols = (uint32_t)cols;
     const dim3 grid((unsigned)(groups * cosets * cols));
-    if (a.debug & 1u) ntt_report_occupancy(name, pass_b, lds <= NTT_LDS_TWO_PER_CU ? 512 : 1024, lds);
     // multiply-adds of the launch: 18 per table-pair multiplication (fe_mul_tw); multiplications per element: every DIT stage 1/2, DIF
     // two-stage rounds 1 each except the last (1/4: the distance-1 stage has no twiddles), plus four-step twiddle / pre-scale / 1/n
     const uint32_t stages = pass_b ? a.log_n2 : a.log_n1;
@@ -445,8 +455,16 @@ static void ntt_launch(dst_ctx* c, bool pass_b, NttArgs& a, size_t groups, size_
     if (!pass_b) mults += ((!a.dit && a.prescale != nullptr) ? 1.0 : 0.0) + (NTT_TW4_PAIRS ? 1.0 : 21.0 / 18.0); else if (a.has_scale) mults += 1.0;     // the four-step product: 18 or 21 mads
     const double elements = (double)groups * a.tiles_per_block * ((size_t)1 << a.tile) * ((size_t)1 << stages) * cosets * cols;
     KScope ks_(c, name, bytes, true, 18.0 * mults * elements);
-    if (lds <= NTT_LDS_TWO_PER_CU) {
-        if (pass_b) hipLaunchKernelGGL(ntt_pass_b<512>, grid, dim3(512), lds, c->stream, a, a.src, a.dst);
+    const char* wv = getenv("DISTAFF_NTT_WAVES");
+    const bool two = lds <= NTT_LDS_TWO_PER_CU, eight = two && (wv ? wv[0] == '8' : stages >= 10);
+    if (a.debug & 1u) ntt_report_occupancy(name, pass_b, eight || !two ? 1024 : 512, eight, lds);
+    if (two) {
+        // 1024-point tiles (five LDS rounds per tile): two workgroups of 1024 lanes = 8 waves per SIMD, 64 registers, no register prefetch -- the
+        // other workgroup's rounds cover a workgroup's loads (measured 20.2 against 20.55 ms of extension per 2^20 proof, same box); shorter
+        // tiles stay with 512 lanes + prefetch (2^16: 0.96 against 1.03 ms).  DISTAFF_NTT_WAVES=4|8 forces one (the tests run both).
+        if (pass_b && eight) hipLaunchKernelGGL((ntt_pass_b<1024, 8, false>), grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
+        else if (pass_b) hipLaunchKernelGGL(ntt_pass_b<512>, grid, dim3(512), lds, c->stream, a, a.src, a.dst);
+        else if (eight) hipLaunchKernelGGL((ntt_pass_a<1024, 8, false>), grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
         else hipLaunchKernelGGL(ntt_pass_a<512>, grid, dim3(512), lds, c->stream, a, a.src, a.dst);
     } else {
         if (pass_b) hipLaunchKernelGGL(ntt_pass_b<1024>, grid, dim3(1024), lds, c->stream, a, a.src, a.dst);

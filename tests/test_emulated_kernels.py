@@ -46,6 +46,7 @@ SELECTION = [
     "test_lde_every_tile_length[reg-13-5]",
     "test_lde_every_tile_length[lds-13-5]",
     "test_lde_every_tile_length[dit2-13-5]",
+    "test_lde_every_tile_length[waves8-13-5]",
 ]
 
 
