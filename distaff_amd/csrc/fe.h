@@ -76,11 +76,18 @@ FE_HD uint32_t fe_selm1(fe_cf m) { return m ? 0xFFFFFFFFu : 0u; }
 #define FE_PAIR(lo, hi) ((uint64_t)(lo) | ((uint64_t)(hi) << 32))
 FE_HD uint32_t fe_mad24(uint32_t a, uint32_t b, uint32_t c) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu) + c; }      // operands below 2^24: v_mad_u32_u24
 
-// canonical addition: s = a + b, z = s - p (= s + C128 mod 2^128); z is the answer when either addition carries
+// canonical addition: s = a + b, z = s - p (= s + C128 mod 2^128); z is the answer when either addition carries.  The trial subtraction
+// runs one link behind the addition (statement order = issue order, see fe_mul_tw).
 FE_HD fe fe_add(const fe& a, const fe& b) {
     fe_cf c, d;
-    uint32_t s0 = fe_add_co(a.v[0], b.v[0], c), s1 = fe_addc_co(a.v[1], b.v[1], c, c), s2 = fe_addc_co(a.v[2], b.v[2], c, c), s3 = fe_addc_co(a.v[3], b.v[3], c, c);
-    uint32_t z0 = fe_addm1_co(s0, d), z1 = fe_addc_co(s1, FE_C1, d, d), z2 = fe_addc0_co(s2, d, d), z3 = fe_addc0_co(s3, d, d);
+    uint32_t s0 = fe_add_co(a.v[0], b.v[0], c);
+    uint32_t s1 = fe_addc_co(a.v[1], b.v[1], c, c);
+    uint32_t z0 = fe_addm1_co(s0, d);
+    uint32_t s2 = fe_addc_co(a.v[2], b.v[2], c, c);
+    uint32_t z1 = fe_addc_co(s1, FE_C1, d, d);
+    uint32_t s3 = fe_addc_co(a.v[3], b.v[3], c, c);
+    uint32_t z2 = fe_addc0_co(s2, d, d);
+    uint32_t z3 = fe_addc0_co(s3, d, d);
     fe_cf s = c | d;
     return fe_make(fe_sel(s, z0, s0), fe_sel(s, z1, s1), fe_sel(s, z2, s2), fe_sel(s, z3, s3));
 }
@@ -91,6 +98,33 @@ FE_HD fe fe_sub(const fe& a, const fe& b) {
     uint32_t k0 = fe_selm1(c), k1 = fe_sel0(c, FE_C1);
     uint32_t e0 = fe_sub_co(d0, k0, d), e1 = fe_subb_co(d1, k1, d, d), e2 = fe_subb0_co(d2, d, d), e3 = fe_subb0_co(d3, d, d);
     return fe_make(e0, e1, e2, e3);
+}
+// sum and difference of one pair (every butterfly): the four carry chains alternate, so none of them waits on its own previous link
+FE_HD void fe_addsub(const fe& a, const fe& b, fe& sum, fe& dif) {
+    fe_cf c, d, g, h;
+    uint32_t s0 = fe_add_co(a.v[0], b.v[0], c);
+    uint32_t d0 = fe_sub_co(a.v[0], b.v[0], g);
+    uint32_t s1 = fe_addc_co(a.v[1], b.v[1], c, c);
+    uint32_t d1 = fe_subb_co(a.v[1], b.v[1], g, g);
+    uint32_t z0 = fe_addm1_co(s0, d);
+    uint32_t s2 = fe_addc_co(a.v[2], b.v[2], c, c);
+    uint32_t d2 = fe_subb_co(a.v[2], b.v[2], g, g);
+    uint32_t z1 = fe_addc_co(s1, FE_C1, d, d);
+    uint32_t s3 = fe_addc_co(a.v[3], b.v[3], c, c);
+    uint32_t d3 = fe_subb_co(a.v[3], b.v[3], g, g);
+    uint32_t z2 = fe_addc0_co(s2, d, d);
+    uint32_t k0 = fe_selm1(g), k1 = fe_sel0(g, FE_C1);
+    uint32_t z3 = fe_addc0_co(s3, d, d);
+    uint32_t e0 = fe_sub_co(d0, k0, h);
+    fe_cf s = c | d;
+    uint32_t r0 = fe_sel(s, z0, s0);
+    uint32_t e1 = fe_subb_co(d1, k1, h, h);
+    uint32_t r1 = fe_sel(s, z1, s1);
+    uint32_t e2 = fe_subb0_co(d2, h, h);
+    uint32_t r2 = fe_sel(s, z2, s2);
+    uint32_t e3 = fe_subb0_co(d3, h, h);
+    sum = fe_make(r0, r1, r2, fe_sel(s, z3, s3));
+    dif = fe_make(e0, e1, e2, e3);
 }
 
 FE_HD fe fe_neg(const fe& a) { return fe_sub(fe_zero(), a); }
@@ -175,66 +209,95 @@ FE_HD fe fe_mul_portable(const fe& a, const fe& b) {
 // with 2^128 = K * 2^32 - 1 (mod p), K = 45 * 2^8, and the last conditional subtraction of p selects with a mask formed on the
 // scalar unit.  VALU instructions: general multiplication 71 (21 of them multiplies), multiplication by a table entry (fe_tw) 55 (18).
 
-// y = r + y4 * 2^128 (y4 a flag) with y < 2p  ->  canonical representative
-FE_HD fe fe_final(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, fe_cf y4) {
-    fe_cf c;
-    uint32_t z0 = fe_addm1_co(r0, c), z1 = fe_addc_co(r1, FE_C1, c, c), z2 = fe_addc0_co(r2, c, c), z3 = fe_addc0_co(r3, c, c);
-    fe_cf s = y4 | c;
-    return fe_make(fe_sel(s, z0, r0), fe_sel(s, z1, r1), fe_sel(s, z2, r2), fe_sel(s, z3, r3));
-}
-
-// reduction of the nine-limb value t0..t8 (t8 < 2^7; the product of two 128-bit values, or a sum of up to 64 of them)
+// reduction of the nine-limb value t0..t8 (t8 < 2^7; the product of two 128-bit values, or a sum of up to 64 of them).  Statement order
+// = issue order (see fe_mul_tw): the two add chains of fold 1 and its subtract chain run one link apart, likewise fold 2 and the trial
+// subtraction of p.
 FE_HD fe fe_fold9(uint32_t t0, uint32_t t1, uint32_t t2, uint32_t t3, uint32_t t4, uint32_t t5, uint32_t t6, uint32_t t7, uint32_t t8, bool has_t8) {
-    fe_cf c, b;
+    fe_cf c, e, b, d;
     // fold 1: v = lo + ((hi * K) << 32) - hi
     uint64_t P0 = (uint64_t)t4 * FE_K, P1 = (uint64_t)t5 * FE_K, P2 = (uint64_t)t6 * FE_K, P3 = (uint64_t)t7 * FE_K;
     uint32_t u1 = fe_add_co(t1, FE_LO(P0), c);
-    uint32_t u2 = fe_addc_co(t2, FE_LO(P1), c, c);
-    uint32_t u3 = fe_addc_co(t3, FE_LO(P2), c, c);
-    uint32_t u4 = fe_addc0_co(FE_LO(P3), c, c);
-    uint32_t u5 = fe_cnt(has_t8 ? fe_mad24(t8, FE_K, FE_HI(P3)) : FE_HI(P3), c);      // t8 * K < 2^21
-    u2 = fe_add_co(u2, FE_HI(P0), c);
-    u3 = fe_addc_co(u3, FE_HI(P1), c, c);
-    u4 = fe_addc_co(u4, FE_HI(P2), c, c);
-    u5 = fe_cnt(u5, c);
     uint32_t v0 = fe_sub_co(t0, t4, b);
+    uint32_t u2 = fe_addc_co(t2, FE_LO(P1), c, c);
     uint32_t v1 = fe_subb_co(u1, t5, b, b);
+    uint32_t h5 = has_t8 ? fe_mad24(t8, FE_K, FE_HI(P3)) : FE_HI(P3);               // t8 * K < 2^21
+    uint32_t u3 = fe_addc_co(t3, FE_LO(P2), c, c);
+    u2 = fe_add_co(u2, FE_HI(P0), e);
+    uint32_t u4 = fe_addc0_co(FE_LO(P3), c, c);
+    u3 = fe_addc_co(u3, FE_HI(P1), e, e);
     uint32_t v2 = fe_subb_co(u2, t6, b, b);
+    uint32_t u5 = fe_cnt(h5, c);
+    u4 = fe_addc_co(u4, FE_HI(P2), e, e);
     uint32_t v3 = fe_subb_co(u3, t7, b, b);
+    u5 = fe_cnt(u5, e);
     uint32_t v4 = has_t8 ? fe_subb_co(u4, t8, b, b) : fe_subb0_co(u4, b, b);
-    uint32_t v5 = fe_subb0_co(u5, b, b);
     // fold 2: y = v_lo + ((V * K) << 32) - V, V = v5:v4 (< 2^46, < 2^54 with t8)
     uint64_t w = (uint64_t)v4 * FE_K;
+    uint32_t v5 = fe_subb0_co(u5, b, b);
+    uint32_t y0 = fe_sub_co(v0, v4, d);
     uint32_t y1 = fe_add_co(v1, FE_LO(w), c), y2, y3;
-    if (has_t8) { uint64_t x = (uint64_t)v5 * FE_K + FE_HI(w); y2 = fe_addc_co(v2, FE_LO(x), c, c); y3 = fe_addc_co(v3, FE_HI(x), c, c); }
-    else { y2 = fe_addc_co(v2, fe_mad24(v5, FE_K, FE_HI(w)), c, c); y3 = fe_addc0_co(v3, c, c); }
-    uint32_t y0 = fe_sub_co(v0, v4, b);
-    y1 = fe_subb_co(y1, v5, b, b);
-    y2 = fe_subb0_co(y2, b, b);
-    y3 = fe_subb0_co(y3, b, b);
-    return fe_final(y0, y1, y2, y3, c & ~b);        // the value is non-negative: a borrow only ever cancels a carry
+    if (has_t8) {
+        uint64_t x = (uint64_t)v5 * FE_K + FE_HI(w);
+        y2 = fe_addc_co(v2, FE_LO(x), c, c);
+        y1 = fe_subb_co(y1, v5, d, d);
+        y3 = fe_addc_co(v3, FE_HI(x), c, c);
+    } else {
+        uint32_t m = fe_mad24(v5, FE_K, FE_HI(w));
+        y2 = fe_addc_co(v2, m, c, c);
+        y1 = fe_subb_co(y1, v5, d, d);
+        y3 = fe_addc0_co(v3, c, c);
+    }
+    uint32_t z0 = fe_addm1_co(y0, e);
+    y2 = fe_subb0_co(y2, d, d);
+    uint32_t z1 = fe_addc_co(y1, FE_C1, e, e);
+    y3 = fe_subb0_co(y3, d, d);
+    uint32_t z2 = fe_addc0_co(y2, e, e);
+    fe_cf y4 = c & ~d;                               // the value is non-negative: a borrow only ever cancels a carry
+    uint32_t z3 = fe_addc0_co(y3, e, e);
+    fe_cf s = y4 | e;                                // y = r + y4 * 2^128 < 2p: subtract p when bit 128 is set or the trial subtraction did not borrow
+    return fe_make(fe_sel(s, z0, y0), fe_sel(s, z1, y1), fe_sel(s, z2, y2), fe_sel(s, z3, y3));
 }
 
-// general multiplication; the operands may be ANY 128-bit values (not only canonical ones)
+// general multiplication; the operands may be ANY 128-bit values (not only canonical ones).  Statement order = issue order (see fe_mul_tw).
 FE_HD fe fe_mul_wide(const fe& a, const fe& b) {
     const uint32_t a0 = a.v[0], a1 = a.v[1], a2 = a.v[2], a3 = a.v[3], b0 = b.v[0], b1 = b.v[1], b2 = b.v[2], b3 = b.v[3];
-    fe_cf c;
+    fe_cf k0, k1, k2, c;
     uint64_t E0 = (uint64_t)a0 * b0;
-    uint64_t O0 = (uint64_t)a0 * b1; O0 = fe_madc(a1, b0, O0, c); uint32_t co0 = fe_cnt0(c);
-    uint64_t E1 = (uint64_t)a0 * b2; E1 = fe_madc(a1, b1, E1, c); uint32_t ce1 = fe_cnt0(c); E1 = fe_madc(a2, b0, E1, c); ce1 = fe_cnt(ce1, c);
-    uint64_t O1 = fe_madc(a0, b3, FE_PAIR(co0, ce1), c); uint32_t co1 = fe_cnt0(c);
-    O1 = fe_madc(a1, b2, O1, c); co1 = fe_cnt(co1, c); O1 = fe_madc(a2, b1, O1, c); co1 = fe_cnt(co1, c); O1 = fe_madc(a3, b0, O1, c); co1 = fe_cnt(co1, c);
-    uint64_t E2 = (uint64_t)a1 * b3; E2 = fe_madc(a2, b2, E2, c); uint32_t ce2 = fe_cnt0(c); E2 = fe_madc(a3, b1, E2, c); ce2 = fe_cnt(ce2, c);
-    uint64_t O2 = fe_madc(a2, b3, FE_PAIR(co1, ce2), c); uint32_t co2 = fe_cnt0(c); O2 = fe_madc(a3, b2, O2, c); co2 = fe_cnt(co2, c);
+    uint64_t O0 = (uint64_t)a0 * b1;
+    uint64_t E1 = (uint64_t)a0 * b2;
+    uint64_t E2 = (uint64_t)a1 * b3;
     uint64_t E3 = (uint64_t)a3 * b3;
+    O0 = fe_madc(a1, b0, O0, k0);
+    E1 = fe_madc(a1, b1, E1, k1);
+    E2 = fe_madc(a2, b2, E2, k2);
+    uint32_t co0 = fe_cnt0(k0);
+    E1 = fe_madc(a2, b0, E1, k0);
+    uint32_t ce1 = fe_cnt0(k1);
+    E2 = fe_madc(a3, b1, E2, k1);
+    uint32_t ce2 = fe_cnt0(k2);
     uint32_t t0 = FE_LO(E0);
-    uint32_t t1 = fe_add_co(FE_HI(E0), FE_LO(O0), c);
+    uint32_t t1 = fe_add_co(FE_HI(E0), FE_LO(O0), c);            // the merge chain starts while the upper windows still accumulate
+    ce1 = fe_cnt(ce1, k0);
+    ce2 = fe_cnt(ce2, k1);
+    uint64_t O1 = fe_madc(a0, b3, FE_PAIR(co0, ce1), k2);
     uint32_t t2 = fe_addc_co(FE_LO(E1), FE_HI(O0), c, c);
+    O1 = fe_madc(a1, b2, O1, k0);
+    uint32_t co1 = fe_cnt0(k2);
+    O1 = fe_madc(a2, b1, O1, k1);
+    co1 = fe_cnt(co1, k0);
+    O1 = fe_madc(a3, b0, O1, k2);
+    co1 = fe_cnt(co1, k1);
     uint32_t t3 = fe_addc_co(FE_HI(E1), FE_LO(O1), c, c);
+    co1 = fe_cnt(co1, k2);
+    uint64_t O2 = fe_madc(a2, b3, FE_PAIR(co1, ce2), k0);
     uint32_t t4 = fe_addc_co(FE_LO(E2), FE_HI(O1), c, c);
+    O2 = fe_madc(a3, b2, O2, k1);
+    uint32_t co2 = fe_cnt0(k0);
     uint32_t t5 = fe_addc_co(FE_HI(E2), FE_LO(O2), c, c);
+    co2 = fe_cnt(co2, k1);
     uint32_t t6 = fe_addc_co(FE_LO(E3), FE_HI(O2), c, c);
-    uint32_t t7 = fe_cnt(FE_HI(E3) + co2, c);
+    uint32_t h7 = FE_HI(E3) + co2;
+    uint32_t t7 = fe_cnt(h7, c);
     return fe_fold9(t0, t1, t2, t3, t4, t5, t6, t7, 0u, false);
 }
 
@@ -242,44 +305,69 @@ FE_HD fe fe_mul_wide(const fe& a, const fe& b) {
 // A twiddle w is stored as the pair (P, Q) = (w, w * 2^64 mod p).  Then  a * w = (a0 + a1 X) * P + (a2 + a3 X) * Q  (X = 2^32) is a sum
 // below 2^193 for ANY 128-bit a: five product columns in windows W0..W4, one merge chain, ONE fold of the 65 bits above 2^128.
 struct __attribute__((aligned(16))) fe_tw { fe p, q; };
+// Statement order = issue order wanted on gfx950: an instruction that reads a carry mask (SGPR pair) needs one other instruction between
+// itself and the instruction that wrote the mask, or the compiler pads with s_nop.  The windows are independent until their counters
+// meet, so the multiply-adds of different windows alternate and every counter update trails its multiply-add by one or two statements;
+// in the tail the add chain, the subtract chain and the trial subtraction of p run one link apart.
 FE_HD fe fe_mul_tw(const fe& a, const fe& P, const fe& Q) {
     const uint32_t a0 = a.v[0], a1 = a.v[1], a2 = a.v[2], a3 = a.v[3];
-    fe_cf c, b;
+    fe_cf k0, k1, k2, c, b, d;
     uint64_t W0 = (uint64_t)a0 * P.v[0];
-    W0 = fe_madc(a2, Q.v[0], W0, c); uint32_t c0 = fe_cnt0(c);
     uint64_t W1 = (uint64_t)a0 * P.v[1];
-    W1 = fe_madc(a1, P.v[0], W1, c); uint32_t c1 = fe_cnt0(c);
-    W1 = fe_madc(a2, Q.v[1], W1, c); c1 = fe_cnt(c1, c);
-    W1 = fe_madc(a3, Q.v[0], W1, c); c1 = fe_cnt(c1, c);
-    uint64_t W2 = fe_madc(a0, P.v[2], FE_PAIR(c0, c1), c); uint32_t c2 = fe_cnt0(c);
-    W2 = fe_madc(a1, P.v[1], W2, c); c2 = fe_cnt(c2, c);
-    W2 = fe_madc(a2, Q.v[2], W2, c); c2 = fe_cnt(c2, c);
-    W2 = fe_madc(a3, Q.v[1], W2, c); c2 = fe_cnt(c2, c);
     uint64_t W3 = (uint64_t)a0 * P.v[3];
-    W3 = fe_madc(a1, P.v[2], W3, c); uint32_t c3 = fe_cnt0(c);
-    W3 = fe_madc(a2, Q.v[3], W3, c); c3 = fe_cnt(c3, c);
-    W3 = fe_madc(a3, Q.v[2], W3, c); c3 = fe_cnt(c3, c);
-    uint64_t W4 = fe_madc(a1, P.v[3], FE_PAIR(c2, c3), c); uint32_t c4 = fe_cnt0(c);
-    W4 = fe_madc(a3, Q.v[3], W4, c); c4 = fe_cnt(c4, c);
+    W0 = fe_madc(a2, Q.v[0], W0, k0);
+    W1 = fe_madc(a1, P.v[0], W1, k1);
+    W3 = fe_madc(a1, P.v[2], W3, k2);
+    uint32_t c0 = fe_cnt0(k0);
+    W1 = fe_madc(a2, Q.v[1], W1, k0);
+    uint32_t c1 = fe_cnt0(k1);
+    W3 = fe_madc(a2, Q.v[3], W3, k1);
+    uint32_t c3 = fe_cnt0(k2);
+    W1 = fe_madc(a3, Q.v[0], W1, k2);
+    c1 = fe_cnt(c1, k0);
+    W3 = fe_madc(a3, Q.v[2], W3, k0);
+    c3 = fe_cnt(c3, k1);
+    c1 = fe_cnt(c1, k2);
     uint32_t T0 = FE_LO(W0);
-    uint32_t T1 = fe_add_co(FE_HI(W0), FE_LO(W1), c);
+    uint32_t T1 = fe_add_co(FE_HI(W0), FE_LO(W1), c);            // the merge chain starts while the upper windows still accumulate
+    c3 = fe_cnt(c3, k0);
+    uint64_t W2 = fe_madc(a0, P.v[2], FE_PAIR(c0, c1), k1);
+    W2 = fe_madc(a1, P.v[1], W2, k2);
+    uint32_t c2 = fe_cnt0(k1);
+    W2 = fe_madc(a2, Q.v[2], W2, k0);
+    c2 = fe_cnt(c2, k2);
+    W2 = fe_madc(a3, Q.v[1], W2, k1);
+    c2 = fe_cnt(c2, k0);
     uint32_t T2 = fe_addc_co(FE_HI(W1), FE_LO(W2), c, c);
+    c2 = fe_cnt(c2, k1);
+    uint64_t W4 = fe_madc(a1, P.v[3], FE_PAIR(c2, c3), k2);
     uint32_t T3 = fe_addc_co(FE_HI(W2), FE_LO(W3), c, c);
+    W4 = fe_madc(a3, Q.v[3], W4, k0);
+    uint32_t c4 = fe_cnt0(k2);
     uint32_t T4 = fe_addc_co(FE_HI(W3), FE_LO(W4), c, c);
-    uint32_t T5 = fe_addc0_co(FE_HI(W4), c, c);
-    uint32_t T6 = fe_cnt(c4, c);                              // 0 or 1: the sum is below 2^193
+    c4 = fe_cnt(c4, k0);
     // fold H = T6:T5:T4 (< 2^65): r = L + ((H * K) << 32) - H
-    uint64_t P4 = (uint64_t)T4 * FE_K, P5 = (uint64_t)T5 * FE_K;
-    uint32_t X1 = fe_add_co(FE_HI(P4), FE_LO(P5), c);
-    uint32_t X2 = fe_cnt(fe_mad24(T6, FE_K, FE_HI(P5)), c);
-    uint32_t u1 = fe_add_co(T1, FE_LO(P4), c);
-    uint32_t u2 = fe_addc_co(T2, X1, c, c);
-    uint32_t u3 = fe_addc_co(T3, X2, c, c);
+    uint64_t P4 = (uint64_t)T4 * FE_K;
+    uint32_t T5 = fe_addc0_co(FE_HI(W4), c, c);
     uint32_t r0 = fe_sub_co(T0, T4, b);
+    uint64_t P5 = (uint64_t)T5 * FE_K;
+    uint32_t T6 = fe_cnt(c4, c);                              // 0 or 1: the sum is below 2^193
+    uint32_t u1 = fe_add_co(T1, FE_LO(P4), c);
+    uint32_t X1 = fe_add_co(FE_HI(P4), FE_LO(P5), d);
+    uint32_t x2 = fe_mad24(T6, FE_K, FE_HI(P5));
     uint32_t r1 = fe_subb_co(u1, T5, b, b);
+    uint32_t X2 = fe_cnt(x2, d);
+    uint32_t u2 = fe_addc_co(T2, X1, c, c);
+    uint32_t z0 = fe_addm1_co(r0, d);
     uint32_t r2 = fe_subb_co(u2, T6, b, b);
+    uint32_t u3 = fe_addc_co(T3, X2, c, c);
+    uint32_t z1 = fe_addc_co(r1, FE_C1, d, d);
     uint32_t r3 = fe_subb0_co(u3, b, b);
-    return fe_final(r0, r1, r2, r3, c & ~b);                 // the value is below 2^128 + 2^111 < 2p
+    uint32_t z2 = fe_addc0_co(r2, d, d);
+    fe_cf y4 = c & ~b;                                        // the value is below 2^128 + 2^111 < 2p and non-negative: a borrow only cancels a carry
+    uint32_t z3 = fe_addc0_co(r3, d, d);
+    fe_cf s = y4 | d;
+    return fe_make(fe_sel(s, z0, r0), fe_sel(s, z1, r1), fe_sel(s, z2, r2), fe_sel(s, z3, r3));
 }
 FE_HD fe fe_mul_tw(const fe& a, const fe_tw& w) { return fe_mul_tw(a, w.p, w.q); }
 // Q = w * 2^64 mod p (table construction; also on the fly where one multiplier serves several products)

@@ -63,13 +63,15 @@ __device__ __forceinline__ void lds_ntt_dif(fe* L, const fe_tw* W, uint32_t log_
             fe* p0 = L + lds_slot(i0, t, log_t); fe* p1 = L + lds_slot(i0 + hd, t, log_t); fe* p2 = L + lds_slot(i0 + d, t, log_t); fe* p3 = L + lds_slot(i0 + d + hd, t, log_t);
             const fe x0 = *p0, x1 = *p1, x2 = *p2, x3 = *p3;
             // stage s: (x0, x2) with w_2d^pos, (x1, x3) with w_2d^(pos + d/2)
-            fe a0 = fe_add(x0, x2), a2 = fe_sub(x0, x2);
-            fe a1 = fe_add(x1, x3), a3 = fe_sub(x1, x3);
+            fe a0, a1, a2, a3;
+            fe_addsub(x0, x2, a0, a2);
+            fe_addsub(x1, x3, a1, a3);
             if (hd != 1) a2 = fe_mul_tw(a2, W[dif_tw_slot(pos << (s - 1))]);          // hd == 1: pos == 0 in every lane
             a3 = fe_mul_tw(a3, W[dif_tw_slot((pos + hd) << (s - 1))]);
             // stage s + 1: (a0, a1) and (a2, a3) with w_d^pos
-            fe y0 = fe_add(a0, a1), y1 = fe_sub(a0, a1);
-            fe y2 = fe_add(a2, a3), y3 = fe_sub(a2, a3);
+            fe y0, y1, y2, y3;
+            fe_addsub(a0, a1, y0, y1);
+            fe_addsub(a2, a3, y2, y3);
             if (!last && hd != 1) { const fe_tw tw = W[dif_tw_slot(pos << s)]; y1 = fe_mul_tw(y1, tw); y3 = fe_mul_tw(y3, tw); }
             if (fin) { out.put(i0, t, y0, k0); out.put(i0 + hd, t, y1, k1); out.put(i0 + d, t, y2, k2); out.put(i0 + d + hd, t, y3, k3); }
             else { *p0 = y0; *p1 = y1; *p2 = y2; *p3 = y3; }
@@ -83,8 +85,10 @@ __device__ __forceinline__ void lds_ntt_dif(fe* L, const fe_tw* W, uint32_t log_
             if (Out::active) { k0 = out.pre(q << 1, t); k1 = out.pre((q << 1) + 1, t); }
             fe* p0 = L + lds_slot(q << 1, t, log_t); fe* p1 = L + lds_slot((q << 1) + 1, t, log_t);
             const fe a = *p0, b = *p1;
-            if (Out::active) { out.put(q << 1, t, fe_add(a, b), k0); out.put((q << 1) + 1, t, fe_sub(a, b), k1); }
-            else { *p0 = fe_add(a, b); *p1 = fe_sub(a, b); }
+            fe sum, dif;
+            fe_addsub(a, b, sum, dif);
+            if (Out::active) { out.put(q << 1, t, sum, k0); out.put((q << 1) + 1, t, dif, k1); }
+            else { *p0 = sum; *p1 = dif; }
         }
         if (!Out::active) __syncthreads();
     }
@@ -112,17 +116,17 @@ __device__ __forceinline__ void lds_ntt_dit(fe* L, const fe_tw* W, uint32_t log_
             fe* p0 = L + lds_slot(base + k, t, log_t); fe* p1 = L + lds_slot(base + k + half, t, log_t); fe* p2 = L + lds_slot(base + k + B, t, log_t); fe* p3 = L + lds_slot(base + k + B + half, t, log_t);
             const fe_tw tb = W[half - 1 + k];
             const fe x0 = *p0, x1 = fe_mul_tw(*p1, tb), x2 = *p2, x3 = fe_mul_tw(*p3, tb);
-            const fe a0 = fe_add(x0, x1), a1 = fe_sub(x0, x1);
+            fe a0, a1, b2, b3;
+            fe_addsub(x0, x1, a0, a1);
+            fe_addsub(x2, x3, b2, b3);
             const bool from_global = Wlast != nullptr && s + 1 == log_len;        // the second stage of this round is the last stage
             const fe_tw t2 = from_global ? Wlast[k] : W[B - 1 + k], t3 = from_global ? Wlast[k + half] : W[B - 1 + k + half];
-            const fe a2 = fe_mul_tw(fe_add(x2, x3), t2), a3 = fe_mul_tw(fe_sub(x2, x3), t3);
-            if (fin) {
-                out.put(base + k, t, fe_add(a0, a2), k0); out.put(base + k + B, t, fe_sub(a0, a2), k2);
-                out.put(base + k + half, t, fe_add(a1, a3), k1); out.put(base + k + B + half, t, fe_sub(a1, a3), k3);
-            } else {
-                *p0 = fe_add(a0, a2); *p2 = fe_sub(a0, a2);
-                *p1 = fe_add(a1, a3); *p3 = fe_sub(a1, a3);
-            }
+            const fe a2 = fe_mul_tw(b2, t2), a3 = fe_mul_tw(b3, t3);
+            fe y0, y1, y2, y3;
+            fe_addsub(a0, a2, y0, y2);
+            fe_addsub(a1, a3, y1, y3);
+            if (fin) { out.put(base + k, t, y0, k0); out.put(base + k + B, t, y2, k2); out.put(base + k + half, t, y1, k1); out.put(base + k + B + half, t, y3, k3); }
+            else { *p0 = y0; *p2 = y2; *p1 = y1; *p3 = y3; }
         }
         if (!fin) __syncthreads();
     }
@@ -134,8 +138,10 @@ __device__ __forceinline__ void lds_ntt_dit(fe* L, const fe_tw* W, uint32_t log_
             if (Out::active) { k0 = out.pre(k, t); k1 = out.pre(k + half, t); }
             fe* p0 = L + lds_slot(k, t, log_t); fe* p1 = L + lds_slot(k + half, t, log_t);
             const fe u = *p0, v = fe_mul_tw(*p1, Wlast != nullptr ? Wlast[k] : W[half - 1 + k]);
-            if (Out::active) { out.put(k, t, fe_add(u, v), k0); out.put(k + half, t, fe_sub(u, v), k1); }
-            else { *p0 = fe_add(u, v); *p1 = fe_sub(u, v); }
+            fe sum, dif;
+            fe_addsub(u, v, sum, dif);
+            if (Out::active) { out.put(k, t, sum, k0); out.put(k + half, t, dif, k1); }
+            else { *p0 = sum; *p1 = dif; }
         }
         if (!Out::active) __syncthreads();
     }

@@ -49,6 +49,23 @@ int main() {
         fe a = fe_make(rnd(), rnd(), (it & 1) ? 0xFFFFFFFFu : rnd(), 0xFFFFFFFFu), b = fe_make(rnd(), rnd(), (it & 2) ? 0xFFFFFFFFu : rnd(), (it & 4) ? 0xFFFFFFFFu : rnd());
         if (!fe_eq(fe_mul_wide(a, b), fe_mul_portable(canon(a), canon(b)))) { if (bad < 5) printf("weak mismatch it=%ld\n", it); bad++; }
     }
+    // the nine-limb reduction with its overflow limb (sums of products: fe_acc_reduce on the device)
+    const fe c128 = fe_make(FE_C0, FE_C1, 0, 0), c256 = fe_mul_portable(c128, c128);
+    for (long it = 0; it < 1000000; it++) {
+        uint32_t t[9];
+        for (int i = 0; i < 8; i++) t[i] = (it & (1 << i)) && (it & 0x300) == 0x300 ? 0xFFFFFFFFu : (uint32_t)rnd();
+        t[8] = (uint32_t)(rnd() & 127);
+        if ((it & 0xC00) == 0xC00) t[8] = 127;
+        fe ref = fe_add(fe_reduce8(t), fe_mul_portable(fe_make(t[8], 0, 0, 0), c256));
+        if (!fe_eq(fe_fold9(t[0], t[1], t[2], t[3], t[4], t[5], t[6], t[7], t[8], true), ref)) { if (bad < 5) printf("fold9 mismatch it=%ld\n", it); bad++; }
+        fe x = fe_make(rnd(), rnd(), rnd(), rnd()), y = fe_make(rnd(), rnd(), rnd(), rnd()), sum, dif;
+        x = canon(x); y = canon(y);
+        if (it & 1) y = special(it >> 1);
+        if ((it & 6) == 6) x = special(it >> 3);
+        x = canon(x); y = canon(y);
+        fe_addsub(x, y, sum, dif);
+        if (!fe_eq(sum, ref_add(x, y)) || !fe_eq(dif, ref_sub(x, y))) { if (bad < 5) printf("addsub mismatch it=%ld\n", it); bad++; }
+    }
     printf("bad=%ld\n", bad);
     return bad != 0;
 }
