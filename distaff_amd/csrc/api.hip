@@ -285,11 +285,15 @@ int dst_trace_upload_async(dst_ctx* c, const uint8_t* const* cols) {
     if (!c || !cols) return DST_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->upload_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
-    c->upload_group = 4;                                              // registers per extension launch (see k_lde_columns)
-    const size_t groups = (c->W + c->upload_group - 1) / c->upload_group;
+    // groups of 4 registers (one extension launch, see k_lde_columns) -- except that the first group is ONE register: its transfer is the
+    // only one nothing overlaps with
+    c->upload_bounds.clear();
+    for (size_t first = 0; first < c->W;) { c->upload_bounds.push_back(first); first += (first == 0 && c->W > 4) ? (c->W % 4 ? c->W % 4 : 1) : 4; }
+    c->upload_bounds.push_back(c->W);
+    const size_t groups = c->upload_bounds.size() - 1;
     while (c->upload_done.size() < groups) { hipEvent_t e; HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->upload_done.push_back(e); }
     for (size_t g = 0; g < groups; g++) {
-        for (size_t i = g * c->upload_group; i < c->W && i < (g + 1) * c->upload_group; i++)
+        for (size_t i = c->upload_bounds[g]; i < c->upload_bounds[g + 1]; i++)
             HIP_TRY(c, hipMemcpyAsync(c->trace + i * c->n, cols[i], c->n * 16, hipMemcpyHostToDevice, c->upload_stream));
         HIP_TRY(c, hipEventRecord(c->upload_done[g], c->upload_stream));
     }
@@ -307,8 +311,8 @@ int dst_commit_trace(dst_ctx* c, uint8_t trace_root[32]) {
     double t0 = wall_ms();
     if (c->upload_pending) {
         // registers arrive in groups (dst_trace_upload_async): each group is interpolated and extended as soon as its copy has landed
-        for (size_t g = 0, first = 0; first < c->W; g++, first += c->upload_group) {
-            const size_t cnt = c->W - first < c->upload_group ? c->W - first : c->upload_group;
+        for (size_t g = 0; g + 1 < c->upload_bounds.size(); g++) {
+            const size_t first = c->upload_bounds[g], cnt = c->upload_bounds[g + 1] - first;
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->upload_done[g], 0));
             k_intt_columns(c, c->trace + first * c->n, c->polys + first * c->n, cnt);
             k_lde_columns(c, c->polys + first * c->n, c->lde + first * c->Bc * c->n, cnt);

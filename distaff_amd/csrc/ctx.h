@@ -146,7 +146,7 @@ struct dst_ctx {
     // asynchronous upload (dst_trace_upload_async): column group g is complete when upload_done[g] has fired on upload_stream
     hipStream_t upload_stream = nullptr;
     std::vector<hipEvent_t> upload_done;
-    size_t upload_group = 0;            // registers per group
+    std::vector<size_t> upload_bounds;  // group g holds registers [upload_bounds[g], upload_bounds[g + 1])
     bool upload_pending = false;
     double phase_ms[9] = {0};
 

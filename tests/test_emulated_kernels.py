@@ -47,6 +47,8 @@ SELECTION = [
     "test_lde_every_tile_length[lds-13-5]",
     "test_lde_every_tile_length[dit2-13-5]",
     "test_lde_every_tile_length[waves8-13-5]",
+    "test_trace_from_pinned_host_memory[w17]",
+    "test_synthetic_division_by_power_tables",
 ]
 
 

@@ -109,6 +109,35 @@ def test_boundary_constraints_by_evaluation(oracle, monkeypatch, instance):
     _check_all_phases(oracle, D, oracle.Trace("begin dup.4 add mul swap.2 add drop drop block push.9 mul end end", [1, 2, 3, 4]), num_outputs=2)
 
 
+@pytest.mark.parametrize("shape", ["fibonacci", "w17", "w18"])
+def test_trace_from_pinned_host_memory(oracle, shape):
+    """dst_trace_upload_async: the registers arrive group by group (the first group is short) and every group is interpolated and extended
+    as it lands; the proof is the one of the synchronous upload.  Register counts 20 (1 + 4 + 4 + 4 + 4 + 3), 17 (1 + 16 / 4) and 18 (2 + ...)."""
+    import distaff_amd as D
+    O = oracle
+    if shape == "fibonacci":
+        t, outs = O.fibonacci_trace(1 << 10), 1
+    elif shape == "w17":
+        t, outs = O.Trace("begin add push.5 mul push.7 end", [1, 2]), 2
+    else:
+        t, outs = O.Trace("begin add block push.5 mul push.7 end end", [1, 2]), 2
+    op = O.Prover.from_trace(t, outs, ext=32, num_queries=50, grinding=12)
+    for k in range(1, 10):
+        op.step(k)
+    ctx = _ctx(D, t, log_blowup=5, num_queries=50, grinding=12)
+    ctx.upload(t.columns)
+    expected = ctx.prove(t.public_inputs, op.outputs)
+    assert expected == op.get_bytes("proof")
+    table, handle = ctx.pinned_trace(t.columns)
+    try:
+        for _ in range(2):                                   # the second round re-uses the events of the first
+            ctx.upload_async(table)
+            assert ctx.prove(t.public_inputs, op.outputs) == expected
+    finally:
+        ctx.release_pinned(handle)
+    ctx.close()
+
+
 def test_other_program_shapes(oracle):
     import distaff_amd as D
     O = oracle
