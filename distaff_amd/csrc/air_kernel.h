@@ -27,6 +27,9 @@
 // 2.25 -> 2.27 (stays at two).  The per-operation formulation (SLCAP 32) keeps two.
 constexpr int air_waves_per_simd(int sd, int slcap, int sect) {
     if (AIR_WAVES_PER_SIMD != 2) return AIR_WAVES_PER_SIMD;                    // forced at compile time
+#ifdef AIR_WAVES_FORCE
+    return AIR_WAVES_FORCE;                                                     // laboratory builds: every instance at this occupancy
+#endif
     if (sect == 2 || sect == 3 || slcap == 32) return 2;
     if (sd == 0 && slcap == 8 && sect == 80) return 2;
     return 3;

@@ -377,53 +377,70 @@ FE_HD fe fe_shift64(const fe& w) {
 }
 FE_HD fe_tw fe_tw_make(const fe& w) { fe_tw t; t.p = w; t.q = fe_shift64(w); return t; }
 
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) || defined(FE_EMULATE_GFX950)
 // ---- sums of products with ONE reduction ----------------------------------------------------------------------------------------
 // A dot product sum_i a_i * b_i accumulates the 256-bit partial products in even/odd 64-bit windows (every accumulating mad counts its
 // carry-out) and folds once at the end: 32 instructions per term + one reduction instead of a full multiplication and a modular
-// addition per term.  Up to 64 terms (the overflow limb stays below 2^7).
-__device__ __forceinline__ void fe_mac_c(uint64_t& acc, uint32_t& cnt, uint32_t a, uint32_t b) {
-    fe_cf c; acc = fe_madc(a, b, acc, c); cnt = fe_cnt(cnt, c);
-}
+// addition per term.  Up to 64 terms (the overflow limb stays below 2^7).  Statement order = issue order (see fe_mul_tw): consecutive
+// multiply-adds go to different windows and a counter trails its multiply-add by two statements.
 struct fe_acc {
     uint64_t E0, E1, E2, E3, O0, O1, O2;              // windows at limbs 0, 2, 4, 6 and 1, 3, 5
     uint32_t cE0, cE1, cE2, cE3, cO0, cO1, cO2;       // 2^64 overflows of each window
 };
-__device__ __forceinline__ void fe_acc_zero(fe_acc& A) {
+FE_HD void fe_acc_zero(fe_acc& A) {
     A.E0 = A.E1 = A.E2 = A.E3 = A.O0 = A.O1 = A.O2 = 0;
     A.cE0 = A.cE1 = A.cE2 = A.cE3 = A.cO0 = A.cO1 = A.cO2 = 0;
 }
-__device__ __forceinline__ void fe_acc_mac(fe_acc& A, const fe& a, const fe& b) {
-    fe_mac_c(A.E0, A.cE0, a.v[0], b.v[0]);
-    fe_mac_c(A.E1, A.cE1, a.v[0], b.v[2]); fe_mac_c(A.E1, A.cE1, a.v[1], b.v[1]); fe_mac_c(A.E1, A.cE1, a.v[2], b.v[0]);
-    fe_mac_c(A.E2, A.cE2, a.v[1], b.v[3]); fe_mac_c(A.E2, A.cE2, a.v[2], b.v[2]); fe_mac_c(A.E2, A.cE2, a.v[3], b.v[1]);
-    fe_mac_c(A.E3, A.cE3, a.v[3], b.v[3]);
-    fe_mac_c(A.O0, A.cO0, a.v[0], b.v[1]); fe_mac_c(A.O0, A.cO0, a.v[1], b.v[0]);
-    fe_mac_c(A.O1, A.cO1, a.v[0], b.v[3]); fe_mac_c(A.O1, A.cO1, a.v[1], b.v[2]); fe_mac_c(A.O1, A.cO1, a.v[2], b.v[1]); fe_mac_c(A.O1, A.cO1, a.v[3], b.v[0]);
-    fe_mac_c(A.O2, A.cO2, a.v[2], b.v[3]); fe_mac_c(A.O2, A.cO2, a.v[3], b.v[2]);
+FE_HD void fe_acc_mac(fe_acc& A, const fe& a, const fe& b) {
+    const uint32_t a0 = a.v[0], a1 = a.v[1], a2 = a.v[2], a3 = a.v[3], b0 = b.v[0], b1 = b.v[1], b2 = b.v[2], b3 = b.v[3];
+    fe_cf k0, k1, k2;
+    A.E0 = fe_madc(a0, b0, A.E0, k0);
+    A.O0 = fe_madc(a0, b1, A.O0, k1);
+    A.E1 = fe_madc(a0, b2, A.E1, k2);   A.cE0 = fe_cnt(A.cE0, k0);
+    A.O1 = fe_madc(a0, b3, A.O1, k0);   A.cO0 = fe_cnt(A.cO0, k1);
+    A.E2 = fe_madc(a1, b3, A.E2, k1);   A.cE1 = fe_cnt(A.cE1, k2);
+    A.O2 = fe_madc(a2, b3, A.O2, k2);   A.cO1 = fe_cnt(A.cO1, k0);
+    A.E3 = fe_madc(a3, b3, A.E3, k0);   A.cE2 = fe_cnt(A.cE2, k1);
+    A.O0 = fe_madc(a1, b0, A.O0, k1);   A.cO2 = fe_cnt(A.cO2, k2);
+    A.E1 = fe_madc(a1, b1, A.E1, k2);   A.cE3 = fe_cnt(A.cE3, k0);
+    A.O1 = fe_madc(a1, b2, A.O1, k0);   A.cO0 = fe_cnt(A.cO0, k1);
+    A.E2 = fe_madc(a2, b2, A.E2, k1);   A.cE1 = fe_cnt(A.cE1, k2);
+    A.O2 = fe_madc(a3, b2, A.O2, k2);   A.cO1 = fe_cnt(A.cO1, k0);
+    A.E1 = fe_madc(a2, b0, A.E1, k0);   A.cE2 = fe_cnt(A.cE2, k1);
+    A.O1 = fe_madc(a2, b1, A.O1, k1);   A.cO2 = fe_cnt(A.cO2, k2);
+    A.E2 = fe_madc(a3, b1, A.E2, k2);   A.cE1 = fe_cnt(A.cE1, k0);
+    A.O1 = fe_madc(a3, b0, A.O1, k0);   A.cO1 = fe_cnt(A.cO1, k1);
+    A.cE2 = fe_cnt(A.cE2, k2);
+    A.cO1 = fe_cnt(A.cO1, k0);
 }
 // adds a field element (weight 1) to the sum
-__device__ __forceinline__ void fe_acc_add(fe_acc& A, const fe& a) {
-    fe_mac_c(A.E0, A.cE0, a.v[0], 1u); fe_mac_c(A.O0, A.cO0, a.v[1], 1u); fe_mac_c(A.E1, A.cE1, a.v[2], 1u); fe_mac_c(A.O1, A.cO1, a.v[3], 1u);
+FE_HD void fe_acc_add(fe_acc& A, const fe& a) {
+    fe_cf k0, k1, k2;
+    A.E0 = fe_madc(a.v[0], 1u, A.E0, k0);
+    A.O0 = fe_madc(a.v[1], 1u, A.O0, k1);
+    A.E1 = fe_madc(a.v[2], 1u, A.E1, k2);   A.cE0 = fe_cnt(A.cE0, k0);
+    A.O1 = fe_madc(a.v[3], 1u, A.O1, k0);   A.cO0 = fe_cnt(A.cO0, k1);
+    A.cE1 = fe_cnt(A.cE1, k2);
+    A.cO1 = fe_cnt(A.cO1, k0);
 }
-__device__ __forceinline__ fe fe_acc_reduce(const fe_acc& A) {
-    fe_cf c;
+FE_HD fe fe_acc_reduce(const fe_acc& A) {
+    fe_cf c, d;
     uint32_t t0 = FE_LO(A.E0);
     uint32_t t1 = fe_add_co(FE_HI(A.E0), FE_LO(A.O0), c);
     uint32_t t2 = fe_addc_co(FE_LO(A.E1), FE_HI(A.O0), c, c);
     uint32_t t3 = fe_addc_co(FE_HI(A.E1), FE_LO(A.O1), c, c);
+    t2 = fe_add_co(t2, A.cE0, d);                                  // the counters' chain runs two links behind the windows' chain
     uint32_t t4 = fe_addc_co(FE_LO(A.E2), FE_HI(A.O1), c, c);
+    t3 = fe_addc_co(t3, A.cO0, d, d);
     uint32_t t5 = fe_addc_co(FE_HI(A.E2), FE_LO(A.O2), c, c);
+    t4 = fe_addc_co(t4, A.cE1, d, d);
     uint32_t t6 = fe_addc_co(FE_LO(A.E3), FE_HI(A.O2), c, c);
+    t5 = fe_addc_co(t5, A.cO1, d, d);
     uint32_t t7 = fe_addc0_co(FE_HI(A.E3), c, c);
+    t6 = fe_addc_co(t6, A.cE2, d, d);
     uint32_t t8 = fe_cnt(A.cE3, c);
-    t2 = fe_add_co(t2, A.cE0, c);
-    t3 = fe_addc_co(t3, A.cO0, c, c);
-    t4 = fe_addc_co(t4, A.cE1, c, c);
-    t5 = fe_addc_co(t5, A.cO1, c, c);
-    t6 = fe_addc_co(t6, A.cE2, c, c);
-    t7 = fe_addc_co(t7, A.cO2, c, c);
-    t8 = fe_cnt(t8, c);
+    t7 = fe_addc_co(t7, A.cO2, d, d);
+    t8 = fe_cnt(t8, d);
     return fe_fold9(t0, t1, t2, t3, t4, t5, t6, t7, t8, true);
 }
 #else

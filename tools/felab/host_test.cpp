@@ -66,6 +66,19 @@ int main() {
         fe_addsub(x, y, sum, dif);
         if (!fe_eq(sum, ref_add(x, y)) || !fe_eq(dif, ref_sub(x, y))) { if (bad < 5) printf("addsub mismatch it=%ld\n", it); bad++; }
     }
+    // sums of products with one reduction: up to 64 terms, operands any 128-bit values
+    for (long it = 0; it < 20000; it++) {
+        fe_acc A; fe_acc_zero(A);
+        fe ref = fe_zero();
+        const int terms = 1 + (int)(rnd() % 63);
+        for (int i = 0; i < terms; i++) {
+            fe x = fe_make(rnd(), rnd(), rnd(), rnd()), y = fe_make(rnd(), rnd(), rnd(), rnd());
+            if ((it & 3) == 3) { x = fe_make(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu); y = x; }
+            if (i & 1) { fe_acc_mac(A, x, y); ref = fe_add(ref, fe_mul_portable(canon(x), canon(y))); }
+            else { fe_acc_mac(A, x, y); fe_acc_add(A, y); ref = fe_add(fe_add(ref, fe_mul_portable(canon(x), canon(y))), canon(y)); }
+        }
+        if (!fe_eq(fe_acc_reduce(A), ref)) { if (bad < 5) printf("acc mismatch it=%ld terms=%d\n", it, terms); bad++; }
+    }
     printf("bad=%ld\n", bad);
     return bad != 0;
 }
