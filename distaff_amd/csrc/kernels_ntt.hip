@@ -11,7 +11,8 @@
 //     pass B: for a tile of T adjacent rows k1, the n2-point NTT over the contiguous dimension, in LDS, stored as
 //             X[k1 + n1*k2] so that the output is in natural order;
 //   three passes (n = n1*nm*n3, n >= 2^21): pass A, pass A again on every row of n/n1 points, pass B with tiles of adjacent k1.
-// Workgroups are persistent over adjacent tiles and prefetch the next tile into registers while the current one is in LDS.
+// Workgroups are persistent over adjacent tiles; the 512-lane instances prefetch the next tile into registers while the current one
+// is in LDS, the 1024-lane instances of 1024-point tiles (8 waves per SIMD) leave the overlap to the CU's other workgroup.
 // The low-degree extension never materialises the zero-padded size-N input of the reference: the N = B*n evaluations
 // are B coset transforms of size n (coset j holds the reference's indices B*k + j), stored coset-major; coset 0 of the trace
 // extension is the trace itself and is copied.  HBM accesses are T*16-byte segments (T = 4 for 1024-point tiles, 16 for the
@@ -81,12 +82,14 @@ struct OutB {                                          // natural-order store X[
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
 
-// Both passes are persistent over `tiles_per_block` adjacent tiles: the tile's elements for the NEXT iteration are fetched from HBM
-// into registers before the butterfly stages of the current one start, so the HBM latency and most of the transfer overlap
-// with the arithmetic (measured: a block that loads, computes and stores in sequence pays HBM time + ALU time, not their maximum).
-// The stage twiddles live in LDS behind the tile as table pairs (32 bytes each), so the stages issue no global loads that would
-// have to wait behind the prefetch.  A 1024-point coset DIT needs 64 KiB of tile + 32 KiB of twiddles: that instance runs as ONE
-// workgroup of 1024 lanes per CU (4 elements per lane); everything that fits 80 KiB runs as two workgroups of 512 lanes (8 per lane).
+// Both passes are persistent over `tiles_per_block` adjacent tiles.  PREFETCH instances (WPE = 4 waves per SIMD, 128 registers): the
+// tile's elements for the NEXT iteration are fetched from HBM into registers before the butterfly stages of the current one start, so
+// the HBM latency and most of the transfer overlap with the arithmetic (measured: a block of this occupancy that loads, computes and
+// stores in sequence pays HBM time + ALU time, not their maximum).  <1024, 8, false>: two workgroups of 1024 lanes per CU, 8 waves per
+// SIMD in 64 registers, no prefetch -- while one workgroup loads, the other one's 16 waves keep the SIMDs busy (ntt_launch picks it for
+// 1024-point tiles).  The stage twiddles live in LDS behind the tile as table pairs (32 bytes each), so the stages issue no global loads
+// that would have to wait behind the prefetch.  A 1024-point coset DIT with its whole table in LDS needs 64 KiB of tile + 32 KiB of
+// twiddles: that instance runs as ONE workgroup of 1024 lanes per CU; everything that fits 80 KiB runs as two workgroups per CU.
 template <int THREADS, int WPE = 4, bool PREFETCH = true>
 __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* __restrict__ src_base, fe* __restrict__ dst_base) {
     constexpr int EPT = NTT_TILE_ELEMS / THREADS;
