@@ -97,24 +97,27 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
 // 1024-point tiles).  The stage twiddles live in LDS behind the tile as table pairs (32 bytes each), so the stages issue no global loads
 // that would have to wait behind the prefetch.  A 1024-point coset DIT with its whole table in LDS needs 64 KiB of tile + 32 KiB of
 // twiddles: that instance runs as ONE workgroup of 1024 lanes per CU; everything that fits 80 KiB runs as two workgroups per CU.
-template <int THREADS, int WPE = 4, bool PREFETCH = true>
+// LOG_LEN / LOG_T != 0: the instance of ONE tile shape (2^LOG_LEN points x 2^LOG_T columns) -- its rounds are separate code with literal
+// strides (ntt_lds.h) and the tile index arithmetic folds into immediates; 0: any shape, from the arguments.
+template <int THREADS, int WPE = 4, bool PREFETCH = true, int LOG_LEN = 0, int LOG_T = 0>
 __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* __restrict__ src_base, fe* __restrict__ dst_base) {
     constexpr int EPT = NTT_TILE_ELEMS / THREADS;
     fe* L = reinterpret_cast<fe*>(ntt_smem);
-    const uint32_t log_t = a.tile, T = 1u << log_t, n1 = 1u << a.log_n1;
+    const uint32_t log_n1 = LOG_LEN ? (uint32_t)LOG_LEN : a.log_n1;
+    const uint32_t log_t = LOG_T ? (uint32_t)LOG_T : a.tile, T = 1u << log_t, n1 = 1u << log_n1;
     fe_tw* TW = reinterpret_cast<fe_tw*>(L + n1 * T);
     uint32_t group, jl, col;
     ntt_block(a, group, jl, col);
     const uint32_t jg = a.j0 + jl;
     const fe* __restrict__ src0 = src_base + (size_t)col * a.src_col_stride + (size_t)jl * a.src_coset_stride;
     fe* __restrict__ dst0 = dst_base + (size_t)col * a.dst_col_stride + (size_t)jl * a.dst_coset_stride;
-    const uint32_t pmask = (1u << (a.log_b + a.log_n1)) - 1u;
+    const uint32_t pmask = (1u << (a.log_b + log_n1)) - 1u;
     if (a.dit) {
         // stage twiddles of this coset: g^(n1/B) * w_B^k = w_{B_lde*n1}^((j + B_lde*k) * n1/B) straight from the pre-scale table
         const uint32_t in_lds = a.dit_last ? n1 / 2 : n1;                                     // entries + 1
         for (uint32_t i = threadIdx.x; i + 1 < in_lds; i += THREADS) {
             const uint32_t lb = 31u - (uint32_t)__clz(i + 1), k = i + 1 - (1u << lb);         // entry i: block size B = 2^(lb+1), index k
-            TW[i] = a.prescale[((jg + (k << a.log_b)) << (a.log_n1 - lb - 1)) & pmask];
+            TW[i] = a.prescale[((jg + (k << a.log_b)) << (log_n1 - lb - 1)) & pmask];
         }
     } else
     for (uint32_t i = threadIdx.x; i < n1 / 2; i += THREADS) TW[dif_tw_slot(i)] = a.stage_tw[i];
@@ -135,13 +138,18 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
         if (!PREFETCH) NTT_FETCH_A(tile)
         __syncthreads();                                   // the previous tile has left LDS (and TW is complete)
         // DISTAFF_NTT_DIF: pre-scale + DIF instead of the coset DIT
-#define NTT_PUT_A(e, var) if constexpr ((e) < EPT) { const uint32_t idx = threadIdx.x + (e) * THREADS; if (idx < count) { if (a.dit) L[lds_slot(__brev(idx >> log_t) >> (32 - a.log_n1), idx & (T - 1), log_t)] = var; else L[lds_slot(idx >> log_t, idx & (T - 1), log_t)] = scaled ? fe_mul_tw(var, a.prescale[(jg * (idx >> log_t)) & pmask]) : var; } }
+#define NTT_PUT_A(e, var) if constexpr ((e) < EPT) { const uint32_t idx = threadIdx.x + (e) * THREADS; if (idx < count) { if (a.dit) L[lds_slot(__brev(idx >> log_t) >> (32 - log_n1), idx & (T - 1), log_t)] = var; else L[lds_slot(idx >> log_t, idx & (T - 1), log_t)] = scaled ? fe_mul_tw(var, a.prescale[(jg * (idx >> log_t)) & pmask]) : var; } }
         NTT_EACH(NTT_PUT_A)
 #undef NTT_PUT_A
         __syncthreads();
         if (PREFETCH && it + 1 < a.tiles_per_block) NTT_FETCH_A(tile + 1)
-        if (a.dit) lds_ntt_dit<THREADS>(L, TW, a.log_n1, log_t, 1u, a.log_n1 + 1u, a.dit_last ? a.dit_last + (size_t)jg * (n1 / 2) : nullptr);
-        else lds_ntt_dif<THREADS>(L, TW, a.log_n1, log_t, 1u, a.log_n1 + 1u);
+        if constexpr (LOG_LEN != 0) {
+            if (a.dit) lds_ntt_dit_fixed<THREADS, LOG_LEN, LOG_T>(L, TW, a.dit_last ? a.dit_last + (size_t)jg * (n1 / 2) : nullptr);
+            else lds_ntt_dif_fixed<THREADS, LOG_LEN, LOG_T>(L, TW);
+        } else {
+            if (a.dit) lds_ntt_dit<THREADS>(L, TW, log_n1, log_t, 1u, log_n1 + 1u, a.dit_last ? a.dit_last + (size_t)jg * (n1 / 2) : nullptr);
+            else lds_ntt_dif<THREADS>(L, TW, log_n1, log_t, 1u, log_n1 + 1u);
+        }
         // read-out in batches of RB elements per lane: the twiddle loads of a batch are in flight together (the 512-lane instance also
         // holds eight prefetched elements: a batch of four would spill).  The second passes store from their last butterfly round instead
         // (OutB); here that costs more than it saves: with the four-step twiddles (and the last-stage pairs from global memory) live in
@@ -157,7 +165,7 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
                 ok[q] = idx < count;
                 idx = ok[q] ? idx : 0u;
                 const uint32_t t = idx & (T - 1), r = idx >> log_t;
-                const uint32_t k1 = a.dit ? r : __brev(r) >> (32 - a.log_n1);        // DIT leaves the tile in natural order
+                const uint32_t k1 = a.dit ? r : __brev(r) >> (32 - log_n1);        // DIT leaves the tile in natural order
                 off[q] = (k1 << a.log_n2) + t;
                 v[q] = L[idx];
                 w[q] = tw[off[q]];
@@ -175,11 +183,12 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
 }
 
 // WPE: waves per SIMD the instance is compiled for (its register budget); PREFETCH: the next tile travels in registers during the rounds
-template <int THREADS, int WPE = 4, bool PREFETCH = true>
+template <int THREADS, int WPE = 4, bool PREFETCH = true, int LOG_LEN = 0, int LOG_T = 0>
 __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_b(NttArgs a, const fe* __restrict__ src_base, fe* __restrict__ dst_base) {
     constexpr int EPT = NTT_TILE_ELEMS / THREADS;
     fe* L = reinterpret_cast<fe*>(ntt_smem);
-    const uint32_t log_t = a.tile, T = 1u << log_t, n2 = 1u << a.log_n2;
+    const uint32_t log_n2 = LOG_LEN ? (uint32_t)LOG_LEN : a.log_n2;
+    const uint32_t log_t = LOG_T ? (uint32_t)LOG_T : a.tile, T = 1u << log_t, n2 = 1u << log_n2;
     fe_tw* TW = reinterpret_cast<fe_tw*>(L + n2 * T);
     uint32_t g, jl, col;
     ntt_block(a, g, jl, col);
@@ -190,7 +199,7 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_b(NttArgs a, const fe* 
     fe pre0 = fe_zero(), pre1 = fe_zero(), pre2 = fe_zero(), pre3 = fe_zero(), pre4 = fe_zero(), pre5 = fe_zero(), pre6 = fe_zero(), pre7 = fe_zero();
     const uint32_t count = n2 * T;
     // contiguous along m2
-#define NTT_FETCH_B1(e, var) if constexpr ((e) < EPT) { uint32_t idx = threadIdx.x + (e) * THREADS; idx = idx < count ? idx : 0u; var = srct[(idx >> a.log_n2) * row_stride + (idx & (n2 - 1))]; }
+#define NTT_FETCH_B1(e, var) if constexpr ((e) < EPT) { uint32_t idx = threadIdx.x + (e) * THREADS; idx = idx < count ? idx : 0u; var = srct[(idx >> log_n2) * row_stride + (idx & (n2 - 1))]; }
 #define NTT_FETCH_B(tile) { const fe* __restrict__ srct = src + (size_t)((tile) * T) * a.src_row_stride; NTT_EACH(NTT_FETCH_B1) }
     const uint32_t row_stride = (uint32_t)a.src_row_stride;
     const uint32_t tile0 = group * a.tiles_per_block;
@@ -199,13 +208,14 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_b(NttArgs a, const fe* 
         const uint32_t k1_0 = (tile0 + it) * T;
         if (!PREFETCH) NTT_FETCH_B(tile0 + it)
         __syncthreads();
-#define NTT_PUT_B(e, var) if constexpr ((e) < EPT) { const uint32_t idx = threadIdx.x + (e) * THREADS; if (idx < count) L[lds_slot(idx & (n2 - 1), idx >> a.log_n2, log_t)] = var; }
+#define NTT_PUT_B(e, var) if constexpr ((e) < EPT) { const uint32_t idx = threadIdx.x + (e) * THREADS; if (idx < count) L[lds_slot(idx & (n2 - 1), idx >> log_n2, log_t)] = var; }
         NTT_EACH(NTT_PUT_B)
 #undef NTT_PUT_B
         __syncthreads();
         if (PREFETCH && it + 1 < a.tiles_per_block) NTT_FETCH_B(tile0 + it + 1)
-        const OutB out{dst + k1_0, (uint32_t)a.dst_k_stride, a.log_n2, a.has_scale != 0, a.scale};
-        lds_ntt_dif<THREADS, OutB>(L, TW, a.log_n2, log_t, 1u, a.log_n2 + 1u, out);
+        const OutB out{dst + k1_0, (uint32_t)a.dst_k_stride, log_n2, a.has_scale != 0, a.scale};
+        if constexpr (LOG_LEN != 0) lds_ntt_dif_fixed<THREADS, LOG_LEN, LOG_T, OutB>(L, TW, out);
+        else lds_ntt_dif<THREADS, OutB>(L, TW, log_n2, log_t, 1u, log_n2 + 1u, out);
     }
 }
 
@@ -443,6 +453,8 @@ static void ntt_raise_lds_limit(dst_ctx* c) {                  // tile + stage t
     (void)hipFuncSetAttribute((const void*)ntt_pass_b<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ntt_pass_b<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ntt_pass_a<1024, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ntt_pass_a<1024, 8, false, 10, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ntt_pass_b<1024, 8, false, 10, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ntt_pass_b<1024, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 
     raised[c->device] = true;
@@ -474,12 +486,15 @@ static void ntt_launch(dst_ctx* c, bool pass_b, NttArgs& a, size_t groups, size_
     KScope ks_(c, name, bytes, true, 18.0 * mults * elements);
     const char* wv = getenv("DISTAFF_NTT_WAVES");
     const bool two = lds <= NTT_LDS_TWO_PER_CU, eight = two && (wv ? wv[0] == '8' : stages >= 10);
+    const bool fixed = stages == 10 && a.tile == 2 && !(getenv("DISTAFF_NTT_FIXED") && getenv("DISTAFF_NTT_FIXED")[0] == '0');   // the 2^20 shape has its own instances
     if (a.debug & 1u) ntt_report_occupancy(name, pass_b, eight || !two ? 1024 : 512, eight, lds);
     if (two) {
         // 1024-point tiles (five LDS rounds per tile): two workgroups of 1024 lanes = 8 waves per SIMD, 64 registers, no register prefetch -- the
         // other workgroup's rounds cover a workgroup's loads (measured 20.2 against 20.55 ms of extension per 2^20 proof, same box); shorter
         // tiles stay with 512 lanes + prefetch (2^16: 0.96 against 1.03 ms).  DISTAFF_NTT_WAVES=4|8 forces one (the tests run both).
-        if (pass_b && eight) hipLaunchKernelGGL((ntt_pass_b<1024, 8, false>), grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
+        if (pass_b && eight && fixed) hipLaunchKernelGGL((ntt_pass_b<1024, 8, false, 10, 2>), grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
+        else if (!pass_b && eight && fixed) hipLaunchKernelGGL((ntt_pass_a<1024, 8, false, 10, 2>), grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
+        else if (pass_b && eight) hipLaunchKernelGGL((ntt_pass_b<1024, 8, false>), grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
         else if (pass_b) hipLaunchKernelGGL(ntt_pass_b<512>, grid, dim3(512), lds, c->stream, a, a.src, a.dst);
         else if (eight) hipLaunchKernelGGL((ntt_pass_a<1024, 8, false>), grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
         else hipLaunchKernelGGL(ntt_pass_a<512>, grid, dim3(512), lds, c->stream, a, a.src, a.dst);

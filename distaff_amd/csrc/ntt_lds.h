@@ -45,53 +45,66 @@ struct NttKeepInLds {
 // in-LDS DIF over the first index of L[len][T]; output position r holds frequency bitrev(r).  W: stage twiddles w_len^t in LDS.
 // Two radix-2 stages are fused into one radix-4 round (one LDS round trip, one barrier and one index computation per two
 // stages; the arithmetic is exactly the two radix-2 stages); an odd stage count ends with a plain radix-2 stage.
+// lds_dif_round = stages s and s + 1, lds_dif_tail = the distance-1 stage of an odd stage count; every argument but the pointers is
+// uniform, and with literal arguments (lds_ntt_dif_fixed) the index arithmetic folds into immediates.
+template <int THREADS, class Out>
+__device__ __forceinline__ void lds_dif_round(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s, const Out& out) {
+    const uint32_t T = 1u << log_t;
+    const uint32_t ld = log_len - s;             // log2 of the first stage's butterfly distance d
+    const uint32_t d = 1u << ld, hd = d >> 1;
+    const bool last = (s + 1 == log_len);        // second stage has distance 1: its twiddles are 1
+    const bool fin = Out::active && last;        // the results of this round leave through `out`
+    for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 2) * T; w += THREADS) {
+        const uint32_t t = w & (T - 1), q = w >> log_t;
+        const uint32_t pos = q & (hd - 1), blk = q >> (ld - 1);
+        const uint32_t i0 = (blk << (ld + 1)) + pos;
+        typename Out::Tok k0, k1, k2, k3;
+        if (fin) { k0 = out.pre(i0, t); k1 = out.pre(i0 + hd, t); k2 = out.pre(i0 + d, t); k3 = out.pre(i0 + d + hd, t); }
+        fe* p0 = L + lds_slot(i0, t, log_t); fe* p1 = L + lds_slot(i0 + hd, t, log_t); fe* p2 = L + lds_slot(i0 + d, t, log_t); fe* p3 = L + lds_slot(i0 + d + hd, t, log_t);
+        const fe x0 = *p0, x1 = *p1, x2 = *p2, x3 = *p3;
+        // stage s: (x0, x2) with w_2d^pos, (x1, x3) with w_2d^(pos + d/2)
+        fe a0, a1, a2, a3;
+        fe_addsub(x0, x2, a0, a2);
+        fe_addsub(x1, x3, a1, a3);
+        if (hd != 1) a2 = fe_mul_tw(a2, W[dif_tw_slot(pos << (s - 1))]);          // hd == 1: pos == 0 in every lane
+        a3 = fe_mul_tw(a3, W[dif_tw_slot((pos + hd) << (s - 1))]);
+        // stage s + 1: (a0, a1) and (a2, a3) with w_d^pos
+        fe y0, y1, y2, y3;
+        fe_addsub(a0, a1, y0, y1);
+        fe_addsub(a2, a3, y2, y3);
+        if (!last && hd != 1) { const fe_tw tw = W[dif_tw_slot(pos << s)]; y1 = fe_mul_tw(y1, tw); y3 = fe_mul_tw(y3, tw); }
+        if (fin) { out.put(i0, t, y0, k0); out.put(i0 + hd, t, y1, k1); out.put(i0 + d, t, y2, k2); out.put(i0 + d + hd, t, y3, k3); }
+        else { *p0 = y0; *p1 = y1; *p2 = y2; *p3 = y3; }
+    }
+    if (!fin) __syncthreads();
+}
+template <int THREADS, class Out>
+__device__ __forceinline__ void lds_dif_tail(fe* L, uint32_t log_len, uint32_t log_t, const Out& out) {       // distance-1 stage, no twiddles
+    const uint32_t T = 1u << log_t;
+    for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 1) * T; w += THREADS) {
+        const uint32_t t = w & (T - 1), q = w >> log_t;
+        typename Out::Tok k0, k1;
+        if (Out::active) { k0 = out.pre(q << 1, t); k1 = out.pre((q << 1) + 1, t); }
+        fe* p0 = L + lds_slot(q << 1, t, log_t); fe* p1 = L + lds_slot((q << 1) + 1, t, log_t);
+        const fe a = *p0, b = *p1;
+        fe sum, dif;
+        fe_addsub(a, b, sum, dif);
+        if (Out::active) { out.put(q << 1, t, sum, k0); out.put((q << 1) + 1, t, dif, k1); }
+        else { *p0 = sum; *p1 = dif; }
+    }
+    if (!Out::active) __syncthreads();
+}
 template <int THREADS, class Out = NttKeepInLds>
 __device__ __forceinline__ void lds_ntt_dif(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s_from, uint32_t s_to, const Out& out = Out()) {
-    const uint32_t T = 1u << log_t;
     uint32_t s = s_from;                             // stages [s_from, s_to), s_from odd
-    for (; s + 1 <= log_len && s < s_to; s += 2) {
-        const uint32_t ld = log_len - s;             // log2 of the first stage's butterfly distance d
-        const uint32_t d = 1u << ld, hd = d >> 1;
-        const bool last = (s + 1 == log_len);        // second stage has distance 1: its twiddles are 1
-        const bool fin = Out::active && last;        // the results of this round leave through `out`
-        for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 2) * T; w += THREADS) {
-            const uint32_t t = w & (T - 1), q = w >> log_t;
-            const uint32_t pos = q & (hd - 1), blk = q >> (ld - 1);
-            const uint32_t i0 = (blk << (ld + 1)) + pos;
-            typename Out::Tok k0, k1, k2, k3;
-            if (fin) { k0 = out.pre(i0, t); k1 = out.pre(i0 + hd, t); k2 = out.pre(i0 + d, t); k3 = out.pre(i0 + d + hd, t); }
-            fe* p0 = L + lds_slot(i0, t, log_t); fe* p1 = L + lds_slot(i0 + hd, t, log_t); fe* p2 = L + lds_slot(i0 + d, t, log_t); fe* p3 = L + lds_slot(i0 + d + hd, t, log_t);
-            const fe x0 = *p0, x1 = *p1, x2 = *p2, x3 = *p3;
-            // stage s: (x0, x2) with w_2d^pos, (x1, x3) with w_2d^(pos + d/2)
-            fe a0, a1, a2, a3;
-            fe_addsub(x0, x2, a0, a2);
-            fe_addsub(x1, x3, a1, a3);
-            if (hd != 1) a2 = fe_mul_tw(a2, W[dif_tw_slot(pos << (s - 1))]);          // hd == 1: pos == 0 in every lane
-            a3 = fe_mul_tw(a3, W[dif_tw_slot((pos + hd) << (s - 1))]);
-            // stage s + 1: (a0, a1) and (a2, a3) with w_d^pos
-            fe y0, y1, y2, y3;
-            fe_addsub(a0, a1, y0, y1);
-            fe_addsub(a2, a3, y2, y3);
-            if (!last && hd != 1) { const fe_tw tw = W[dif_tw_slot(pos << s)]; y1 = fe_mul_tw(y1, tw); y3 = fe_mul_tw(y3, tw); }
-            if (fin) { out.put(i0, t, y0, k0); out.put(i0 + hd, t, y1, k1); out.put(i0 + d, t, y2, k2); out.put(i0 + d + hd, t, y3, k3); }
-            else { *p0 = y0; *p1 = y1; *p2 = y2; *p3 = y3; }
-        }
-        if (!fin) __syncthreads();
-    }
-    if (s == log_len && s < s_to) {                  // distance-1 stage, no twiddles
-        for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 1) * T; w += THREADS) {
-            const uint32_t t = w & (T - 1), q = w >> log_t;
-            typename Out::Tok k0, k1;
-            if (Out::active) { k0 = out.pre(q << 1, t); k1 = out.pre((q << 1) + 1, t); }
-            fe* p0 = L + lds_slot(q << 1, t, log_t); fe* p1 = L + lds_slot((q << 1) + 1, t, log_t);
-            const fe a = *p0, b = *p1;
-            fe sum, dif;
-            fe_addsub(a, b, sum, dif);
-            if (Out::active) { out.put(q << 1, t, sum, k0); out.put((q << 1) + 1, t, dif, k1); }
-            else { *p0 = sum; *p1 = dif; }
-        }
-        if (!Out::active) __syncthreads();
-    }
+    for (; s + 1 <= log_len && s < s_to; s += 2) lds_dif_round<THREADS, Out>(L, W, log_len, log_t, s, out);
+    if (s == log_len && s < s_to) lds_dif_tail<THREADS, Out>(L, log_len, log_t, out);
+}
+// the same transform for a tile shape known at compile time: the rounds are separate code with literal strides
+template <int THREADS, int LOG_LEN, int LOG_T, class Out = NttKeepInLds>
+__device__ __forceinline__ void lds_ntt_dif_fixed(fe* L, const fe_tw* W, const Out& out = Out()) {
+    static_for<0, LOG_LEN / 2>([&](auto r_) { constexpr uint32_t s = 1u + 2u * decltype(r_)::value; lds_dif_round<THREADS, Out>(L, W, (uint32_t)LOG_LEN, (uint32_t)LOG_T, s, out); });
+    if constexpr (LOG_LEN & 1) lds_dif_tail<THREADS, Out>(L, (uint32_t)LOG_LEN, (uint32_t)LOG_T, out);
 }
 
 // in-LDS DIT over the first index of L[len][T] for a COSET transform: X[k] = sum_m x[m] * g^m * w_len^(m*k).  The input sits in
@@ -101,49 +114,58 @@ __device__ __forceinline__ void lds_ntt_dif(fe* L, const fe_tw* W, uint32_t log_
 // B/2 - 1 (len - 1 entries for the workgroup's coset).  Two stages per LDS round trip, as in lds_ntt_dif.
 // `Wlast` != nullptr: the len/2 twiddles of the LAST stage (half of the coset's table) are not in LDS but read from this global array
 // (contiguous per coset, L2-resident): tile + the other len/2 - 1 pairs then fit the 80 KiB that let two workgroups share a CU.
+template <int THREADS, class Out>
+__device__ __forceinline__ void lds_dit_round(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s, const fe_tw* __restrict__ Wlast, const Out& out) {
+    const uint32_t T = 1u << log_t;
+    const uint32_t B = 1u << s, half = B >> 1;                     // first stage merges blocks of size B / 2 into B, second B into 2B
+    const bool fin = Out::active && s + 1 == log_len;              // the results of this round leave through `out`
+    for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 2) * T; w += THREADS) {
+        const uint32_t t = w & (T - 1), q = w >> log_t;
+        const uint32_t k = q & (half - 1), base = (q >> (s - 1)) << (s + 1);
+        typename Out::Tok k0, k1, k2, k3;
+        if (fin) { k0 = out.pre(base + k, t); k1 = out.pre(base + k + half, t); k2 = out.pre(base + k + B, t); k3 = out.pre(base + k + B + half, t); }
+        fe* p0 = L + lds_slot(base + k, t, log_t); fe* p1 = L + lds_slot(base + k + half, t, log_t); fe* p2 = L + lds_slot(base + k + B, t, log_t); fe* p3 = L + lds_slot(base + k + B + half, t, log_t);
+        const fe_tw tb = W[half - 1 + k];
+        const fe x0 = *p0, x1 = fe_mul_tw(*p1, tb), x2 = *p2, x3 = fe_mul_tw(*p3, tb);
+        fe a0, a1, b2, b3;
+        fe_addsub(x0, x1, a0, a1);
+        fe_addsub(x2, x3, b2, b3);
+        const bool from_global = Wlast != nullptr && s + 1 == log_len;        // the second stage of this round is the last stage
+        const fe_tw t2 = from_global ? Wlast[k] : W[B - 1 + k], t3 = from_global ? Wlast[k + half] : W[B - 1 + k + half];
+        const fe a2 = fe_mul_tw(b2, t2), a3 = fe_mul_tw(b3, t3);
+        fe y0, y1, y2, y3;
+        fe_addsub(a0, a2, y0, y2);
+        fe_addsub(a1, a3, y1, y3);
+        if (fin) { out.put(base + k, t, y0, k0); out.put(base + k + B, t, y2, k2); out.put(base + k + half, t, y1, k1); out.put(base + k + B + half, t, y3, k3); }
+        else { *p0 = y0; *p2 = y2; *p1 = y1; *p3 = y3; }
+    }
+    if (!fin) __syncthreads();
+}
+template <int THREADS, class Out>
+__device__ __forceinline__ void lds_dit_tail(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, const fe_tw* __restrict__ Wlast, const Out& out) {   // last single stage: blocks of len / 2 into len
+    const uint32_t T = 1u << log_t;
+    const uint32_t half = 1u << (log_len - 1);
+    for (uint32_t w = threadIdx.x; w < half * T; w += THREADS) {
+        const uint32_t t = w & (T - 1), k = w >> log_t;
+        typename Out::Tok k0, k1;
+        if (Out::active) { k0 = out.pre(k, t); k1 = out.pre(k + half, t); }
+        fe* p0 = L + lds_slot(k, t, log_t); fe* p1 = L + lds_slot(k + half, t, log_t);
+        const fe u = *p0, v = fe_mul_tw(*p1, Wlast != nullptr ? Wlast[k] : W[half - 1 + k]);
+        fe sum, dif;
+        fe_addsub(u, v, sum, dif);
+        if (Out::active) { out.put(k, t, sum, k0); out.put(k + half, t, dif, k1); }
+        else { *p0 = sum; *p1 = dif; }
+    }
+    if (!Out::active) __syncthreads();
+}
 template <int THREADS, class Out = NttKeepInLds>
 __device__ __forceinline__ void lds_ntt_dit(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s_from, uint32_t s_to, const fe_tw* __restrict__ Wlast = nullptr, const Out& out = Out()) {
-    const uint32_t T = 1u << log_t;
     uint32_t s = s_from;                             // stages [s_from, s_to), s_from odd
-    for (; s + 1 <= log_len && s < s_to; s += 2) {
-        const uint32_t B = 1u << s, half = B >> 1;                     // first stage merges blocks of size B / 2 into B, second B into 2B
-        const bool fin = Out::active && s + 1 == log_len;              // the results of this round leave through `out`
-        for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 2) * T; w += THREADS) {
-            const uint32_t t = w & (T - 1), q = w >> log_t;
-            const uint32_t k = q & (half - 1), base = (q >> (s - 1)) << (s + 1);
-            typename Out::Tok k0, k1, k2, k3;
-            if (fin) { k0 = out.pre(base + k, t); k1 = out.pre(base + k + half, t); k2 = out.pre(base + k + B, t); k3 = out.pre(base + k + B + half, t); }
-            fe* p0 = L + lds_slot(base + k, t, log_t); fe* p1 = L + lds_slot(base + k + half, t, log_t); fe* p2 = L + lds_slot(base + k + B, t, log_t); fe* p3 = L + lds_slot(base + k + B + half, t, log_t);
-            const fe_tw tb = W[half - 1 + k];
-            const fe x0 = *p0, x1 = fe_mul_tw(*p1, tb), x2 = *p2, x3 = fe_mul_tw(*p3, tb);
-            fe a0, a1, b2, b3;
-            fe_addsub(x0, x1, a0, a1);
-            fe_addsub(x2, x3, b2, b3);
-            const bool from_global = Wlast != nullptr && s + 1 == log_len;        // the second stage of this round is the last stage
-            const fe_tw t2 = from_global ? Wlast[k] : W[B - 1 + k], t3 = from_global ? Wlast[k + half] : W[B - 1 + k + half];
-            const fe a2 = fe_mul_tw(b2, t2), a3 = fe_mul_tw(b3, t3);
-            fe y0, y1, y2, y3;
-            fe_addsub(a0, a2, y0, y2);
-            fe_addsub(a1, a3, y1, y3);
-            if (fin) { out.put(base + k, t, y0, k0); out.put(base + k + B, t, y2, k2); out.put(base + k + half, t, y1, k1); out.put(base + k + B + half, t, y3, k3); }
-            else { *p0 = y0; *p2 = y2; *p1 = y1; *p3 = y3; }
-        }
-        if (!fin) __syncthreads();
-    }
-    if (s == log_len && s < s_to) {                  // last single stage: blocks of len / 2 into len
-        const uint32_t half = 1u << (log_len - 1);
-        for (uint32_t w = threadIdx.x; w < half * T; w += THREADS) {
-            const uint32_t t = w & (T - 1), k = w >> log_t;
-            typename Out::Tok k0, k1;
-            if (Out::active) { k0 = out.pre(k, t); k1 = out.pre(k + half, t); }
-            fe* p0 = L + lds_slot(k, t, log_t); fe* p1 = L + lds_slot(k + half, t, log_t);
-            const fe u = *p0, v = fe_mul_tw(*p1, Wlast != nullptr ? Wlast[k] : W[half - 1 + k]);
-            fe sum, dif;
-            fe_addsub(u, v, sum, dif);
-            if (Out::active) { out.put(k, t, sum, k0); out.put(k + half, t, dif, k1); }
-            else { *p0 = sum; *p1 = dif; }
-        }
-        if (!Out::active) __syncthreads();
-    }
+    for (; s + 1 <= log_len && s < s_to; s += 2) lds_dit_round<THREADS, Out>(L, W, log_len, log_t, s, Wlast, out);
+    if (s == log_len && s < s_to) lds_dit_tail<THREADS, Out>(L, W, log_len, log_t, Wlast, out);
 }
-
+template <int THREADS, int LOG_LEN, int LOG_T, class Out = NttKeepInLds>
+__device__ __forceinline__ void lds_ntt_dit_fixed(fe* L, const fe_tw* W, const fe_tw* __restrict__ Wlast = nullptr, const Out& out = Out()) {
+    static_for<0, LOG_LEN / 2>([&](auto r_) { constexpr uint32_t s = 1u + 2u * decltype(r_)::value; lds_dit_round<THREADS, Out>(L, W, (uint32_t)LOG_LEN, (uint32_t)LOG_T, s, Wlast, out); });
+    if constexpr (LOG_LEN & 1) lds_dit_tail<THREADS, Out>(L, W, (uint32_t)LOG_LEN, (uint32_t)LOG_T, Wlast, out);
+}

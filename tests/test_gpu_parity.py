@@ -439,7 +439,7 @@ def _random_columns(W, n, seed):
 @pytest.mark.parametrize("family,log_n,log_blowup", [("reg", 13, 5), ("reg", 14, 5), ("reg", 15, 4), ("reg", 16, 5), ("reg", 17, 4), ("reg", 18, 4),
                                                       ("reg", 19, 4), ("reg", 20, 4), ("reg", 21, 4), ("reg", 22, 4), ("reg", 23, 4), ("reg", 24, 4),
                                                       ("lds", 13, 5), ("lds", 16, 5), ("lds", 19, 4), ("lds", 22, 4), ("auto", 21, 4), ("auto", 22, 4), ("auto", 23, 4), ("auto", 24, 4), ("3pass", 20, 5), ("dif", 16, 5), ("dif", 21, 4), ("dit", 16, 5), ("dit", 20, 5), ("dit2", 13, 5), ("dit2", 20, 5),
-                                                      ("waves4", 20, 5), ("waves8", 13, 5), ("waves8", 16, 5), ("order0", 16, 5), ("order0", 20, 5)])
+                                                      ("waves4", 20, 5), ("waves8", 13, 5), ("waves8", 16, 5), ("order0", 16, 5), ("order0", 20, 5), ("generic", 20, 5)])
 def test_lde_every_tile_length(oracle, monkeypatch, family, log_n, log_blowup):
     """Both NTT kernel families (register-radix: every tile length 2^6 .. 2^12 in both passes; LDS radix-2) and the default per-pass
     choice at the largest size, through size-independent properties that pin the
@@ -452,9 +452,13 @@ def test_lde_every_tile_length(oracle, monkeypatch, family, log_n, log_blowup):
     monkeypatch.delenv("DISTAFF_NTT_DIF", raising=False)
     monkeypatch.delenv("DISTAFF_NTT_WAVES", raising=False)
     monkeypatch.delenv("DISTAFF_NTT_ORDER", raising=False)
+    monkeypatch.delenv("DISTAFF_NTT_FIXED", raising=False)
     if family in ("waves4", "waves8"):                                   # LDS family forced to 512 lanes + register prefetch / to 1024 lanes at 8 waves per SIMD
         monkeypatch.delenv("DISTAFF_NTT", raising=False)                # (default: the latter for 1024-point tiles only)
         monkeypatch.setenv("DISTAFF_NTT_WAVES", family[-1])
+    elif family == "generic":                                            # the any-shape instances instead of the ones compiled for 1024 x 4 tiles
+        monkeypatch.delenv("DISTAFF_NTT", raising=False)
+        monkeypatch.setenv("DISTAFF_NTT_FIXED", "0")
     elif family == "order0":                                             # coset-slow block order of the first pass (default: every coset of a tile group first)
         monkeypatch.delenv("DISTAFF_NTT", raising=False)
         monkeypatch.setenv("DISTAFF_NTT_ORDER", "0")
