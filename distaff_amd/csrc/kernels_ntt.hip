@@ -128,17 +128,19 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
     // lane past the tile re-reads element 0.
 #define NTT_EACH(M) { M(0, pre0) M(1, pre1) M(2, pre2) M(3, pre3) M(4, pre4) M(5, pre5) M(6, pre6) M(7, pre7) }
     // uniform base (scalar registers) + 32-bit lane offset: the transform has at most 2^24 points
-#define NTT_FETCH_A1(e, var) if constexpr ((e) < EPT) { uint32_t idx = threadIdx.x + (e) * THREADS; idx = idx < count ? idx : 0u; var = src[((idx >> log_t) << a.log_n2) + (idx & (T - 1))]; }
+#define NTT_FETCH_A1(e, var) if constexpr ((e) < EPT) { uint32_t idx = lane + (e) * THREADS; idx = idx < count ? idx : 0u; var = src[((idx >> log_t) << a.log_n2) + (idx & (T - 1))]; }
 #define NTT_FETCH_A(tile) { const fe* __restrict__ src = src0 + (tile) * T; NTT_EACH(NTT_FETCH_A1) }
     const tw4_t* __restrict__ tw4 = a.tw4 + (size_t)jl * a.tw4_coset_stride;
     const uint32_t tile0 = group * a.tiles_per_block;
+    uint32_t lane = threadIdx.x;
     if (PREFETCH) NTT_FETCH_A(tile0)
     for (uint32_t it = 0; it < a.tiles_per_block; it++) {
         const uint32_t tile = tile0 + it;
+        if constexpr (LOG_LEN != 0) lane = lds_opaque_lane();           // per-tile index arithmetic is recomputed, not kept live (and spilled) across the loop
         if (!PREFETCH) NTT_FETCH_A(tile)
         __syncthreads();                                   // the previous tile has left LDS (and TW is complete)
         // DISTAFF_NTT_DIF: pre-scale + DIF instead of the coset DIT
-#define NTT_PUT_A(e, var) if constexpr ((e) < EPT) { const uint32_t idx = threadIdx.x + (e) * THREADS; if (idx < count) { if (a.dit) L[lds_slot(__brev(idx >> log_t) >> (32 - log_n1), idx & (T - 1), log_t)] = var; else L[lds_slot(idx >> log_t, idx & (T - 1), log_t)] = scaled ? fe_mul_tw(var, a.prescale[(jg * (idx >> log_t)) & pmask]) : var; } }
+#define NTT_PUT_A(e, var) if constexpr ((e) < EPT) { const uint32_t idx = lane + (e) * THREADS; if (idx < count) { if (a.dit) L[lds_slot(__brev(idx >> log_t) >> (32 - log_n1), idx & (T - 1), log_t)] = var; else L[lds_slot(idx >> log_t, idx & (T - 1), log_t)] = scaled ? fe_mul_tw(var, a.prescale[(jg * (idx >> log_t)) & pmask]) : var; } }
         NTT_EACH(NTT_PUT_A)
 #undef NTT_PUT_A
         __syncthreads();
@@ -161,7 +163,7 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
             fe v[RB]; tw4_t w[RB]; uint32_t off[RB]; bool ok[RB];
             static_for<0, RB>([&](auto q_) {
                 constexpr int q = decltype(q_)::value;
-                uint32_t idx = base + q * THREADS + threadIdx.x;
+                uint32_t idx = base + q * THREADS + lane;
                 ok[q] = idx < count;
                 idx = ok[q] ? idx : 0u;
                 const uint32_t t = idx & (T - 1), r = idx >> log_t;
@@ -199,16 +201,18 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_b(NttArgs a, const fe* 
     fe pre0 = fe_zero(), pre1 = fe_zero(), pre2 = fe_zero(), pre3 = fe_zero(), pre4 = fe_zero(), pre5 = fe_zero(), pre6 = fe_zero(), pre7 = fe_zero();
     const uint32_t count = n2 * T;
     // contiguous along m2
-#define NTT_FETCH_B1(e, var) if constexpr ((e) < EPT) { uint32_t idx = threadIdx.x + (e) * THREADS; idx = idx < count ? idx : 0u; var = srct[(idx >> log_n2) * row_stride + (idx & (n2 - 1))]; }
+#define NTT_FETCH_B1(e, var) if constexpr ((e) < EPT) { uint32_t idx = lane + (e) * THREADS; idx = idx < count ? idx : 0u; var = srct[(idx >> log_n2) * row_stride + (idx & (n2 - 1))]; }
 #define NTT_FETCH_B(tile) { const fe* __restrict__ srct = src + (size_t)((tile) * T) * a.src_row_stride; NTT_EACH(NTT_FETCH_B1) }
     const uint32_t row_stride = (uint32_t)a.src_row_stride;
     const uint32_t tile0 = group * a.tiles_per_block;
+    uint32_t lane = threadIdx.x;
     if (PREFETCH) NTT_FETCH_B(tile0)
     for (uint32_t it = 0; it < a.tiles_per_block; it++) {
         const uint32_t k1_0 = (tile0 + it) * T;
+        if constexpr (LOG_LEN != 0) lane = lds_opaque_lane();
         if (!PREFETCH) NTT_FETCH_B(tile0 + it)
         __syncthreads();
-#define NTT_PUT_B(e, var) if constexpr ((e) < EPT) { const uint32_t idx = threadIdx.x + (e) * THREADS; if (idx < count) L[lds_slot(idx & (n2 - 1), idx >> log_n2, log_t)] = var; }
+#define NTT_PUT_B(e, var) if constexpr ((e) < EPT) { const uint32_t idx = lane + (e) * THREADS; if (idx < count) L[lds_slot(idx & (n2 - 1), idx >> log_n2, log_t)] = var; }
         NTT_EACH(NTT_PUT_B)
 #undef NTT_PUT_B
         __syncthreads();

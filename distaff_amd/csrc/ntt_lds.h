@@ -48,13 +48,13 @@ struct NttKeepInLds {
 // lds_dif_round = stages s and s + 1, lds_dif_tail = the distance-1 stage of an odd stage count; every argument but the pointers is
 // uniform, and with literal arguments (lds_ntt_dif_fixed) the index arithmetic folds into immediates.
 template <int THREADS, class Out>
-__device__ __forceinline__ void lds_dif_round(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s, const Out& out) {
+__device__ __forceinline__ void lds_dif_round(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s, const Out& out, uint32_t lane) {
     const uint32_t T = 1u << log_t;
     const uint32_t ld = log_len - s;             // log2 of the first stage's butterfly distance d
     const uint32_t d = 1u << ld, hd = d >> 1;
     const bool last = (s + 1 == log_len);        // second stage has distance 1: its twiddles are 1
     const bool fin = Out::active && last;        // the results of this round leave through `out`
-    for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 2) * T; w += THREADS) {
+    for (uint32_t w = lane; w < ((1u << log_len) >> 2) * T; w += THREADS) {
         const uint32_t t = w & (T - 1), q = w >> log_t;
         const uint32_t pos = q & (hd - 1), blk = q >> (ld - 1);
         const uint32_t i0 = (blk << (ld + 1)) + pos;
@@ -79,9 +79,9 @@ __device__ __forceinline__ void lds_dif_round(fe* L, const fe_tw* W, uint32_t lo
     if (!fin) __syncthreads();
 }
 template <int THREADS, class Out>
-__device__ __forceinline__ void lds_dif_tail(fe* L, uint32_t log_len, uint32_t log_t, const Out& out) {       // distance-1 stage, no twiddles
+__device__ __forceinline__ void lds_dif_tail(fe* L, uint32_t log_len, uint32_t log_t, const Out& out, uint32_t lane) {       // distance-1 stage, no twiddles
     const uint32_t T = 1u << log_t;
-    for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 1) * T; w += THREADS) {
+    for (uint32_t w = lane; w < ((1u << log_len) >> 1) * T; w += THREADS) {
         const uint32_t t = w & (T - 1), q = w >> log_t;
         typename Out::Tok k0, k1;
         if (Out::active) { k0 = out.pre(q << 1, t); k1 = out.pre((q << 1) + 1, t); }
@@ -97,14 +97,24 @@ __device__ __forceinline__ void lds_dif_tail(fe* L, uint32_t log_len, uint32_t l
 template <int THREADS, class Out = NttKeepInLds>
 __device__ __forceinline__ void lds_ntt_dif(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s_from, uint32_t s_to, const Out& out = Out()) {
     uint32_t s = s_from;                             // stages [s_from, s_to), s_from odd
-    for (; s + 1 <= log_len && s < s_to; s += 2) lds_dif_round<THREADS, Out>(L, W, log_len, log_t, s, out);
-    if (s == log_len && s < s_to) lds_dif_tail<THREADS, Out>(L, log_len, log_t, out);
+    for (; s + 1 <= log_len && s < s_to; s += 2) lds_dif_round<THREADS, Out>(L, W, log_len, log_t, s, out, threadIdx.x);
+    if (s == log_len && s < s_to) lds_dif_tail<THREADS, Out>(L, log_len, log_t, out, threadIdx.x);
 }
-// the same transform for a tile shape known at compile time: the rounds are separate code with literal strides
+// The same transform for a tile shape known at compile time: the rounds are separate code with literal strides.  The lane index goes
+// through an empty asm statement per call: the slot addresses of all rounds are invariant over the tiles a workgroup walks through, the
+// compiler would compute them once, keep them live across the loop -- and spill them (measured: 1 GB of scratch reloads per launch).
+__device__ __forceinline__ uint32_t lds_opaque_lane() {
+    uint32_t lane = threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(lane));
+#endif
+    return lane;
+}
 template <int THREADS, int LOG_LEN, int LOG_T, class Out = NttKeepInLds>
 __device__ __forceinline__ void lds_ntt_dif_fixed(fe* L, const fe_tw* W, const Out& out = Out()) {
-    static_for<0, LOG_LEN / 2>([&](auto r_) { constexpr uint32_t s = 1u + 2u * decltype(r_)::value; lds_dif_round<THREADS, Out>(L, W, (uint32_t)LOG_LEN, (uint32_t)LOG_T, s, out); });
-    if constexpr (LOG_LEN & 1) lds_dif_tail<THREADS, Out>(L, (uint32_t)LOG_LEN, (uint32_t)LOG_T, out);
+    const uint32_t lane = lds_opaque_lane();
+    static_for<0, LOG_LEN / 2>([&](auto r_) { constexpr uint32_t s = 1u + 2u * decltype(r_)::value; lds_dif_round<THREADS, Out>(L, W, (uint32_t)LOG_LEN, (uint32_t)LOG_T, s, out, lane); });
+    if constexpr (LOG_LEN & 1) lds_dif_tail<THREADS, Out>(L, (uint32_t)LOG_LEN, (uint32_t)LOG_T, out, lane);
 }
 
 // in-LDS DIT over the first index of L[len][T] for a COSET transform: X[k] = sum_m x[m] * g^m * w_len^(m*k).  The input sits in
@@ -115,11 +125,11 @@ __device__ __forceinline__ void lds_ntt_dif_fixed(fe* L, const fe_tw* W, const O
 // `Wlast` != nullptr: the len/2 twiddles of the LAST stage (half of the coset's table) are not in LDS but read from this global array
 // (contiguous per coset, L2-resident): tile + the other len/2 - 1 pairs then fit the 80 KiB that let two workgroups share a CU.
 template <int THREADS, class Out>
-__device__ __forceinline__ void lds_dit_round(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s, const fe_tw* __restrict__ Wlast, const Out& out) {
+__device__ __forceinline__ void lds_dit_round(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s, const fe_tw* __restrict__ Wlast, const Out& out, uint32_t lane) {
     const uint32_t T = 1u << log_t;
     const uint32_t B = 1u << s, half = B >> 1;                     // first stage merges blocks of size B / 2 into B, second B into 2B
     const bool fin = Out::active && s + 1 == log_len;              // the results of this round leave through `out`
-    for (uint32_t w = threadIdx.x; w < ((1u << log_len) >> 2) * T; w += THREADS) {
+    for (uint32_t w = lane; w < ((1u << log_len) >> 2) * T; w += THREADS) {
         const uint32_t t = w & (T - 1), q = w >> log_t;
         const uint32_t k = q & (half - 1), base = (q >> (s - 1)) << (s + 1);
         typename Out::Tok k0, k1, k2, k3;
@@ -142,10 +152,10 @@ __device__ __forceinline__ void lds_dit_round(fe* L, const fe_tw* W, uint32_t lo
     if (!fin) __syncthreads();
 }
 template <int THREADS, class Out>
-__device__ __forceinline__ void lds_dit_tail(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, const fe_tw* __restrict__ Wlast, const Out& out) {   // last single stage: blocks of len / 2 into len
+__device__ __forceinline__ void lds_dit_tail(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, const fe_tw* __restrict__ Wlast, const Out& out, uint32_t lane) {   // last single stage: blocks of len / 2 into len
     const uint32_t T = 1u << log_t;
     const uint32_t half = 1u << (log_len - 1);
-    for (uint32_t w = threadIdx.x; w < half * T; w += THREADS) {
+    for (uint32_t w = lane; w < half * T; w += THREADS) {
         const uint32_t t = w & (T - 1), k = w >> log_t;
         typename Out::Tok k0, k1;
         if (Out::active) { k0 = out.pre(k, t); k1 = out.pre(k + half, t); }
@@ -161,11 +171,12 @@ __device__ __forceinline__ void lds_dit_tail(fe* L, const fe_tw* W, uint32_t log
 template <int THREADS, class Out = NttKeepInLds>
 __device__ __forceinline__ void lds_ntt_dit(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s_from, uint32_t s_to, const fe_tw* __restrict__ Wlast = nullptr, const Out& out = Out()) {
     uint32_t s = s_from;                             // stages [s_from, s_to), s_from odd
-    for (; s + 1 <= log_len && s < s_to; s += 2) lds_dit_round<THREADS, Out>(L, W, log_len, log_t, s, Wlast, out);
-    if (s == log_len && s < s_to) lds_dit_tail<THREADS, Out>(L, W, log_len, log_t, Wlast, out);
+    for (; s + 1 <= log_len && s < s_to; s += 2) lds_dit_round<THREADS, Out>(L, W, log_len, log_t, s, Wlast, out, threadIdx.x);
+    if (s == log_len && s < s_to) lds_dit_tail<THREADS, Out>(L, W, log_len, log_t, Wlast, out, threadIdx.x);
 }
 template <int THREADS, int LOG_LEN, int LOG_T, class Out = NttKeepInLds>
 __device__ __forceinline__ void lds_ntt_dit_fixed(fe* L, const fe_tw* W, const fe_tw* __restrict__ Wlast = nullptr, const Out& out = Out()) {
-    static_for<0, LOG_LEN / 2>([&](auto r_) { constexpr uint32_t s = 1u + 2u * decltype(r_)::value; lds_dit_round<THREADS, Out>(L, W, (uint32_t)LOG_LEN, (uint32_t)LOG_T, s, Wlast, out); });
-    if constexpr (LOG_LEN & 1) lds_dit_tail<THREADS, Out>(L, W, (uint32_t)LOG_LEN, (uint32_t)LOG_T, Wlast, out);
+    const uint32_t lane = lds_opaque_lane();
+    static_for<0, LOG_LEN / 2>([&](auto r_) { constexpr uint32_t s = 1u + 2u * decltype(r_)::value; lds_dit_round<THREADS, Out>(L, W, (uint32_t)LOG_LEN, (uint32_t)LOG_T, s, Wlast, out, lane); });
+    if constexpr (LOG_LEN & 1) lds_dit_tail<THREADS, Out>(L, W, (uint32_t)LOG_LEN, (uint32_t)LOG_T, Wlast, out, lane);
 }
