@@ -154,8 +154,9 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
         }
         // read-out in batches of RB elements per lane: the twiddle loads of a batch are in flight together (the 512-lane instance also
         // holds eight prefetched elements: a batch of four would spill).  The second passes store from their last butterfly round instead
-        // (OutB); here that costs more than it saves: with the four-step twiddles (and the last-stage pairs from global memory) live in
-        // the last round the kernel spills (measured 13.15 / 13.3 against 13.05 ms).
+        // (OutB); here that does not pay: in the 128-register instances the four-step twiddles (and the last-stage pairs from global memory)
+        // live in the last round spill (13.15 / 13.3 against 13.05 ms), in the spill-free fixed-shape instance it is within the noise
+        // (18.85 against 18.95 ms of extension, with the twiddle requested before or after the butterfly).
         constexpr int RB = WPE > 4 ? 1 : THREADS == 512 ? 2 : 4;
         fe* __restrict__ dst = dst0 + tile * T;          // uniform bases, 32-bit lane offsets
         const tw4_t* __restrict__ tw = tw4 + tile * T;
@@ -458,7 +459,7 @@ static void ntt_raise_lds_limit(dst_ctx* c) {                  // tile + stage t
     (void)hipFuncSetAttribute((const void*)ntt_pass_b<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ntt_pass_a<1024, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ntt_pass_a<1024, 8, false, 10, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)ntt_pass_b<1024, 8, false, 10, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ntt_pass_b<1024, 8, true, 10, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ntt_pass_b<1024, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 
     raised[c->device] = true;
