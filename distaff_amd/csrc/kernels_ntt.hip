@@ -497,7 +497,9 @@ static void ntt_launch(dst_ctx* c, bool pass_b, NttArgs& a, size_t groups, size_
         // 1024-point tiles (five LDS rounds per tile): two workgroups of 1024 lanes = 8 waves per SIMD, 64 registers, no register prefetch -- the
         // other workgroup's rounds cover a workgroup's loads (measured 20.2 against 20.55 ms of extension per 2^20 proof, same box); shorter
         // tiles stay with 512 lanes + prefetch (2^16: 0.96 against 1.03 ms).  DISTAFF_NTT_WAVES=4|8 forces one (the tests run both).
-        if (pass_b && eight && fixed) hipLaunchKernelGGL((ntt_pass_b<1024, 8, false, 10, 2>), grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
+        // the fixed-shape second pass needs 44 registers: its 60-register form with the register prefetch still runs at 8 waves (9.03 -> 8.85 ms
+        // per proof); the first pass with the prefetch spills (12.0 -> 12.3 ms) and stays without
+        if (pass_b && eight && fixed) hipLaunchKernelGGL((ntt_pass_b<1024, 8, true, 10, 2>), grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
         else if (!pass_b && eight && fixed) hipLaunchKernelGGL((ntt_pass_a<1024, 8, false, 10, 2>), grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
         else if (pass_b && eight) hipLaunchKernelGGL((ntt_pass_b<1024, 8, false>), grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
         else if (pass_b) hipLaunchKernelGGL(ntt_pass_b<512>, grid, dim3(512), lds, c->stream, a, a.src, a.dst);
