@@ -459,6 +459,10 @@ static void ntt_raise_lds_limit(dst_ctx* c) {                  // tile + stage t
     (void)hipFuncSetAttribute((const void*)ntt_pass_b<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ntt_pass_a<1024, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ntt_pass_a<1024, 8, false, 10, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ntt_pass_a<1024, 8, false, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ntt_pass_b<1024, 8, false, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ntt_pass_a<512, 4, true, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ntt_pass_b<512, 4, true, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ntt_pass_b<1024, 8, true, 10, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ntt_pass_b<1024, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 
@@ -491,7 +495,9 @@ static void ntt_launch(dst_ctx* c, bool pass_b, NttArgs& a, size_t groups, size_
     KScope ks_(c, name, bytes, true, 18.0 * mults * elements);
     const char* wv = getenv("DISTAFF_NTT_WAVES");
     const bool two = lds <= NTT_LDS_TWO_PER_CU, eight = two && (wv ? wv[0] == '8' : stages >= 10);
-    const bool fixed = stages == 10 && a.tile == 2 && !(getenv("DISTAFF_NTT_FIXED") && getenv("DISTAFF_NTT_FIXED")[0] == '0');   // the 2^20 shape has its own instances
+    const bool any_shape = getenv("DISTAFF_NTT_FIXED") && getenv("DISTAFF_NTT_FIXED")[0] == '0';
+    const bool fixed = stages == 10 && a.tile == 2 && !any_shape;      // 1024 x 4 tiles (n = 2^20) have their own instances,
+    const bool fixed84 = stages == 8 && a.tile == 4 && !any_shape;     // and so have 256 x 16 tiles (n = 2^16, the first two passes of three-pass plans)
     if (a.debug & 1u) ntt_report_occupancy(name, pass_b, eight || !two ? 1024 : 512, eight, lds);
     if (two) {
         // 1024-point tiles (five LDS rounds per tile): two workgroups of 1024 lanes = 8 waves per SIMD, 64 registers, no register prefetch -- the
@@ -501,6 +507,10 @@ static void ntt_launch(dst_ctx* c, bool pass_b, NttArgs& a, size_t groups, size_
         // per proof); the first pass with the prefetch spills (12.0 -> 12.3 ms) and stays without
         if (pass_b && eight && fixed) hipLaunchKernelGGL((ntt_pass_b<1024, 8, true, 10, 2>), grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
         else if (!pass_b && eight && fixed) hipLaunchKernelGGL((ntt_pass_a<1024, 8, false, 10, 2>), grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
+        else if (pass_b && eight && fixed84) hipLaunchKernelGGL((ntt_pass_b<1024, 8, false, 8, 4>), grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
+        else if (!pass_b && eight && fixed84) hipLaunchKernelGGL((ntt_pass_a<1024, 8, false, 8, 4>), grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
+        else if (pass_b && fixed84) hipLaunchKernelGGL((ntt_pass_b<512, 4, true, 8, 4>), grid, dim3(512), lds, c->stream, a, a.src, a.dst);
+        else if (!pass_b && fixed84) hipLaunchKernelGGL((ntt_pass_a<512, 4, true, 8, 4>), grid, dim3(512), lds, c->stream, a, a.src, a.dst);
         else if (pass_b && eight) hipLaunchKernelGGL((ntt_pass_b<1024, 8, false>), grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
         else if (pass_b) hipLaunchKernelGGL(ntt_pass_b<512>, grid, dim3(512), lds, c->stream, a, a.src, a.dst);
         else if (eight) hipLaunchKernelGGL((ntt_pass_a<1024, 8, false>), grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
