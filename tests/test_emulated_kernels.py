@@ -47,6 +47,8 @@ SELECTION = [
     "test_lde_every_tile_length[lds-13-5]",
     "test_lde_every_tile_length[dit2-13-5]",
     "test_lde_every_tile_length[waves8-13-5]",
+    "test_lde_every_tile_length[lds-16-5]",
+    "test_lde_every_tile_length[waves8-16-5]",
     "test_trace_from_pinned_host_memory[w17]",
     "test_synthetic_division_by_power_tables",
 ]
@@ -202,4 +204,43 @@ def test_three_pass_transform_plan_at_small_sizes(emulated_library, tmp_path):
     script.write_text(THREE_PASS_WORKER % {"root": ROOT})
     env = dict(os.environ, DISTAFF_HIP_LIB=emulated_library, DISTAFF_HIP_RUNTIME="none")
     r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    assert r.returncode == 0 and b"ok" in r.stdout, r.stdout.decode()[-3000:]
+
+
+FIXED_SHAPE_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r)
+import numpy as np
+import oracle as O
+import distaff_amd as D
+log_n, log_b, W = 20, 4, 16
+n, B = 1 << log_n, 1 << log_b
+rng = np.random.default_rng(log_n)
+cols = rng.integers(0, 2**63, size=(W, n, 2), dtype=np.uint64)
+ctx = D.Context(log_n, W, 0, 0, log_blowup=log_b)
+ctx.upload(cols)
+ctx.commit_trace()
+g_n, g_N = O.root_of_unity(n), O.root_of_unity(n * B)
+for c in (0, 9):
+    poly = ctx.read_elements("polys").reshape(W, n, 2)[c]
+    lde = ctx.read_elements("lde", c)
+    for k in (0, 1, n - 1, 77777):
+        assert O.poly_eval(poly, O.exp(g_n, k)) == O.to_ints(cols[c, k:k + 1])[0], ("interpolation", c, k)
+    for i in (1, B - 1, B, n * B - 1, 1234567, 7 * n + 5):
+        assert O.poly_eval(poly, O.exp(g_N, i)) == O.to_ints(lde[i:i + 1])[0], ("extension", c, i)
+    assert (lde[::B] == cols[c]).all()
+ctx.close()
+print("ok")
+'''
+
+
+def test_transform_instances_of_the_bench_size(emulated_library, tmp_path):
+    """n = 2^20 runs on instances compiled for its 1024 x 4 tiles (1024-lane workgroups, rounds with literal strides, coset-fast block
+    order): interpolation and a 16-fold extension of 16 random registers on the emulated build against Horner evaluations by the oracle."""
+    script = tmp_path / "fixed_shape_worker.py"
+    script.write_text(FIXED_SHAPE_WORKER % {"root": ROOT})
+    env = dict(os.environ, DISTAFF_HIP_LIB=emulated_library, DISTAFF_HIP_RUNTIME="none")
+    for k in ("DISTAFF_NTT", "DISTAFF_NTT_FIXED", "DISTAFF_NTT_WAVES", "DISTAFF_NTT_ORDER", "DISTAFF_NTT_DIF"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
     assert r.returncode == 0 and b"ok" in r.stdout, r.stdout.decode()[-3000:]
