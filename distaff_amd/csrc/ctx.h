@@ -109,6 +109,7 @@ struct dst_ctx {
 
     // data (device)
     fe *trace = nullptr, *polys = nullptr, *lde = nullptr, *tmp = nullptr;
+    size_t tmp_regs = 4;                // tmp (and tmp2) hold tmp_regs x Bc arrays of n elements
     digest *trace_leaves = nullptr, *trace_nodes = nullptr;
     fe *ceval = nullptr;                // [3][8c][n] combined constraint evaluations (i, f, t), coset-major over the 8n domain
     fe *cwork = nullptr;                // scratch, 3 * 8n

@@ -674,7 +674,7 @@ int k_build_twiddle_tables(dst_ctx* c) {
 }
 
 // how many (coset x column) size-n arrays fit in c->tmp
-static size_t tmp_capacity_arrays(const dst_ctx* c) { return c->Bc * 4; }
+static size_t tmp_capacity_arrays(const dst_ctx* c) { return c->Bc * c->tmp_regs; }
 
 void k_intt_columns(dst_ctx* c, const fe* src, fe* dst, size_t ncols) {
     size_t cap = tmp_capacity_arrays(c);
