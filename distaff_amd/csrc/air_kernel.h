@@ -20,19 +20,19 @@
 #ifndef AIR_WAVES_PER_SIMD
 #define AIR_WAVES_PER_SIMD 2      // caps the kernel at 256 registers per lane
 #endif
-// Waves per SIMD the compiler must make room for.  Two = 256 registers per lane, no scratch.  Three (168 registers, 50-300 bytes of scratch
-// per lane) is faster all the same for every launch but the op-bit one: the third wave fills the carry-chain wait states two waves leave
-// open.  Measured at 2^20 (ms, two -> three waves): Fibonacci shape 4.51 -> 4.31 (stack), 1.76 -> 1.59 (sponge / context), 1.28 -> 1.39
-// (op bits: stays at two); any-shape instance 4.65 -> 4.46, 3.22 -> 3.08, 2.19 -> 2.07; depth <= 8 instance 4.51 -> 4.46, 1.75 -> 1.64,
-// 2.25 -> 2.27 (stays at two).  The per-operation formulation (SLCAP 32) keeps two.
+// Waves per SIMD the compiler must make room for: two = 256 registers per lane, no scratch for every instance but the per-operation
+// formulation.  Three waves (168 registers, 50-300 bytes of scratch per lane) used to be faster (the third wave filled the wait states the
+// carry chains left open: 8.8 -> 8.4 ms for the three Fibonacci-shape launches); since the arithmetic is written in issue order (fe.h) both
+// forms take the same time on a healthy box (7.37 against 7.35 ms) -- and on one box of the pool the scratch-heavy launch ran three times
+// slower (12.7 against 4.3 ms, every other kernel within 8 %): the product build does not depend on scratch.  -DAIR_WAVES_FORCE=3 builds
+// the three-wave form for comparison.
 constexpr int air_waves_per_simd(int sd, int slcap, int sect) {
-    if (AIR_WAVES_PER_SIMD != 2) return AIR_WAVES_PER_SIMD;                    // forced at compile time
+    (void)sd; (void)slcap; (void)sect;
 #ifdef AIR_WAVES_FORCE
-    return AIR_WAVES_FORCE;                                                     // laboratory builds: every instance at this occupancy
+    return AIR_WAVES_FORCE;
+#else
+    return AIR_WAVES_PER_SIMD;
 #endif
-    if (sect == 2 || sect == 3 || slcap == 32) return 2;
-    if (sd == 0 && slcap == 8 && sect == 80) return 2;
-    return 3;
 }
 
 // Rescue matrices (utils/sponge.rs:72-83, utils/hasher.rs:97-113), uploaded once per context to device memory
