@@ -75,7 +75,7 @@ static std::vector<fe> build_periodic_table() {
 }
 
 static void free_all(dst_ctx* c) {
-    void* ptrs[] = {c->tw_lo, c->tw_hi, c->itw_lo, c->itw_hi, c->w1f, c->w2f, c->w1i, c->w2i, c->prescale, c->dit_last, c->tw4_lde, c->tw4_fwd, c->tw4_inv, c->tw4_row_fwd, c->tw4_row_inv, c->w3f, c->w3i, c->tmp2, c->periodic, c->trace, c->polys, c->lde, c->tmp,
+    void* ptrs[] = {c->tw_lo, c->tw_hi, c->itw_lo, c->itw_hi, c->w1f, c->w2f, c->w1i, c->w2i, c->prescale, c->dit_last, c->tw4_lde, c->tw4_fwd, c->tw4_inv, c->tw4_row_fwd, c->tw4_row_inv, c->w3f, c->w3i, c->tmp2, c->periodic, c->trace == c->lde ? nullptr : c->trace, c->polys, c->lde, c->tmp,
                     c->trace_leaves, c->trace_nodes, c->air_consts, c->ceval, c->cwork, c->cpoly, c->cevals, c->cnodes, c->comp_poly, c->comp, c->scratch, c->d_u64, c->d_stage};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& e : c->kpending) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
@@ -196,9 +196,10 @@ static int ctx_init(dst_ctx* c) {
 
     // data buffers
     const size_t n = c->n, Nl = c->Bc * n;
-    if ((r = dev_alloc(c, &c->trace, c->W * n))) return r;
     if ((r = dev_alloc(c, &c->polys, c->W * n))) return r;
     if ((r = dev_alloc(c, &c->lde, c->W * Nl))) return r;
+    if (c->j0 == 0 && c->Bc > 1 && !(getenv("DISTAFF_TRACE_BUFFER") && getenv("DISTAFF_TRACE_BUFFER")[0] == '1')) { c->trace = c->lde; c->trace_stride = Nl; }     // see ctx.h; DISTAFF_TRACE_BUFFER=1: separate buffer + copy (tests)
+    else { if ((r = dev_alloc(c, &c->trace, c->W * n))) return r; c->trace_stride = n; }
     // staging buffer of the two-pass transforms: tmp_regs registers x Bc cosets per pair of launches.  Every launch ends with a partly
     // filled last wave of workgroups (4 registers x 31 cosets at n = 2^20: 7.75 waves of 512 resident workgroups), so as many registers per
     // launch as 12 GiB of staging hold (all 20 at n = 2^20: 39.75 waves, one tail instead of five); at least 4.  DISTAFF_TMP_REGS overrides.
@@ -261,7 +262,7 @@ int dst_phase_ms(const dst_ctx* c, double out_ms[9]) { if (!c || !out_ms) return
 int dst_trace_upload(dst_ctx* c, const uint8_t* const* cols) {
     if (!c || !cols) return DST_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    for (size_t i = 0; i < c->W; i++) HIP_TRY(c, hipMemcpyAsync(c->trace + i * c->n, cols[i], c->n * 16, hipMemcpyHostToDevice, c->stream));
+    for (size_t i = 0; i < c->W; i++) HIP_TRY(c, hipMemcpyAsync(c->trace + i * c->trace_stride, cols[i], c->n * 16, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->upload_pending = false;
     c->have_trace = true; c->committed = c->constraints_done = c->composed = false;
@@ -270,7 +271,7 @@ int dst_trace_upload(dst_ctx* c, const uint8_t* const* cols) {
 int dst_trace_upload_contiguous(dst_ctx* c, const uint8_t* cols) {
     if (!c || !cols) return DST_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipMemcpy(c->trace, cols, c->W * c->n * 16, hipMemcpyHostToDevice));
+    for (size_t i = 0; i < c->W; i++) HIP_TRY(c, hipMemcpy(c->trace + i * c->trace_stride, cols + i * c->n * 16, c->n * 16, hipMemcpyHostToDevice));
     c->upload_pending = false;
     c->have_trace = true; c->committed = c->constraints_done = c->composed = false;
     return DST_OK;
@@ -300,7 +301,7 @@ int dst_trace_upload_async(dst_ctx* c, const uint8_t* const* cols) {
     while (c->upload_done.size() < groups) { hipEvent_t e; HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->upload_done.push_back(e); }
     for (size_t g = 0; g < groups; g++) {
         for (size_t i = c->upload_bounds[g]; i < c->upload_bounds[g + 1]; i++)
-            HIP_TRY(c, hipMemcpyAsync(c->trace + i * c->n, cols[i], c->n * 16, hipMemcpyHostToDevice, c->upload_stream));
+            HIP_TRY(c, hipMemcpyAsync(c->trace + i * c->trace_stride, cols[i], c->n * 16, hipMemcpyHostToDevice, c->upload_stream));
         HIP_TRY(c, hipEventRecord(c->upload_done[g], c->upload_stream));
     }
     c->upload_pending = true;
@@ -320,12 +321,12 @@ int dst_commit_trace(dst_ctx* c, uint8_t trace_root[32]) {
         for (size_t g = 0; g + 1 < c->upload_bounds.size(); g++) {
             const size_t first = c->upload_bounds[g], cnt = c->upload_bounds[g + 1] - first;
             HIP_TRY(c, hipStreamWaitEvent(c->stream, c->upload_done[g], 0));
-            k_intt_columns(c, c->trace + first * c->n, c->polys + first * c->n, cnt);
+            k_intt_columns(c, c->trace + first * c->trace_stride, c->trace_stride, c->polys + first * c->n, cnt);
             k_lde_columns(c, c->polys + first * c->n, c->lde + first * c->Bc * c->n, cnt);
         }
         c->upload_pending = false;
     } else {
-        k_intt_columns(c, c->trace, c->polys, c->W);                 // interpolate_fft_twiddles (trace_table.rs:159)
+        k_intt_columns(c, c->trace, c->trace_stride, c->polys, c->W);   // interpolate_fft_twiddles (trace_table.rs:159)
         k_lde_columns(c, c->polys, c->lde, c->W);                    // eval_fft_twiddles over the LDE domain (trace_table.rs:166)
     }
     HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -335,7 +336,7 @@ int dst_commit_trace(dst_ctx* c, uint8_t trace_root[32]) {
     HIP_TRY(c, hipMemcpyAsync(c->trace_root, c->trace_nodes + 1, 32, hipMemcpyDeviceToHost, c->stream));
     // last state of the un-extended trace: op counter and program hash (evaluator.rs:37,73-74)
     fe last[3];
-    for (int i = 0; i < 3; i++) HIP_TRY(c, hipMemcpyAsync(&last[i], c->trace + (size_t)i * c->n + (c->n - 1), 16, hipMemcpyDeviceToHost, c->stream));
+    for (int i = 0; i < 3; i++) HIP_TRY(c, hipMemcpyAsync(&last[i], c->trace + (size_t)i * c->trace_stride + (c->n - 1), 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     c->op_count = (uint64_t)fe_to_u128(last[0]);

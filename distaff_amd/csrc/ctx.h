@@ -110,6 +110,9 @@ struct dst_ctx {
     // data (device)
     fe *trace = nullptr, *polys = nullptr, *lde = nullptr, *tmp = nullptr;
     size_t tmp_regs = 4;                // tmp (and tmp2) hold tmp_regs x Bc arrays of n elements
+    // register r of the trace starts at trace + r * trace_stride.  A context that owns coset 0 of the extension keeps the trace IN the
+    // coset-0 slots of `lde` (trace == lde, trace_stride == Bc * n): coset 0 of the extension is the trace itself, nothing is copied
+    size_t trace_stride = 0;
     digest *trace_leaves = nullptr, *trace_nodes = nullptr;
     fe *ceval = nullptr;                // [3][8c][n] combined constraint evaluations (i, f, t), coset-major over the 8n domain
     fe *cwork = nullptr;                // scratch, 3 * 8n
@@ -190,7 +193,7 @@ struct KScope {
 extern "C" bool dst_internal_boundary_by_evaluation();                                  // api.hip: DISTAFF_BOUNDARY=eval
 extern "C" int dst_internal_boundary_polys(dst_ctx* c, const fe* draws344, fe* ip, fe* fp);   // api.hip: boundary combinations in coefficient form
 int k_build_twiddle_tables(dst_ctx* c);                                                 // fills tw4_lde / tw4_fwd / tw4_inv (context creation)
-void k_intt_columns(dst_ctx* c, const fe* src, fe* dst, size_t ncols);                  // size-n inverse NTT of ncols contiguous columns
+void k_intt_columns(dst_ctx* c, const fe* src, size_t src_stride, fe* dst, size_t ncols); // size-n inverse NTT of ncols columns src_stride apart -> contiguous columns
 void k_lde_columns(dst_ctx* c, const fe* polys, fe* lde, size_t ncols);                 // n coefficients -> coset-major [Bc][n] per column
 void k_lde_fold8(dst_ctx* c, const fe* poly8n, fe* out);                                // 8n coefficients -> coset-major [Bc][n]
 void k_intt8_cosets(dst_ctx* c, fe* vals /* [8][n] coset-major, in place scratch */, fe* out8n, fe* work);

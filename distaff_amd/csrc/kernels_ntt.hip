@@ -681,11 +681,11 @@ int k_build_twiddle_tables(dst_ctx* c) {
 // how many (coset x column) size-n arrays fit in c->tmp
 static size_t tmp_capacity_arrays(const dst_ctx* c) { return c->Bc * c->tmp_regs; }
 
-void k_intt_columns(dst_ctx* c, const fe* src, fe* dst, size_t ncols) {
+void k_intt_columns(dst_ctx* c, const fe* src, size_t src_stride, fe* dst, size_t ncols) {
     size_t cap = tmp_capacity_arrays(c);
     for (size_t done = 0; done < ncols;) {
         size_t cols = ncols - done < cap ? ncols - done : cap;
-        launch_two_pass(c, src + done * c->n, c->n, 0, dst + done * c->n, c->n, 0, 1, cols, true, false);
+        launch_two_pass(c, src + done * src_stride, src_stride, 0, dst + done * c->n, c->n, 0, 1, cols, true, false);
         done += cols;
     }
 }
@@ -695,7 +695,8 @@ void k_lde_columns(dst_ctx* c, const fe* polys, fe* lde, size_t ncols) {
     // the interpolated trace, it is copied instead of transformed (1/B of the extension work)
     const bool of_trace = polys >= c->polys && polys < c->polys + c->W * c->n;          // a group of the interpolated trace registers
     const uint32_t skip = (c->j0 == 0 && of_trace && c->Bc > 1) ? 1u : 0u;
-    if (skip) (void)hipMemcpy2DAsync(lde, c->Bc * c->n * sizeof(fe), c->trace + (polys - c->polys), c->n * sizeof(fe), c->n * sizeof(fe), ncols, hipMemcpyDeviceToDevice, c->stream);
+    if (skip && c->trace != c->lde)         // a context that owns coset 0 normally keeps the trace in those slots already (ctx.h: trace_stride)
+        (void)hipMemcpy2DAsync(lde, c->Bc * c->n * sizeof(fe), c->trace + ((polys - c->polys) / c->n) * c->trace_stride, c->trace_stride * sizeof(fe), c->n * sizeof(fe), ncols, hipMemcpyDeviceToDevice, c->stream);
     // launch granularity: `bcols` registers x `bcos` cosets per pair of passes (the staging buffer holds tmp_capacity_arrays arrays)
     size_t bcols = tmp_capacity_arrays(c) / c->Bc, bcos = c->Bc - skip;
     if (const char* e = getenv("DISTAFF_LDE_BATCH")) { unsigned x = 0, y = 0; if (sscanf(e, "%u,%u", &x, &y) == 2 && x >= 1 && y >= 1 && (size_t)x * y <= tmp_capacity_arrays(c)) { bcols = x; bcos = y; } }

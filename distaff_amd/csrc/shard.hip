@@ -82,12 +82,12 @@ int dst_shard_commit_trace(dst_ctx* c) {
     if (r) return r;
     c->sharded_layout = true;
     for (bool& b : c->tree_krange) b = false;                  // dst_prove_sharded switches trees to k-ranges as it exchanges them
-    k_intt_columns(c, c->trace, c->polys, c->W);
+    k_intt_columns(c, c->trace, c->trace_stride, c->polys, c->W);
     k_lde_columns(c, c->polys, c->lde, c->W);
     k_trace_leaves(c);
     k_merkle_levels_to(c, c->trace_leaves, c->trace_nodes, c->Bc * c->n, c->n);
     fe last[3];
-    for (int i = 0; i < 3; i++) HIP_TRY(c, hipMemcpyAsync(&last[i], c->trace + (size_t)i * c->n + (c->n - 1), 16, hipMemcpyDeviceToHost, c->stream));
+    for (int i = 0; i < 3; i++) HIP_TRY(c, hipMemcpyAsync(&last[i], c->trace + (size_t)i * c->trace_stride + (c->n - 1), 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     c->op_count = (uint64_t)fe_to_u128(last[0]);

@@ -51,6 +51,7 @@ SELECTION = [
     "test_lde_every_tile_length[waves8-16-5]",
     "test_trace_from_pinned_host_memory[w17]",
     "test_synthetic_division_by_power_tables",
+    "test_trace_in_its_own_buffer",
 ]
 
 

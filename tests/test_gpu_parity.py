@@ -88,6 +88,15 @@ def test_fibonacci_all_phases(oracle, log_n):
     _check_all_phases(oracle, D, oracle.fibonacci_trace(1 << log_n))
 
 
+def test_trace_in_its_own_buffer(oracle, monkeypatch):
+    """A context that owns coset 0 of the extension keeps the trace in the coset-0 slots of the extension buffer (nothing is copied);
+    DISTAFF_TRACE_BUFFER=1 gives the trace its own buffer and copies it into coset 0, as contexts of the other ranks of a sharded proof
+    do for their interpolation input.  Same intermediates, same proof."""
+    import distaff_amd as D
+    monkeypatch.setenv("DISTAFF_TRACE_BUFFER", "1")
+    _check_all_phases(oracle, D, oracle.fibonacci_trace(1 << 10))
+
+
 def test_synthetic_division_by_power_tables(oracle, monkeypatch):
     """k_syn_div's first formulation (scale by b^t, additive suffix scan, scale by b^-(i+1)) is kept beside the blocked one; both give the
     oracle's quotients (polynom.rs:190) -- at 2^12 steps the blocked form recurses once (16 chunks of 2048 coefficients)."""
