@@ -86,3 +86,16 @@ def test_c_abi_header_is_plain_c_and_links(tmp_path):
     if not torch.cuda.is_available():                      # without a GPU the host fails loudly at context creation (no CPU fallback)
         r = subprocess.run([exe, "8"], capture_output=True, text=True)
         assert r.returncode == 1 and "dst_ctx_create" in r.stderr
+
+
+def test_limb_level_field_arithmetic_on_the_host(tmp_path):
+    """fe.h's gfx950 formulations (windowed and table-pair multiplication, the nine-limb reduction with its overflow limb, sum/difference
+    pairs, sums of products) are written over carry primitives that have a plain-integer host form: tools/felab/host_test.cpp runs
+    that dataflow on 6 million random and edge-case operands against the portable multiplication, which the oracle tests pin.  (The
+    device form of the same primitives -- one instruction each -- is pinned on the GPU by test_device_field_arithmetic.)"""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "fe_host_test"
+    subprocess.check_call(["g++", "-O2", "-o", str(exe), os.path.join(root, "tools", "felab", "host_test.cpp")])
+    r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert r.returncode == 0 and b"bad=0" in r.stdout, r.stdout.decode()[-2000:]
