@@ -61,6 +61,57 @@ def cpu_baseline(log_n, blowup=32, queries=50):
             "prove_ms": dt * 1e3, "phase_ms": [round(x, 1) for x in p.phase_ms]}
 
 
+def pmc_row(kernel):
+    """Row of `kernel` in the newest committed PMC summary (profiles/*_pmc_per_kernel.csv) -- or (None, reason) when there is none, when
+    it carries no stamp, or when its stamp (digest of distaff_amd/csrc at the time of the rocprofv3 passes) differs from the sources of
+    this run.  Kernel names are compared without blanks and with template booleans as 0 / 1 (the library's event names print them so)."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_per_kernel.csv")))
+    if not files:
+        return None, "no PMC summary under profiles/"
+    meta_path = files[-1].replace("_pmc_per_kernel.csv", "_meta.json")
+    if not os.path.exists(meta_path):
+        return None, os.path.basename(files[-1]) + " carries no stamp"
+    meta = json.load(open(meta_path))
+    if meta.get("csrc_sha16") != csrc_digest():
+        return None, "%s was taken on kernel sources %s, this run is %s: refused" % (os.path.basename(files[-1]), meta.get("csrc_sha16"), csrc_digest())
+
+    def norm(name):
+        return name.replace("void ", "").replace(" ", "").replace("false", "0").replace("true", "1")
+    with open(files[-1], newline="") as fh:
+        for row in csv.DictReader(fh):
+            if norm(row["kernel"]).startswith(norm(kernel)):
+                return row, "%s (git %s)" % (os.path.basename(files[-1]), str(meta.get("git_head"))[:10])
+    return None, "kernel not in " + os.path.basename(files[-1])
+
+
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4        # wave-instructions per second: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
+
+
+def valu_issue(stats, proof_ms, steps):
+    """Share of the VALU issue slots the kernels of one proof fill: SQ_INSTS_VALU per launch (committed, stamped PMC summary) x the
+    launches of this run, against 1024 SIMDs x 2.4 GHz / 4 cycles.  `stats`: {kernel: {"launches", "ms"}} over `steps` proofs."""
+    per_kernel, total, missing = {}, 0.0, []
+    for name, st in stats.items():
+        row, _ = pmc_row(name)
+        if row is None or not row.get("SQ_INSTS_VALU"):
+            if st["ms"] / steps >= 0.05:
+                missing.append(name)
+            continue
+        insts = float(row["SQ_INSTS_VALU"]) * st["launches"]
+        total += insts
+        if st["ms"] / steps >= 0.5:
+            per_kernel[name] = round(insts / (st["ms"] * 1e-3) / VALU_ISSUE_PEAK, 4)
+    if total == 0:
+        return None
+    return {"unit": "wave64 VALU instructions/s", "peak": VALU_ISSUE_PEAK, "proof_achieved": total / steps / (proof_ms * 1e-3),
+            "proof_frac": round(total / steps / (proof_ms * 1e-3) / VALU_ISSUE_PEAK, 4), "kernel_frac": per_kernel,
+            "not_counted": missing, "note": "instruction counts per launch from the stamped rocprofv3 summary, launch times of this run; "
+            "the SQ_INSTS_VALU of a kernel name is the average over its launches of a proof, so kernels whose launches differ in size are exact for the whole proof only"}
+
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,22 +271,10 @@ def main():
         """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command (profiles/README.md): FETCH_SIZE
         doubled (gfx950 correction for wide coalesced reads) + WRITE_SIZE, both converted from KiB.  Only a summary whose stamp
         (profiles/<tag>_meta.json: digest of the kernel sources) matches the sources of THIS run is accepted: a stale one gives null."""
-        import csv
-        import glob
-        files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_per_kernel.csv")))
-        if not files:
-            return None, "no PMC summary under profiles/"
-        meta_path = files[-1].replace("_pmc_per_kernel.csv", "_meta.json")
-        if not os.path.exists(meta_path):
-            return None, os.path.basename(files[-1]) + " carries no stamp"
-        meta = json.load(open(meta_path))
-        if meta.get("csrc_sha16") != csrc_digest():
-            return None, "%s was taken on kernel sources %s, this run is %s: refused" % (os.path.basename(files[-1]), meta.get("csrc_sha16"), csrc_digest())
-        with open(files[-1], newline="") as fh:
-            for row in csv.DictReader(fh):
-                if row["kernel"].replace("void ", "").replace(" ", "").startswith(kernel.replace(" ", "")) and row["fetch_bytes_per_launch_x2"] and row["write_bytes_per_launch_raw"]:
-                    return int(row["fetch_bytes_per_launch_x2"]) + int(row["write_bytes_per_launch_raw"]), "%s (git %s)" % (os.path.basename(files[-1]), str(meta.get("git_head"))[:10])
-        return None, "kernel not in " + os.path.basename(files[-1])
+        row, source = pmc_row(kernel)
+        if row is None or not row.get("fetch_bytes_per_launch_x2") or not row.get("write_bytes_per_launch_raw"):
+            return None, source
+        return int(row["fetch_bytes_per_launch_x2"]) + int(row["write_bytes_per_launch_raw"]), source
     default_workload = log_n == 20 and world == 1 and (blowup, args.queries) == (32, 50)     # what the committed PMC passes were taken on
     if dom[0]:
         name, st = dom
@@ -292,6 +331,10 @@ def main():
     alu["proof"] = {"mads": proof_mads, "achieved": proof_mads / (ms_per_step * 1e-3), "frac": round(proof_mads / (ms_per_step * 1e-3) / mad_peak, 4),
                     "counted_kernels": sorted(k for k, v in counted.items() if v > 0),
                     "note": "multiply-adds of the NTT passes and the constraint kernels (the other kernels' are not counted) over the whole proof time"}
+    try:
+        alu["valu_issue"] = valu_issue(all_stats, ms_per_step, 1) if default_workload else None      # all_stats: the launches of ONE proof
+    except Exception as e:                                           # noqa: BLE001  (never lose the bench line over a summary file)
+        alu["valu_issue"] = {"error": str(e)}
     # ALU ceiling: dependent-chain modular multiplications per second measured on this device with the same fe_mul
     mm_ms = ctx.bench_mulmod(1 << 21, 512)
     mulmod_peak = (1 << 21) * 512 * 4 / (mm_ms * 1e-3)
