@@ -99,3 +99,26 @@ def test_limb_level_field_arithmetic_on_the_host(tmp_path):
     subprocess.check_call(["g++", "-O2", "-o", str(exe), os.path.join(root, "tools", "felab", "host_test.cpp")])
     r = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert r.returncode == 0 and b"bad=0" in r.stdout, r.stdout.decode()[-2000:]
+
+
+def test_bench_reads_the_stamped_counter_summary():
+    """bench.py takes counter-derived figures (roofline.traffic, alu_roofline.valu_issue) from profiles/*_pmc_per_kernel.csv only while the
+    summary's stamp equals the digest of the kernel sources; kernel names match with or without blanks and with template booleans as
+    0 / 1.  With a stale summary every lookup is refused with a reason -- never a number from other code."""
+    import json, os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    import bench
+    row, why = bench.pmc_row("ntt_pass_a")
+    meta = json.load(open(sorted(p for p in (os.path.join(root, "profiles", f) for f in os.listdir(os.path.join(root, "profiles"))) if p.endswith("_meta.json"))[-1]))
+    if meta["csrc_sha16"] != bench.csrc_digest():
+        assert row is None and "refused" in why
+        assert bench.valu_issue({"ntt_pass_a": {"launches": 5, "ms": 12.0}}, 38.0, 1) is None
+        return
+    assert row is not None and float(row["SQ_INSTS_VALU"]) > 0 and int(row["fetch_bytes_per_launch_x2"]) > 0
+    assert bench.pmc_row("air_kernel<2,1,4,8,88,0,1>")[0] is not None          # the library prints template booleans as 0 / 1, rocprofv3 as false / true
+    assert bench.pmc_row("no_such_kernel")[0] is None
+    line = json.loads(open(os.path.join(root, "profiles", "r2_bench_default.json")).read().strip().splitlines()[-1])
+    stats = {k: {"launches": v["launches"], "ms": v["ms_per_step"]} for k, v in line["kernels"].items()}
+    v = bench.valu_issue(stats, line["ms_per_step"], 1)
+    assert 0.5 < v["proof_frac"] < 1.0 and all(0.3 < f < 1.0 for f in v["kernel_frac"].values()) and not v["not_counted"]
