@@ -78,7 +78,9 @@ def pmc_row(kernel):
         return None, "%s was taken on kernel sources %s, this run is %s: refused" % (os.path.basename(files[-1]), meta.get("csrc_sha16"), csrc_digest())
 
     def norm(name):
-        return name.replace("void ", "").replace(" ", "").replace("false", "0").replace("true", "1")
+        import re
+        name = name.replace("void ", "").replace(" ", "").replace("false", "0").replace("true", "1")
+        return re.sub(r"(\d+)u\b", r"\1", re.sub(r"\(unsignedint\)(\d+)", r"\1", name))       # unsigned template arguments: 240u / (unsigned int)240
     with open(files[-1], newline="") as fh:
         for row in csv.DictReader(fh):
             if norm(row["kernel"]).startswith(norm(kernel)):

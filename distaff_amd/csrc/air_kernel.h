@@ -16,7 +16,16 @@
 #include "ctx.h"
 #include <type_traits>
 
+#ifndef AIR_THREADS
 #define AIR_THREADS 128
+#endif
+// AIR_CONVOY (experiment, tools/ab_variant.sh): workgroup barriers between the sections of a launch keep the wavefronts of a workgroup
+// at about the same program counter, so that they share the instruction-cache lines of straight-line code
+#ifdef AIR_CONVOY
+#define AIR_SYNC() __builtin_amdgcn_s_barrier()
+#else
+#define AIR_SYNC()
+#endif
 #ifndef AIR_WAVES_PER_SIMD
 #define AIR_WAVES_PER_SIMD 2      // caps the kernel at 256 registers per lane
 #endif
@@ -46,6 +55,7 @@ struct AirArgs {
     const fe* periodic;          // [128][23]: 8 sponge ark, 12 hasher ark, 3 masks
     const AirConsts* consts;
     fe* partial;                 // [7][Q][n] partial sums between launches
+    fe* ev[10];                  // [Q][n] each: partial values of the stack constraints between launches (slots 0..7, two auxiliary)
     const fe* tw_lo; const fe* tw_hi; uint32_t lo_bits;
     unsigned long long* bad_step;
     size_t n, col_stride;        // col_stride = Bc * n
@@ -129,7 +139,7 @@ __device__ __forceinline__ fe st_term(const StackRows& s) {
     auto R = [&](int num) { return fe_sub(o[i - num < 0 ? 0 : i - num], nw[i]); };   // right shift by num (callers: i >= num)
     auto C = [&]() { return fe_sub(o[i], nw[i]); };                       // copy
     auto sel = [&](const fe& c, const fe& x, const fe& y) { return fe_add(y, fe_mul(c, fe_sub(x, y))); };   // c*x + (1-c)*y with one multiplication
-    if constexpr (OP == 0x00) { if constexpr (I == ST_AUX0) return fe_mul(s.hd0, bnot(o[0])); else return fe_mul(s.hd0, L(1)); }   // ASSERT flag carries hd[0] (trace_state.rs:346)
+    if constexpr (OP == 0x00) { if constexpr (I == ST_AUX0) return bnot(o[0]); else return L(1); }   // the ASSERT flag carries hd[0] (trace_state.rs:346): st_output puts it into the coefficient
     else if constexpr (OP == 0x01) { if constexpr (I == ST_AUX0) return fe_sub(o[0], o[1]); else return L(2); }
     else if constexpr (OP == 0x02) {
         const fe diff = fe_sub(o[1], o[2]);
@@ -200,18 +210,113 @@ __device__ __forceinline__ fe st_term(const StackRows& s) {
     else return fe_zero();
 }
 
-// slot I of the low-degree part: the three nested sums
+// ---- which operations a launch evaluates ---------------------------------------------------------------------------------------------
+// The stack constraints are linear in the operation flags, so a launch may evaluate any subset of the operations for all slots and hand
+// the partial values on through memory (AirArgs::ev); the launch that holds the last subset emits the constraints.  Cutting by operation
+// group rather than by slot keeps what a launch has to derive first small: the low-degree groups of one `c` need lo2, mid and one top
+// entry, the high-degree / flow operations the four hd flags -- and no straight-line kernel grows past the 64 KiB instruction cache of a
+// CU pair (tools/codeobj_info.py, gated by build()).
+//   bits 0..3: low-degree operations 4b .. 4b+3 (c = 0), bits 4..7: 16 + 4b .. (c = 1), then PUSH, CMP, RESCR, BEGIN / NOOP ("keep"),
+//   and the slots >= 8 of the deep instance.
+#define AG_LOW(c, b) (1u << ((c) * 4 + (b)))
+#define AG_LOW0 0x00Fu
+#define AG_LOW1 0x0F0u
+#define AG_PUSH 0x100u
+#define AG_CMP 0x200u
+#define AG_RESCR 0x400u
+#define AG_KEEP 0x800u
+#define AG_HIGH 0xF00u
+#define AG_DEEP 0x1000u
+#define AG_STACK_ALL 0x1FFFu
+// FLAGS of a launch: FIRST / LAST in the chain of partial sums (res, adj[6]); EV_IN: partial stack values come in; EV_OUT: they go out
+// (else this launch emits the stack constraints)
+#define AF_FIRST 1
+#define AF_LAST 2
+#define AF_EV_IN 4
+#define AF_EV_OUT 8
+
+// What term(op, slot) is, for the terms that are plain differences of stack items: kind 1: o[j] - nw[I], 2: nw[I] - o[j], 3: nw[I],
+// 4: -nw[I], 5: anything else (st_term computes it), 0: the operation does not constrain the slot.  SDK = compile-time stack depth (0:
+// known at run time only): items o[j], j >= SDK, are zeros then (trace_state.rs:58-60 pads the slice), which turns differences into +-nw[I]
+// and removes the selector of CHOOSE2 / CSWAP2 (item 4).  DEEP: the slice may be longer than 8, left shifts past item 7 stay with st_term.
+struct StDesc { int kind, j; };
+template <int SDK, bool DEEP>
+constexpr StDesc st_desc(int op, int I) {
+    const bool o4_zero = SDK != 0 && SDK <= 4;
+    if (I >= 8) {                                                      // auxiliary constraints: computed; j >= 100 names values that several operations share
+        if ((op == 0x0A || op == 0x0B)) return StDesc{5, I == ST_AUX0 ? 100 : 101};         // is_bin(o[0]) / is_bin(o[1])
+        if ((op == 0x06 || op == 0x07) && o4_zero) return StDesc{0, 0};                     // is_bin(o[4]) of a zero
+        return StDesc{5, -1};
+    }
+    const int i = I;
+    auto diff = [&](int j) { return (SDK != 0 && j >= SDK) ? StDesc{4, 0} : StDesc{1, j}; };
+    auto rdiff = [&](int j) { return (SDK != 0 && j >= SDK) ? StDesc{3, 0} : StDesc{2, j}; };
+    auto L = [&](int num) { return i + num < 8 ? diff(i + num) : (DEEP ? StDesc{5, -1} : StDesc{3, 0}); };
+    auto R = [&](int num) { return diff(i - num < 0 ? 0 : i - num); };
+    switch (op) {
+        case 0x00: return L(1);
+        case 0x01: return L(2);
+        case 0x02: return i == 0 ? StDesc{5, -1} : L(2);
+        case 0x03: return L(1);
+        case 0x04: return L(4);
+        case 0x05: return i == 0 ? StDesc{5, -1} : L(2);
+        case 0x06: return i < 2 ? (o4_zero ? rdiff(i + 2) : StDesc{5, -1}) : L(4);          // selector o[4] = 0: the second operand
+        case 0x07: return i < 4 ? (o4_zero ? rdiff(i) : StDesc{5, -1}) : L(2);
+        case 0x08: case 0x0B: return i == 0 ? StDesc{5, -1} : L(1);
+        case 0x09: case 0x0A: return i == 0 ? StDesc{5, 102} : L(1);                         // MUL and AND: nw[0] - o[0] * o[1]
+        case 0x0C: case 0x0D: case 0x0E: return i == 0 ? StDesc{5, -1} : diff(i);
+        case 0x10: return R(1);
+        case 0x11: return R(2);
+        case 0x12: return i == 0 ? rdiff(0) : R(1);
+        case 0x13: return i < 2 ? rdiff(i) : R(2);
+        case 0x14: return i < 4 ? rdiff(i) : R(4);
+        case 0x15: return i < 2 ? StDesc{3, 0} : R(2);
+        case 0x18: return i == 0 ? StDesc{5, -1} : diff(i);
+        case 0x19: return i < 4 ? rdiff(i ^ 2) : diff(i);
+        case 0x1A: return rdiff(i ^ 4);
+        case 0x1B: return i < 4 ? rdiff((i + 3) & 3) : diff(i);
+        case 0x1C: return rdiff((i + 7) & 7);
+        case 0x1D: return i == 1 ? StDesc{3, 0} : (i < 4 ? StDesc{5, -1} : diff(i));
+        default: return StDesc{0, 0};
+    }
+}
+// operations of one group (4 consecutive opcodes) whose terms for slot I coincide up to sign share ONE product: entry e of the merge
+// holds the basis term (kind / j of its first member) and the sign of every member's coefficient relative to it
+struct StMerge { int n; int kind[4], j[4], lead[4]; int sgn[4][4]; };
+template <int BASE, int I, int SDK, bool DEEP>
+constexpr StMerge st_merge() {
+    StMerge m{};
+    for (int a = 0; a < 4; a++) {
+        const StDesc d = st_desc<SDK, DEEP>(BASE + a, I);
+        // has the operation a term here at all?  (st_has is the authority: st_desc only classifies)
+        bool has = false;
+        switch (a) { case 0: has = st_has<BASE, I>(); break; case 1: has = st_has<BASE + 1, I>(); break; case 2: has = st_has<BASE + 2, I>(); break; default: has = st_has<BASE + 3, I>(); }
+        if (!has || d.kind == 0) continue;
+        const int cls = d.kind == 5 ? 5 : (d.kind <= 2 ? 1 : 3);           // 1: differences with o[j], 3: +-nw[I], 5: computed
+        const int sign = (d.kind == 2 || d.kind == 4) ? -1 : 1;
+        int e = -1;
+        for (int k = 0; k < m.n; k++) {
+            const int kc = m.kind[k] == 5 ? 5 : (m.kind[k] <= 2 ? 1 : 3);
+            if (kc != cls) continue;
+            if (cls == 3 || (cls == 1 && m.j[k] == d.j) || (cls == 5 && d.j >= 100 && m.j[k] == d.j)) e = k;
+        }
+        if (e < 0) { e = m.n++; m.kind[e] = d.kind; m.j[e] = d.j; m.lead[e] = a; m.sgn[e][a] = 1; }
+        else { const int lead_sign = (m.kind[e] == 2 || m.kind[e] == 4) ? -1 : 1; m.sgn[e][a] = sign * lead_sign; }
+    }
+    return m;
+}
+
 // The operations selected by the high-degree bits and the flow flags join the outermost sum of a slot (one more product each,
 // no separate multiplication and modular addition): PUSH (input.rs:6), CMP (comparison.rs:64-105), RESCR (hash.rs:9-35; its six
 // differences are computed once by the caller), BEGIN / NOOP (stack untouched).
-struct StackHigh { fe push, cmp, rescr, keep; fe resc[6]; bool on; };       // the four flags; on = false: low-degree part only
+struct StackHigh { fe push, cmp, rescr, keep; fe resc[6]; };       // the four flags and the RESCR differences
 
-template <int I>
+template <int I, uint32_t GROUPS>
 __device__ __forceinline__ void st_high_degree(fe_acc& outer, const StackRows& s, const StackHigh& h) {
     if constexpr (I < 8) {
         const fe* o = s.o; const fe* nw = s.nw;
-        if constexpr (I >= 1) fe_acc_mac(outer, h.push, fe_sub(o[I - 1 < 0 ? 0 : I - 1], nw[I]));
-        {
+        if constexpr (I >= 1 && (GROUPS & AG_PUSH) != 0) fe_acc_mac(outer, h.push, fe_sub(o[I - 1 < 0 ? 0 : I - 1], nw[I]));
+        if constexpr ((GROUPS & AG_CMP) != 0) {
             const fe x_bit = nw[1], y_bit = nw[2], not_set = nw[3];
             fe v;
             if constexpr (I == 0) v = is_bin(x_bit);
@@ -224,35 +329,66 @@ __device__ __forceinline__ void st_high_degree(fe_acc& outer, const StackRows& s
             else v = fe_sub(fe_double(nw[0]), o[0]);
             fe_acc_mac(outer, h.cmp, v);
         }
-        const fe keep = fe_sub(o[I < 8 ? I : 0], nw[I < 8 ? I : 0]);
-        if constexpr (I < 6) fe_acc_mac(outer, h.rescr, h.resc[I < 6 ? I : 0]); else fe_acc_mac(outer, h.rescr, keep);
-        fe_acc_mac(outer, h.keep, keep);
+        if constexpr ((GROUPS & (AG_RESCR | AG_KEEP)) != 0) {
+            const fe keep = fe_sub(o[I < 8 ? I : 0], nw[I < 8 ? I : 0]);
+            if constexpr ((GROUPS & AG_RESCR) != 0) { if constexpr (I < 6) fe_acc_mac(outer, h.rescr, h.resc[I < 6 ? I : 0]); else fe_acc_mac(outer, h.rescr, keep); }
+            if constexpr ((GROUPS & AG_KEEP) != 0) fe_acc_mac(outer, h.keep, keep);
+        }
     }
 }
 
-// slot I of the stack constraints: the three nested sums of the low-degree part, plus the high-degree / flow operations
-template <int I>
-__device__ __forceinline__ fe st_low_degree(const StackRows& s, const fe* lo2, const fe* mid, const fe* top, const StackHigh& h) {
+// does the launch's selection contribute anything to output I?  (the auxiliary constraints only hear from low-degree operations of c = 0)
+template <int I, uint32_t GROUPS> constexpr bool st_touches() {
+    if (I >= 8) return (GROUPS & AG_LOW0) != 0;
+    return (GROUPS & (AG_LOW0 | AG_LOW1 | AG_HIGH)) != 0;
+}
+
+// output I (slot 0..7, ST_AUX0, ST_AUX1) of the selected operations:
+//     sum_c top[c] * ( sum_b mid[b] * ( sum_e coefficient_e * basis term_e ) )  +  high-degree / flow flags * their terms
+// every level one sum of products with a single reduction (fe_acc); coefficient_e = +-lo2[a] summed over the merged members
+// (lo0h = lo2[0] * hd[0] stands for lo2[0] in group 0: the ASSERT flag carries hd[0], trace_state.rs:346)
+template <int I, uint32_t GROUPS, int SDK, bool DEEP>
+__device__ __forceinline__ fe st_output(const StackRows& s, const fe* lo2, const fe& lo0h, const fe* mid, const fe* top, const StackHigh& h) {
     fe_acc outer; fe_acc_zero(outer);
     static_for_air<0, 2>([&](auto c_) {
         constexpr int c = decltype(c_)::value;
-        fe_acc middle; fe_acc_zero(middle);
-        static_for_air<0, 4>([&](auto b_) {
-            constexpr int b = decltype(b_)::value;
-            constexpr int base = 4 * b + 16 * c;
-            constexpr bool any = st_has<base, I>() || st_has<base + 1, I>() || st_has<base + 2, I>() || st_has<base + 3, I>();
-            if constexpr (any) {
-                fe_acc inner; fe_acc_zero(inner);
-                static_for_air<0, 4>([&](auto a_) {
-                    constexpr int a = decltype(a_)::value;
-                    if constexpr (st_has<base + a, I>()) fe_acc_mac(inner, lo2[a], st_term<base + a, I>(s));
-                });
-                fe_acc_mac(middle, mid[b], fe_acc_reduce(inner));
-            }
-        });
-        fe_acc_mac(outer, top[c], fe_acc_reduce(middle));
+        if constexpr (((GROUPS >> (4 * c)) & 0xFu) != 0) {
+            fe_acc middle; fe_acc_zero(middle);
+            static_for_air<0, 4>([&](auto b_) {
+                constexpr int b = decltype(b_)::value;
+                constexpr int base = 4 * b + 16 * c;
+                if constexpr ((GROUPS & AG_LOW(c, b)) != 0) {
+                    static constexpr StMerge M = st_merge<base, I, SDK, DEEP>();
+                    if constexpr (M.n > 0) {
+                        fe_acc inner; fe_acc_zero(inner);
+                        static_for_air<0, M.n>([&](auto e_) {
+                            constexpr int e = decltype(e_)::value;
+                            // coefficient: the leader's, plus / minus the other members'
+                            fe cf = (base == 0 && M.lead[e] == 0) ? lo0h : lo2[M.lead[e]];
+                            static_for_air<0, 4>([&](auto a_) {
+                                constexpr int a = decltype(a_)::value;
+                                if constexpr (a != M.lead[e] && M.sgn[e][a] != 0) {
+                                    const fe other = (base == 0 && a == 0) ? lo0h : lo2[a];
+                                    cf = M.sgn[e][a] > 0 ? fe_add(cf, other) : fe_sub(cf, other);
+                                }
+                            });
+                            constexpr int ii = I < 8 ? I : 0;
+                            fe term;
+                            if constexpr (M.kind[e] == 1) term = fe_sub(s.o[M.j[e]], s.nw[ii]);
+                            else if constexpr (M.kind[e] == 2) term = fe_sub(s.nw[ii], s.o[M.j[e]]);
+                            else if constexpr (M.kind[e] == 3) term = s.nw[ii];
+                            else if constexpr (M.kind[e] == 4) term = fe_neg(s.nw[ii]);
+                            else term = st_term<base + M.lead[e], I>(s);
+                            fe_acc_mac(inner, cf, term);
+                        });
+                        fe_acc_mac(middle, mid[b], fe_acc_reduce(inner));
+                    }
+                }
+            });
+            fe_acc_mac(outer, top[c], fe_acc_reduce(middle));
+        }
     });
-    if (h.on) st_high_degree<I>(outer, s, h);
+    if constexpr ((GROUPS & AG_HIGH) != 0) st_high_degree<I, GROUPS>(outer, s, h);
     return fe_acc_reduce(outer);
 }
 
@@ -277,12 +413,16 @@ struct Acc {
 // CL, LL: compile-time capacities of the context / loop stack slices (>= a.cl, a.ll).
 // SD: compile-time user stack depth, or 0 when the depth is only known at run time (then SLCAP bounds the slice length).
 // Only the first `stack_depth` stack constraints are emitted (stack/mod.rs:194), so with SD known the unused slots vanish.
-// SECT selects which constraint sections this launch evaluates (bit 0 boundary, 1 op bits, 2 sponge/context/loop, 3 stack:
-// low-degree ops that move items, 5 stack: low-degree arithmetic / selection ops, 4 stack: PUSH / CMP / BEGIN / NOOP, 6 stack: RESCR).  The combination is linear in the constraints, so a launch that is
-// not FIRST starts from the partial sums (res, adj[6]) left by the previous launch and one that is not LAST stores them;
-// splitting the evaluation this way keeps the live state of each launch within the register budget.
-template <int CL, int LL, int SD, int SLCAP, int SECT, bool FIRST, bool LAST>
+// SECT selects the constraint sections of this launch: bit 0 boundary, 1 op bits, 2 sponge, 7 loop image + context / loop stacks; for the per-operation
+// formulation (the instance with SLCAP == 32) also 3 stack: low-degree ops that move items, 5 stack: low-degree arithmetic / selection
+// ops, 4 stack: PUSH / CMP / BEGIN / NOOP, 6 stack: RESCR.  The nested-sum instances select stack OPERATIONS with GROUPS (AG_*).
+// The combination is linear in the constraints, so a launch that is not FIRST starts from the partial sums (res, adj[6]) left by the
+// previous launch and one that is not LAST stores them; the stack constraints themselves are linear in the operation flags, so their
+// partial values travel the same way (AF_EV_IN / AF_EV_OUT) and are emitted by the launch that completes them.  Splitting the evaluation
+// this way keeps the live state of each launch within the register budget and its code within the instruction cache.
+template <int CL, int LL, int SD, int SLCAP, int SECT, uint32_t GROUPS, int FLAGS>
 __global__ void __launch_bounds__(AIR_THREADS, air_waves_per_simd(SD, SLCAP, SECT)) air_kernel(AirArgs a) {
+    constexpr bool FIRST = (FLAGS & AF_FIRST) != 0, LAST = (FLAGS & AF_LAST) != 0, EV_IN = (FLAGS & AF_EV_IN) != 0, EV_OUT = (FLAGS & AF_EV_OUT) != 0;
     constexpr int SL = SD ? (SD > 8 ? SD : 8) : SLCAP;
     // SLCAP == 12 is the deep instance: any stack depth; slots 0..7 as nested sums from 12 register-resident items of the current
     // row, slots 8.. from memory as seven flag sums times shifted differences (see the stack section)
@@ -360,6 +500,7 @@ __global__ void __launch_bounds__(AIR_THREADS, air_waves_per_simd(SD, SLCAP, SEC
         }
     }
 
+    AIR_SYNC();
     // ---- op flags (trace_state.rs:281-350) -----------------------------------------------------------------------------
     fe cff[8], hdf[4], begin_flag, noop_flag, n_void, assert_flag;
     // low-degree op flags are products of three small tables and are formed where they are used:
@@ -389,6 +530,7 @@ __global__ void __launch_bounds__(AIR_THREADS, air_waves_per_simd(SD, SLCAP, SEC
         assert_flag = fe_mul(ld0, hd[0]);                              // ASSERT (trace_state.rs:346)
     }
 
+    AIR_SYNC();
     const fe* per = a.periodic + (size_t)(step & 127u) * 23;
     // specialised instances: every group a launch without op bits emits into; with op bits (five groups) only degree 2, which
     // takes ten of its fifteen constraints
@@ -467,6 +609,9 @@ __global__ void __launch_bounds__(AIR_THREADS, air_waves_per_simd(SD, SLCAP, SEC
             }
         }
         acc.emit(15, 3, sp[0]); acc.emit(16, 4, sp[1]); acc.emit(17, 3, sp[2]); acc.emit(18, 3, sp[3]);
+    }
+    if constexpr ((SECT & 128) != 0) {
+        const fe f_begin = cff[1], f_tend = cff[2], f_fend = cff[3], f_loop = cff[4], f_wrap = cff[5], f_break = cff[6], f_void = cff[7];
         // loop image (WRAP, BREAK)
         acc.emit(19, 2, fe_mul(fe_add(f_wrap, f_break), fe_sub(c_sp[0], c_lp[0])));
         // context stack: BEGIN/LOOP push sponge[0]; TEND/FEND pop; WRAP/BREAK/VOID copy
@@ -498,8 +643,65 @@ __global__ void __launch_bounds__(AIR_THREADS, air_waves_per_simd(SD, SLCAP, SEC
     }
 
     // ---- stack constraints (constraints/stack/mod.rs:117-195) ---------------------------------------------------------------
-    if constexpr ((SECT & 120) != 0) {
-        constexpr int SLR = DEEP ? 8 : SL;                  // slots whose constraints are formed in registers
+    constexpr bool NESTED = SD == 4 || (SD == 0 && SLCAP == 8) || DEEP;      // depth 4 exactly, any depth <= 8 (all 8 slots, `sd` of them emitted), or the first 8 slots of a deeper stack
+    static_assert(NESTED ? (SECT & 120) == 0 : GROUPS == 0, "nested-sum instances select stack operations with GROUPS, the per-operation instance with SECT");
+    if constexpr (NESTED && (GROUPS & AG_STACK_ALL & ~AG_DEEP) != 0) {
+        // low-degree operations as nested sums over the merged terms of each group (st_output), high-degree / flow operations inside the
+        // outermost sum; outputs: slots 0..NS-1, ST_AUX0, ST_AUX1
+        constexpr int NS = SD == 4 ? 4 : 8;
+        StackRows rows;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { rows.o[i] = o[i]; rows.nw[i] = nw[i]; }
+#pragma unroll
+        for (int i = 8; i < 12; i++) rows.o[i] = DEEP ? o[i < SL ? i : 0] : fe_zero();
+        rows.hd0 = hd[0];
+        rows.sl = DEEP ? sl : 8;
+        const fe lo0h = fe_mul(lo2[0], hd[0]);                       // ASSERT = LDF(0) * hd[0] (trace_state.rs:346)
+        StackHigh high;
+        high.push = hdf[0]; high.cmp = hdf[1]; high.rescr = hdf[2]; high.keep = fe_add(begin_flag, noop_flag);
+        if constexpr ((GROUPS & AG_RESCR) != 0) {
+            // hash.rs:9-35.  Items at and above a known depth are zeros: their round-constant cubes come from the periodic table's
+            // values alone, and the inverse-matrix rows are shorter.
+            constexpr int NZ = (SD != 0 && SD < 6) ? SD : 6;         // items that can be non-zero
+            fe os[6], ns[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) os[i] = fe_cube(i < NZ ? fe_add(o[i], per[8 + i]) : per[8 + i]);
+            matmul<6>(os, c_hasher_mds);
+            constexpr int NR = NS < 6 ? NS : 6;                      // differences that are used
+#pragma unroll
+            for (int i = 0; i < NR; i++) {
+                fe_acc A; fe_acc_zero(A);
+#pragma unroll
+                for (int j = 0; j < NZ; j++) fe_acc_mac(A, c_hasher_inv_mds[i * 6 + j], nw[j]);
+                ns[i] = fe_acc_reduce(A);
+            }
+#pragma unroll
+            for (int i = 0; i < NR; i++) high.resc[i] = fe_sub(fe_sub(fe_cube(ns[i]), per[14 + i]), os[i]);
+        }
+        AIR_SYNC();
+        const uint32_t sbase = 20 + cl + ll;
+        static_for_air<0, NS + 2>([&](auto k_) {
+            constexpr int kk = decltype(k_)::value;
+            constexpr int I = kk < NS ? kk : (kk == NS ? ST_AUX0 : ST_AUX1);
+            constexpr bool touched = st_touches<I, GROUPS>();
+            // a launch that neither completes the constraints nor contributes to this one leaves the partial value where it is
+            if constexpr (touched || !EV_OUT) {
+                if (I >= 8 || I < sd) {
+                    fe v = fe_zero();
+                    if constexpr (touched) v = st_output<I, GROUPS, SD, DEEP>(rows, lo2, lo0h, mid, top, high);
+                    fe* slot = a.ev[I] + pidx;
+                    if constexpr (EV_IN) v = touched ? fe_add(v, *slot) : *slot;
+                    if constexpr (EV_OUT) *slot = v;
+                    else acc.emit(I >= 8 ? sbase + (I - 8) : sbase + 2 + I, 4, v);
+                }
+            } else if constexpr (!EV_IN) {
+                a.ev[I][pidx] = fe_zero();                           // the first stack launch defines every partial value
+            }
+            AIR_SYNC();
+        });
+    }
+    if constexpr (!NESTED && (SECT & 120) != 0) {
+        constexpr int SLR = SL;                  // slots whose constraints are formed in registers
         fe ev[SLR], aux0 = fe_zero(), aux1 = fe_zero();
 #pragma unroll
         for (int i = 0; i < SLR; i++) ev[i] = fe_zero();
@@ -520,44 +722,7 @@ __global__ void __launch_bounds__(AIR_THREADS, air_waves_per_simd(SD, SLCAP, SEC
             }
         };
         fe f;
-        constexpr bool NESTED = SD == 4 || (SD == 0 && SLCAP == 8) || DEEP;      // depth 4 exactly, any depth <= 8 (all 8 slots, `sd` of them emitted), or the first 8 slots of a deeper stack
-        constexpr bool HD_FUSED = NESTED && (SECT & 88) == 88;             // the whole stack in one launch: high-degree ops join the nested sums
-        if constexpr (NESTED && (SECT & 8) != 0) {
-            // all low-degree operations (both halves) as nested sums, see st_low_degree
-            StackRows rows;
-#pragma unroll
-            for (int i = 0; i < 8; i++) { rows.o[i] = o[i]; rows.nw[i] = nw[i]; }
-#pragma unroll
-            for (int i = 8; i < 12; i++) rows.o[i] = DEEP ? o[i < SL ? i : 0] : fe_zero();
-            rows.hd0 = hd[0];
-            rows.sl = DEEP ? sl : 8;
-            StackHigh high;
-            high.on = HD_FUSED;
-            if constexpr (HD_FUSED) {
-                high.push = hdf[0]; high.cmp = hdf[1]; high.rescr = hdf[2]; high.keep = fe_add(begin_flag, noop_flag);
-                fe os[6], ns[6];
-#pragma unroll
-                for (int i = 0; i < 6; i++) os[i] = fe_cube(fe_add(o[i], per[8 + i]));
-                matmul<6>(os, c_hasher_mds);
-#pragma unroll
-                for (int i = 0; i < 6; i++) ns[i] = nw[i];
-                matmul<6>(ns, c_hasher_inv_mds);
-#pragma unroll
-                for (int i = 0; i < 6; i++) high.resc[i] = fe_sub(fe_sub(fe_cube(ns[i]), per[14 + i]), os[i]);
-            }
-            ev[0] = st_low_degree<0>(rows, lo2, mid, top, high);
-            ev[1] = st_low_degree<1>(rows, lo2, mid, top, high);
-            ev[2] = st_low_degree<2>(rows, lo2, mid, top, high);
-            ev[3] = st_low_degree<3>(rows, lo2, mid, top, high);
-            if constexpr (SD != 4) {
-                ev[4] = st_low_degree<4>(rows, lo2, mid, top, high);
-                ev[5] = st_low_degree<5>(rows, lo2, mid, top, high);
-                ev[6] = st_low_degree<6>(rows, lo2, mid, top, high);
-                ev[7] = st_low_degree<7>(rows, lo2, mid, top, high);
-            }
-            aux0 = st_low_degree<ST_AUX0>(rows, lo2, mid, top, high);
-            aux1 = st_low_degree<ST_AUX1>(rows, lo2, mid, top, high);
-        }
+        constexpr bool HD_FUSED = false;
         if constexpr (!NESTED && (SECT & 8) != 0) {
         // flags that only shift / copy are merged before the multiplications
         // right shift by 1: READ (0x10), DUP (0x12)  (PUSH is with the high-degree ops)
@@ -698,7 +863,10 @@ __global__ void __launch_bounds__(AIR_THREADS, air_waves_per_simd(SD, SLCAP, SEC
         if constexpr ((SECT & 40) != 0) { acc.emit(sbase, 4, aux0); acc.emit(sbase + 1, 4, aux1); }    // only low-degree ops touch the aux constraints
 #pragma unroll
         for (int i = 0; i < SLR; i++) if (i < sd) acc.emit(sbase + 2 + i, 4, ev[i]);
-        if constexpr (DEEP && (SECT & 16) != 0) {
+    }
+    if constexpr (DEEP && (GROUPS & AG_DEEP) != 0) {
+        {
+            const uint32_t sbase = 20 + cl + ll;
             // Slots 8 .. sd-1 of a deep stack.  No operation computes anything there: a slot is copied, or takes the item 1, 2 or 4
             // places to its left or right (left shifts zero-fill the end of the slice), constraints/stack/mod.rs:117-195 with the
             // shift helpers :199-262.  So the constraint is a sum of seven products, flag sum * (shifted old item - new item), and
@@ -741,7 +909,8 @@ __global__ void __launch_bounds__(AIR_THREADS, air_waves_per_simd(SD, SLCAP, SEC
     // the partial sums of the previous launches join at the end (they are not live during the evaluation); a launch only moves the
     // degree-group sums its sections emit into: op bits {2,3,4,6,8}, sponge / context / loop {4,6,7}, stack {7}
     acc.res = fe_acc_reduce(acc.res_acc);
-    constexpr uint32_t USED = ((SECT & 2) ? 0x2Fu : 0u) | ((SECT & 4) ? 0x1Cu : 0u) | ((SECT & 120) ? 0x10u : 0u);
+    constexpr bool EMITS_STACK = (SECT & 120) != 0 || (GROUPS & AG_DEEP) != 0 || ((GROUPS & AG_STACK_ALL) != 0 && !EV_OUT);
+    constexpr uint32_t USED = ((SECT & 2) ? 0x2Fu : 0u) | ((SECT & 4) ? 0x18u : 0u) | ((SECT & 128) ? 0x04u : 0u) | (EMITS_STACK ? 0x10u : 0u);
 #pragma unroll
     for (int i = 0; i < 6; i++) if (((ACC_MASK & USED) >> i) & 1u) acc.adj[i] = fe_add(acc.adj[i], fe_acc_reduce(acc.adj_acc[i]));
     if constexpr (!FIRST) {
@@ -774,12 +943,15 @@ __global__ void __launch_bounds__(AIR_THREADS, air_waves_per_simd(SD, SLCAP, SEC
 }
 
 
-template <int CL, int LL, int SD, int SLCAP, int SECT, bool FIRST, bool LAST>
+template <int CL, int LL, int SD, int SLCAP, int SECT, uint32_t GROUPS, int FLAGS>
 static void launch_air(dst_ctx* c, const AirArgs& a, uint32_t Q) {
     dim3 g((unsigned)((c->n + AIR_THREADS - 1) / AIR_THREADS), Q);
-    static char name[48];          // one name per instantiation, matching the template arguments rocprofv3 prints
-    if (!name[0]) snprintf(name, sizeof(name), "air_kernel<%d,%d,%d,%d,%d,%d,%d>", CL, LL, SD, SLCAP, SECT, (int)FIRST, (int)LAST);
-    { KScope ks_(c, name, 16.0 * c->n * Q * (c->W + (FIRST ? 0 : 7) + (LAST ? 1 : 7) + ((SECT & 1) ? 2 : 0)), true); hipLaunchKernelGGL((air_kernel<CL, LL, SD, SLCAP, SECT, FIRST, LAST>), g, dim3(AIR_THREADS), 0, c->stream, a); }
+    static char name[64];          // one name per instantiation, matching the template arguments rocprofv3 prints
+    if (!name[0]) snprintf(name, sizeof(name), "air_kernel<%d,%d,%d,%d,%d,%u,%d>", CL, LL, SD, SLCAP, SECT, (unsigned)GROUPS, FLAGS);
+    // algorithmic bytes: the W registers of a row, the partial sums that come in and go out, the stack partial values, the result
+    constexpr int NS = SD == 4 ? 6 : 10;
+    const double units = c->W + ((FLAGS & AF_FIRST) ? 0 : 7) + ((FLAGS & AF_LAST) ? 1 : 7) + ((SECT & 1) ? 2 : 0) + ((FLAGS & AF_EV_IN) ? NS : 0) + ((FLAGS & AF_EV_OUT) ? NS : 0);
+    { KScope ks_(c, name, 16.0 * c->n * Q * units, true); hipLaunchKernelGGL((air_kernel<CL, LL, SD, SLCAP, SECT, GROUPS, FLAGS>), g, dim3(AIR_THREADS), 0, c->stream, a); }
 }
 // instances live in their own translation units (compile time): Fibonacci shape, small stacks, fully generic
 void air_launch_sd4(dst_ctx* c, const AirArgs& a, uint32_t Q);      // cl <= 2, ll <= 1, stack_depth == 4

@@ -259,9 +259,17 @@ void dst_ctx_destroy(dst_ctx* c) { if (!c) return; hipSetDevice(c->device); free
 const char* dst_last_error(const dst_ctx* c) { return c ? c->err.c_str() : g_create_error.c_str(); }
 int dst_phase_ms(const dst_ctx* c, double out_ms[9]) { if (!c || !out_ms) return DST_ERR_ARG; for (int i = 0; i < 9; i++) out_ms[i] = c->phase_ms[i]; return DST_OK; }
 
+// an asynchronous upload still in flight writes the same buffer from upload_stream: drain it before another upload starts
+static int drain_pending_upload(dst_ctx* c) {
+    if (c->upload_pending && c->upload_stream) HIP_TRY(c, hipStreamSynchronize(c->upload_stream));
+    c->upload_pending = false;
+    return DST_OK;
+}
+
 int dst_trace_upload(dst_ctx* c, const uint8_t* const* cols) {
     if (!c || !cols) return DST_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    { int rd = drain_pending_upload(c); if (rd) return rd; }
     for (size_t i = 0; i < c->W; i++) HIP_TRY(c, hipMemcpyAsync(c->trace + i * c->trace_stride, cols[i], c->n * 16, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->upload_pending = false;
@@ -271,6 +279,7 @@ int dst_trace_upload(dst_ctx* c, const uint8_t* const* cols) {
 int dst_trace_upload_contiguous(dst_ctx* c, const uint8_t* cols) {
     if (!c || !cols) return DST_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
+    { int rd = drain_pending_upload(c); if (rd) return rd; }
     for (size_t i = 0; i < c->W; i++) HIP_TRY(c, hipMemcpy(c->trace + i * c->trace_stride, cols + i * c->n * 16, c->n * 16, hipMemcpyHostToDevice));
     c->upload_pending = false;
     c->have_trace = true; c->committed = c->constraints_done = c->composed = false;
@@ -292,6 +301,9 @@ int dst_trace_upload_async(dst_ctx* c, const uint8_t* const* cols) {
     if (!c || !cols) return DST_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     if (!c->upload_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->upload_stream, hipStreamNonBlocking));
+    { int rd = drain_pending_upload(c); if (rd) return rd; }
+    // the previous proof's kernels may still read the buffer on c->stream (coset 0 of the extension IS the trace buffer)
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     // groups of 4 registers (one extension launch, see k_lde_columns) -- except that the first group is ONE register: its transfer is the
     // only one nothing overlaps with
     c->upload_bounds.clear();

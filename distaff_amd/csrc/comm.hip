@@ -32,7 +32,7 @@ RcclApi* rccl_api() {
         // a process that already holds an RCCL (PyTorch-ROCm ships one) keeps using that copy: same soname
         const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
         for (const char* nm : names) { api.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL); if (api.handle) break; }
-        if (!api.handle) { api.error = std::string("librccl.so could not be loaded: ") + (dlerror() ? dlerror() : "?"); return; }
+        if (!api.handle) { const char* e = dlerror(); api.error = std::string("librccl.so could not be loaded: ") + (e ? e : "?"); return; }      // dlerror() clears the state: call it once
         auto sym = [&](const char* s) { void* p = dlsym(api.handle, s); if (!p && api.error.empty()) api.error = std::string("librccl.so lacks ") + s; return p; };
         api.GetUniqueId = (int (*)(ncclUniqueId*))sym("ncclGetUniqueId");
         api.CommInitRank = (int (*)(ncclComm_t*, int, ncclUniqueId, int))sym("ncclCommInitRank");
@@ -157,7 +157,7 @@ struct CallbackComm : dst_comm {
 };
 }  // namespace
 
-static std::string g_comm_error;
+static thread_local std::string g_comm_error;      // errors before a communicator exists, per calling thread (ranks may be threads)
 
 extern "C" {
 

@@ -480,18 +480,13 @@ FE_HD fe fe_cube(const fe& a) { return fe_mul(fe_sqr(a), a); }
 // b^e for a 128-bit exponent given as limbs (0^e = 0, b^0 = 1 for b != 0, as field.rs:201-203)
 FE_HD fe fe_pow(fe b, const fe& e) {
     if (fe_is_zero(b)) return fe_zero();
+    // square-and-multiply from the low bit; the exponent is shifted through four scalars (no run-time indexed limb array: no scratch)
+    uint32_t w0 = e.v[0], w1 = e.v[1], w2 = e.v[2], w3 = e.v[3];
     fe r = fe_one();
-    for (int l = 0; l < 4; l++) {
-        uint32_t w = e.v[l];
-        bool rest = false;
-        for (int k = l + 1; k < 4; k++) rest |= e.v[k] != 0;
-        for (int i = 0; i < 32; i++) {
-            if (w & 1) r = fe_mul(r, b);
-            w >>= 1;
-            if (w == 0 && !rest) break;
-            b = fe_sqr(b);
-        }
-        if (!rest) break;
+    while ((w0 | w1 | w2 | w3) != 0) {
+        if (w0 & 1u) r = fe_mul(r, b);
+        w0 = (w0 >> 1) | (w1 << 31); w1 = (w1 >> 1) | (w2 << 31); w2 = (w2 >> 1) | (w3 << 31); w3 >>= 1;
+        if ((w0 | w1 | w2 | w3) != 0) b = fe_sqr(b);
     }
     return r;
 }

@@ -5,13 +5,13 @@
 void air_launch_generic(dst_ctx* c, const AirArgs& a, uint32_t Q) {
     // any shape the VM can produce (up to 16 context, 8 loop and 32 stack registers, known at run time), per-operation formulation,
     // cut into the same section launches as the specialised instances
-    launch_air<16, 8, 0, 32, 2, true, false>(c, a, Q);     // op bits
-    if (dst_internal_boundary_by_evaluation()) launch_air<16, 8, 0, 32, 1, false, false>(c, a, Q);    // boundary (normally in coefficient form, api.hip)
-    launch_air<16, 8, 0, 32, 4, false, false>(c, a, Q);    // sponge, loop image, context / loop stacks
-    launch_air<16, 8, 0, 32, 8, false, false>(c, a, Q);    // stack: low-degree ops that move items
-    launch_air<16, 8, 0, 32, 32, false, false>(c, a, Q);   // stack: low-degree arithmetic / selection ops
-    launch_air<16, 8, 0, 32, 16, false, false>(c, a, Q);   // stack: PUSH, CMP, BEGIN / NOOP
-    launch_air<16, 8, 0, 32, 64, false, true>(c, a, Q);    // stack: RESCR + combination
+    launch_air<16, 8, 0, 32, 2, 0, AF_FIRST>(c, a, Q);     // op bits
+    if (dst_internal_boundary_by_evaluation()) launch_air<16, 8, 0, 32, 1, 0, 0>(c, a, Q);    // boundary (normally in coefficient form, api.hip)
+    launch_air<16, 8, 0, 32, 132, 0, 0>(c, a, Q);          // sponge, loop image, context / loop stacks
+    launch_air<16, 8, 0, 32, 8, 0, 0>(c, a, Q);            // stack: low-degree ops that move items
+    launch_air<16, 8, 0, 32, 32, 0, 0>(c, a, Q);           // stack: low-degree arithmetic / selection ops
+    launch_air<16, 8, 0, 32, 16, 0, 0>(c, a, Q);           // stack: PUSH, CMP, BEGIN / NOOP
+    launch_air<16, 8, 0, 32, 64, 0, AF_LAST>(c, a, Q);     // stack: RESCR + combination
 }
 
 
@@ -25,6 +25,14 @@ int k_eval_constraints(dst_ctx* c, const fe* coeffs_dev, const fe* tc_dev, int64
     }
     AirArgs a{};
     a.lde = c->lde; a.out = c->ceval; a.coef = coeffs_dev; a.tc = tc_dev; a.periodic = c->periodic; a.consts = (const AirConsts*)c->air_consts; a.partial = c->cwork;
+    // partial values of the stack constraints between launches: buffers that are idle during the evaluation -- the staging buffer of the
+    // transforms (>= 4 registers x Bc cosets = (B / 2) of these arrays for B >= 16) and the two polynomials written after this phase
+    {
+        const size_t per = (size_t)(c->Bc / (c->B / 8)) * c->n;
+        if (8 * per > c->Bc * c->tmp_regs * c->n) { c->err = "constraint evaluation: staging buffer too small for the stack partial values"; return DST_ERR_STATE; }
+        for (int i = 0; i < 8; i++) a.ev[i] = c->tmp + (size_t)i * per;
+        a.ev[8] = c->cpoly; a.ev[9] = c->comp_poly;
+    }
     a.tw_lo = c->tw_lo; a.tw_hi = c->tw_hi; a.lo_bits = c->tw_lo_bits;
     a.bad_step = (unsigned long long*)c->d_u64;
     a.n = c->n; a.col_stride = c->Bc * c->n;

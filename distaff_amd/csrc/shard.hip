@@ -82,6 +82,11 @@ int dst_shard_commit_trace(dst_ctx* c) {
     if (r) return r;
     c->sharded_layout = true;
     for (bool& b : c->tree_krange) b = false;                  // dst_prove_sharded switches trees to k-ranges as it exchanges them
+    if (c->upload_pending) {
+        // dst_trace_upload_async: the copies run on upload_stream; the transforms below read every register, so they wait for every group
+        for (size_t g = 0; g + 1 < c->upload_bounds.size(); g++) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->upload_done[g], 0));
+        c->upload_pending = false;
+    }
     k_intt_columns(c, c->trace, c->trace_stride, c->polys, c->W);
     k_lde_columns(c, c->polys, c->lde, c->W);
     k_trace_leaves(c);
@@ -718,16 +723,19 @@ int tree_exchange(dst_ctx* c, dst_comm* comm, uint32_t what, uint32_t arg, uint8
 }  // namespace
 
 int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t* proof_out, size_t cap, size_t* proof_len) {
-    if (!c || !comm || !pub || !proof_len) return DST_ERR_ARG;
-    if (comm->world != c->prm.world || comm->rank != c->prm.rank) { c->err = "dst_prove_sharded: the communicator's rank / world differ from the context's"; return DST_ERR_ARG; }
-    HIP_TRY(c, hipSetDevice(c->device));
+    if (!c || !comm) return DST_ERR_ARG;                      // nothing to agree through: the caller's bug, peers are its to stop
+    // Rank-local pre-flight failures must not leave the peers waiting in the first collective: they travel with the first status word.
+    int pre = DST_OK;
+    if (!pub || !proof_len) { c->err = "dst_prove_sharded: null argument"; pre = DST_ERR_ARG; }
+    else if (comm->world != c->prm.world || comm->rank != c->prm.rank) { c->err = "dst_prove_sharded: the communicator's rank / world differ from the context's"; pre = DST_ERR_ARG; }
+    else if (hipSetDevice(c->device) != hipSuccess) { c->err = "dst_prove_sharded: hipSetDevice failed"; pre = DST_ERR_HIP; }
     const size_t G = comm->world;
     Agree agree{c, comm};
     int rc;
     double t0 = wall_ms_shard();
     auto mark = [&](int i) { const double t = wall_ms_shard(); c->phase_ms[i] = t - t0; t0 = t; };
     // steps 1-2
-    if ((rc = agree(dst_shard_commit_trace(c), "extension"))) return rc;
+    if ((rc = agree(pre ? pre : dst_shard_commit_trace(c), "extension"))) return rc;
     mark(0);
     uint8_t trace_root[32], constraint_root[32];
     if ((rc = agree(tree_exchange(c, comm, SH_TRACE_TREE, 0, trace_root), "trace tree"))) return rc;
@@ -826,6 +834,11 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
 // with the trace uploaded), one thread per context, in-process transport.  Every context's proof is identical; the first is returned.
 int dst_prove_sharded_local(dst_ctx** ctxs, uint32_t world, const dst_public* pub, uint8_t* proof_out, size_t cap, size_t* proof_len) {
     if (!ctxs || !pub || !proof_len || world == 0 || world > 8) return DST_ERR_ARG;
+    // validated BEFORE the rank threads exist: a thread that returned early would leave the others in the first barrier
+    for (uint32_t r = 0; r < world; r++) {
+        if (!ctxs[r]) return DST_ERR_ARG;
+        if (ctxs[r]->prm.world != world || ctxs[r]->prm.rank != r) { ctxs[r]->err = "dst_prove_sharded_local: context " + std::to_string(r) + " was not created as rank " + std::to_string(r) + " of " + std::to_string(world); return DST_ERR_ARG; }
+    }
     std::vector<dst_comm*> comms(world, nullptr);
     int rc = dst_comm_init_local(world, comms.data());
     if (rc) return rc;

@@ -49,7 +49,7 @@ def air_key(demangled):
     if not m:
         return None
     args = [a.strip() for a in m.group(1).split(",")]
-    args = ["1" if a == "true" else "0" if a == "false" else a for a in args]
+    args = ["1" if a == "true" else "0" if a == "false" else re.sub(r"^(?:\(unsigned int\))?(\d+)u?$", r"\1", a) for a in args]
     return "air_kernel<" + ",".join(args) + ">"
 
 
