@@ -114,6 +114,59 @@ def valu_issue(stats, proof_ms, steps):
 
 
 
+def box_fingerprint(ctx, mad_peak, mulmod_peak):
+    """What tells one box of the pool from another: the two arithmetic calibrations, the straight-line-code probe (dst_bench_code: time per
+    instruction of 176 KiB of code against 16 KiB -- 1.0 on a healthy device), device name / CU count and rocm-smi's clocks and partition modes."""
+    import subprocess
+    import torch
+    box = {"mad_peak": mad_peak, "mulmod_peak": mulmod_peak}
+    try:
+        props = torch.cuda.get_device_properties(torch.cuda.current_device())
+        box["device"] = props.name
+        box["compute_units"] = props.multi_processor_count
+        box["hbm_GiB"] = round(props.total_memory / 2**30, 1)
+    except Exception as e:                                           # noqa: BLE001
+        box["device_error"] = str(e)
+    try:
+        t16, t176 = ctx.bench_code(16), ctx.bench_code(176)
+        box["code_probe"] = {"ms_16KiB": round(t16, 4), "ms_176KiB": round(t176, 4), "per_instruction_ratio": round((t176 / 176.0) / (t16 / 16.0), 3),
+                             "note": "2^23 lanes, 128 per workgroup, two waves per SIMD, every wavefront runs the code once (kernels_probe.hip)"}
+    except Exception as e:                                           # noqa: BLE001
+        box["code_probe"] = {"error": str(e)}
+    try:
+        r = subprocess.run(["rocm-smi", "--showclocks", "--showcomputepartition", "--showmemorypartition", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=20)
+        smi = json.loads(r.stdout.decode() or "{}")
+        card = smi.get("card%d" % torch.cuda.current_device()) or (list(smi.values())[0] if smi else {})
+        box["rocm_smi"] = {k: v for k, v in card.items() if any(t in k.lower() for t in ("sclk", "mclk", "fclk", "socclk", "partition"))}
+    except Exception as e:                                           # noqa: BLE001
+        box["rocm_smi"] = {"error": str(e)}
+    return box
+
+
+def kernel_rooflines(stats, steps, default_workload, top=5):
+    """Per kernel of the timed region (the heavy kernels are bracketed by HIP events on the launch stream), largest total time first: the
+    HBM fraction of its algorithmic bytes, the counter traffic and the VALU-issue fraction (stamped PMC summary of the same command)."""
+    rows = []
+    for name, st in sorted(stats.items(), key=lambda kv: -kv[1]["ms"])[:top]:
+        if st["launches"] == 0 or st["ms"] <= 0:
+            continue
+        per_launch_ms = st["ms"] / st["launches"]
+        per_launch_bytes = st["bytes"] / st["launches"]
+        achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
+        row, source = pmc_row(name) if default_workload else (None, "PMC passes exist for the default workload only")
+        traffic = None
+        if row is not None and row.get("fetch_bytes_per_launch_x2") and row.get("write_bytes_per_launch_raw"):
+            traffic = int(row["fetch_bytes_per_launch_x2"]) + int(row["write_bytes_per_launch_raw"])
+        valu = None
+        if row is not None and row.get("SQ_INSTS_VALU"):
+            valu = round(float(row["SQ_INSTS_VALU"]) / (per_launch_ms * 1e-3) / VALU_ISSUE_PEAK, 4)
+        rows.append({"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                     "traffic": traffic, "traffic_over_algorithmic": None if traffic is None else round(traffic / per_launch_bytes, 2), "traffic_source": source,
+                     "valu_issue_frac": valu, "ms_per_step": round(st["ms"] / steps, 3), "launches_per_step": st["launches"] / steps,
+                     "avg_launch_ms": round(per_launch_ms, 4), "algorithmic_bytes_per_launch": per_launch_bytes})
+    return rows
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -220,8 +273,11 @@ def main():
     t0 = time.perf_counter()
     phase_sum = [0.0] * 9
     stage_sum = {}
+    step_ms = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         proof = prove()
+        step_ms.append((time.perf_counter() - ts) * 1e3)               # prove() returns the finished proof: no extra synchronisation
         for i, v in enumerate(ctx.phase_ms()):
             phase_sum[i] += v
         if transport != "none":
@@ -265,30 +321,16 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     cells = n * W_FIB
     value = cells / (elapsed / args.steps)                      # one proof per step regardless of the number of GPUs
-    # dominant kernel by device time, measured with HIP events on the launch stream inside the timed region
-    dom = max(stats.items(), key=lambda kv: kv[1]["ms"]) if stats else (None, None)
-    roofline = None
-
-    def pmc_traffic(kernel):
-        """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes of this same command (profiles/README.md): FETCH_SIZE
-        doubled (gfx950 correction for wide coalesced reads) + WRITE_SIZE, both converted from KiB.  Only a summary whose stamp
-        (profiles/<tag>_meta.json: digest of the kernel sources) matches the sources of THIS run is accepted: a stale one gives null."""
-        row, source = pmc_row(kernel)
-        if row is None or not row.get("fetch_bytes_per_launch_x2") or not row.get("write_bytes_per_launch_raw"):
-            return None, source
-        return int(row["fetch_bytes_per_launch_x2"]) + int(row["write_bytes_per_launch_raw"]), source
+    # kernels by device time, measured with HIP events on the launch stream inside the timed region.  `roofline` is the kernel with the
+    # largest total time IN THIS RUN; `roofline_transform` is always the first pass of the transforms (the kernel profiles/README.md
+    # describes), so that the two can be told apart when another kernel is dominant on some box; `rooflines` lists the top five.
     default_workload = log_n == 20 and world == 1 and (blowup, args.queries) == (32, 50)     # what the committed PMC passes were taken on
-    if dom[0]:
-        name, st = dom
-        per_launch_ms = st["ms"] / st["launches"]
-        per_launch_bytes = st["bytes"] / st["launches"]
-        achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
-        traffic, traffic_source = pmc_traffic(name) if default_workload else (None, "PMC passes exist for the default workload only")
-        roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                    "launches_per_step": st["launches"] / args.steps, "avg_launch_ms": round(per_launch_ms, 4),
-                    "algorithmic_bytes_per_launch": per_launch_bytes,
-                    "note": "the path is 128-bit modular integer arithmetic on the VALU: see alu_roofline and DESIGN.md"}
+    rooflines = kernel_rooflines(stats, args.steps, default_workload)
+    note = "the path is 128-bit modular integer arithmetic on the VALU: see valu_issue_frac, alu_roofline and DESIGN.md"
+    roofline = dict(rooflines[0], note=note) if rooflines else None
+    transform = [r for r in kernel_rooflines(stats, args.steps, default_workload, top=len(stats)) if r["kernel"].startswith("ntt_pass_a")]
+    roofline_transform = dict(transform[0], note=note) if transform else None
+    dom = (roofline["kernel"], stats[roofline["kernel"]]) if roofline else (None, None)
     # phase-level HBM fractions: SURVEY section 8(d)'s bytes counted once per phase, against the phase's wall time
     phase_names = ["lde", "trace_merkle", "constraint_eval", "combine", "constraint_lde_merkle", "deep_composition", "fri", "pow_queries", "openings"]
     phase_hbm = None
@@ -355,6 +397,10 @@ def main():
         "proof_bytes": len(proof),
         "shard_stage_ms_rank0": {k: round(v / args.steps, 3) for k, v in stage_sum.items()} or None,
         "roofline": roofline,
+        "roofline_transform": roofline_transform,
+        "rooflines": rooflines,
+        "step_ms": {"min": round(min(step_ms), 3), "median": round(float(np.median(step_ms)), 3), "max": round(max(step_ms), 3), "all": [round(x, 3) for x in step_ms]},
+        "box": box_fingerprint(ctx, mad_peak, mulmod_peak),
         "alu_roofline": dict(alu, mulmod_peak_measured=mulmod_peak, mulmod_kernel="mulmod_bench_kernel: general fe_mul, 4 dependent chains per lane (21 mads + 50 other VALU instructions each)"),
         "phase_hbm": phase_hbm,
         "prover_ms_incl_upload": incl_upload_ms,

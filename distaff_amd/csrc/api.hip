@@ -738,6 +738,11 @@ int dst_bench_mulmod(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms) {
     HIP_TRY(c, hipSetDevice(c->device));
     return k_bench_mulmod(c, lanes, iters, ms);
 }
+int dst_bench_code(dst_ctx* c, uint32_t code_kib, double* ms) {
+    if (!c || !ms) return DST_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return k_bench_code(c, code_kib, ms);
+}
 int dst_bench_mad(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms) {
     if (!c || !ms) return DST_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));

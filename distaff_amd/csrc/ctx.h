@@ -230,6 +230,7 @@ void k_gather_rows(dst_ctx* c, const uint64_t* positions_dev, size_t count, fe* 
 void k_gather_pieces(dst_ctx* c, const uint64_t* addr_dev, size_t count, void* dst);          // dst[t] = the 16 bytes at device address addr[t]
 int k_bench_mulmod(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms);
 int k_bench_mad(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms);
+int k_bench_code(dst_ctx* c, uint32_t code_kib, double* ms);      // kernels_probe.hip
 // coset-sharded (multi-GPU) helpers
 void k_merkle_local_levels(dst_ctx* c, digest* nodes, size_t count, size_t stop_count);
 void k_merkle_levels_to(dst_ctx* c, const digest* leaves, digest* nodes, size_t num_leaves, size_t stop_count);

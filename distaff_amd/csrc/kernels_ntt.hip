@@ -22,6 +22,11 @@
 #include <type_traits>
 #include "ntt_lds.h"
 
+#if defined(NTT_NO_ROTATE)
+#define NTT_NO_ROTATE_DEFINED 1
+#else
+#define NTT_NO_ROTATE_DEFINED 0
+#endif
 #define NTT_TILE_ELEMS 4096      // elements of an LDS tile (64 KiB); a workgroup of 512 lanes holds 8 per lane, one of 1024 lanes 4
 
 struct NttArgs {
@@ -133,7 +138,12 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
     // lane past the tile re-reads element 0.
 #define NTT_EACH(M) { M(0, pre0) M(1, pre1) M(2, pre2) M(3, pre3) M(4, pre4) M(5, pre5) M(6, pre6) M(7, pre7) }
     // uniform base (scalar registers) + 32-bit lane offset: the transform has at most 2^24 points
-#define NTT_FETCH_A1(e, var) if constexpr ((e) < EPT) { uint32_t idx = lane + (e) * THREADS; idx = idx < count ? idx : 0u; var = src[((idx >> log_t) << a.log_n2) + (idx & (T - 1))]; }
+    // Element (row, column) of the tile that lane index idx carries.  A coset DIT enters LDS bit-reversed: the rows r .. r + 3 of one LDS
+    // access group land 256-byte multiples apart, i.e. on the same banks; rotating the column by the row spreads them (the 64-byte HBM
+    // segment of a row is read by the same four lanes as before, in another order).
+    const bool rot_a = a.dit && log_t == 2 && !NTT_NO_ROTATE_DEFINED;
+#define NTT_COL_A(idx) (rot_a ? (((idx) + ((idx) >> log_t)) & (T - 1)) : ((idx) & (T - 1)))
+#define NTT_FETCH_A1(e, var) if constexpr ((e) < EPT) { uint32_t idx = lane + (e) * THREADS; idx = idx < count ? idx : 0u; var = src[((idx >> log_t) << a.log_n2) + NTT_COL_A(idx)]; }
 #define NTT_FETCH_A(tile) { const fe* __restrict__ src = src0 + (tile) * T; NTT_EACH(NTT_FETCH_A1) }
     const tw4_t* __restrict__ tw4 = a.tw4 + (size_t)jl * a.tw4_coset_stride;
     const uint32_t tile0 = group * a.tiles_per_block;
@@ -145,7 +155,7 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
         if (!PREFETCH) NTT_FETCH_A(tile)
         __syncthreads();                                   // the previous tile has left LDS (and TW is complete)
         // DISTAFF_NTT_DIF: pre-scale + DIF instead of the coset DIT
-#define NTT_PUT_A(e, var) if constexpr ((e) < EPT) { const uint32_t idx = lane + (e) * THREADS; if (idx < count) { if (a.dit) L[lds_slot(__brev(idx >> log_t) >> (32 - log_n1), idx & (T - 1), log_t)] = var; else L[lds_slot(idx >> log_t, idx & (T - 1), log_t)] = scaled ? fe_mul_tw(var, a.prescale[(jg * (idx >> log_t)) & pmask]) : var; } }
+#define NTT_PUT_A(e, var) if constexpr ((e) < EPT) { const uint32_t idx = lane + (e) * THREADS; if (idx < count) { if (a.dit) L[lds_slot(__brev(idx >> log_t) >> (32 - log_n1), NTT_COL_A(idx), log_t)] = var; else L[lds_slot(idx >> log_t, idx & (T - 1), log_t)] = scaled ? fe_mul_tw(var, a.prescale[(jg * (idx >> log_t)) & pmask]) : var; } }
         NTT_EACH(NTT_PUT_A)
 #undef NTT_PUT_A
         __syncthreads();
@@ -207,7 +217,13 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_b(NttArgs a, const fe* 
     fe pre0 = fe_zero(), pre1 = fe_zero(), pre2 = fe_zero(), pre3 = fe_zero(), pre4 = fe_zero(), pre5 = fe_zero(), pre6 = fe_zero(), pre7 = fe_zero();
     const uint32_t count = n2 * T;
     // contiguous along m2
-#define NTT_FETCH_B1(e, var) if constexpr ((e) < EPT) { uint32_t idx = lane + (e) * THREADS; idx = idx < count ? idx : 0u; var = srct[(idx >> log_n2) * row_stride + (idx & (n2 - 1))]; }
+    // Four-column tiles: lane index = (m2, row), row fastest -- a wavefront reads 16 consecutive elements (256 bytes) of each of the four
+    // rows and writes 64 consecutive LDS slots.  (With m2 fastest the slots of neighbouring lanes are 64 bytes apart: the 16 lanes of an
+    // access group share their banks four times over.)  Wider tiles keep m2 fastest.
+    const bool colfast_b = log_t == 2 && !NTT_NO_ROTATE_DEFINED;
+#define NTT_ROW_B(idx) (colfast_b ? ((idx) & (T - 1)) : ((idx) >> log_n2))
+#define NTT_M2_B(idx) (colfast_b ? ((idx) >> log_t) : ((idx) & (n2 - 1)))
+#define NTT_FETCH_B1(e, var) if constexpr ((e) < EPT) { uint32_t idx = lane + (e) * THREADS; idx = idx < count ? idx : 0u; var = srct[NTT_ROW_B(idx) * row_stride + NTT_M2_B(idx)]; }
 #define NTT_FETCH_B(tile) { const fe* __restrict__ srct = src + (size_t)((tile) * T) * a.src_row_stride; NTT_EACH(NTT_FETCH_B1) }
     const uint32_t row_stride = (uint32_t)a.src_row_stride;
     const uint32_t tile0 = group * a.tiles_per_block;
@@ -218,7 +234,7 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_b(NttArgs a, const fe* 
         if constexpr (LOG_LEN != 0) lane = lds_opaque_lane();
         if (!PREFETCH) NTT_FETCH_B(tile0 + it)
         __syncthreads();
-#define NTT_PUT_B(e, var) if constexpr ((e) < EPT) { const uint32_t idx = lane + (e) * THREADS; if (idx < count) L[lds_slot(idx & (n2 - 1), idx >> log_n2, log_t)] = var; }
+#define NTT_PUT_B(e, var) if constexpr ((e) < EPT) { const uint32_t idx = lane + (e) * THREADS; if (idx < count) L[lds_slot(NTT_M2_B(idx), NTT_ROW_B(idx), log_t)] = var; }
         NTT_EACH(NTT_PUT_B)
 #undef NTT_PUT_B
         __syncthreads();

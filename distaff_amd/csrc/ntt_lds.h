@@ -19,6 +19,18 @@ __device__ __forceinline__ uint32_t lds_slot(uint32_t i, uint32_t t, uint32_t lo
     return (i << log_t) + t;
 }
 
+// Column of the tile that lane w = (q, t) works on.  In the round whose butterflies span four ADJACENT rows (distance 2 and 1) the
+// neighbouring butterflies q, q + 1, .. of a four-column tile start 256 bytes apart: with every lane of a butterfly on "its" column t the
+// 16 lanes of an LDS access group hit the same banks four times over (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE 0.22 / 0.35 in the two
+// passes, profiles/r2).  Which lane takes which column is free: rotating the column by q spreads the group over the 256 bytes.
+__device__ __forceinline__ uint32_t lds_column(uint32_t w, uint32_t q, uint32_t log_t, bool adjacent_rows) {
+    const uint32_t T = 1u << log_t;
+#if !defined(NTT_NO_ROTATE)
+    if (adjacent_rows && log_t == 2) return (w + q) & (T - 1);
+#endif
+    return w & (T - 1);
+}
+
 // Slot of DIF stage twiddle w_len^e in LDS.  Stage s reads the entries e = pos * 2^(s-1) of neighbouring butterflies: from the third stage
 // on that is a stride of a multiple of 256 bytes, i.e. every lane of an LDS access group on the same banks (measured on the rounds in
 // isolation: 11 % of their time).  XOR-ing bits 3..5 and 6..8 of the index into its low three bits spreads strides 4, 16 and 64 over
@@ -55,7 +67,8 @@ __device__ __forceinline__ void lds_dif_round(fe* L, const fe_tw* W, uint32_t lo
     const bool last = (s + 1 == log_len);        // second stage has distance 1: its twiddles are 1
     const bool fin = Out::active && last;        // the results of this round leave through `out`
     for (uint32_t w = lane; w < ((1u << log_len) >> 2) * T; w += THREADS) {
-        const uint32_t t = w & (T - 1), q = w >> log_t;
+        const uint32_t q = w >> log_t;
+        const uint32_t t = lds_column(w, q, log_t, hd == 1);
         const uint32_t pos = q & (hd - 1), blk = q >> (ld - 1);
         const uint32_t i0 = (blk << (ld + 1)) + pos;
         typename Out::Tok k0, k1, k2, k3;
@@ -130,7 +143,8 @@ __device__ __forceinline__ void lds_dit_round(fe* L, const fe_tw* W, uint32_t lo
     const uint32_t B = 1u << s, half = B >> 1;                     // first stage merges blocks of size B / 2 into B, second B into 2B
     const bool fin = Out::active && s + 1 == log_len;              // the results of this round leave through `out`
     for (uint32_t w = lane; w < ((1u << log_len) >> 2) * T; w += THREADS) {
-        const uint32_t t = w & (T - 1), q = w >> log_t;
+        const uint32_t q = w >> log_t;
+        const uint32_t t = lds_column(w, q, log_t, half == 1);
         const uint32_t k = q & (half - 1), base = (q >> (s - 1)) << (s + 1);
         typename Out::Tok k0, k1, k2, k3;
         if (fin) { k0 = out.pre(base + k, t); k1 = out.pre(base + k + half, t); k2 = out.pre(base + k + B, t); k3 = out.pre(base + k + B + half, t); }

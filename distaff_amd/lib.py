@@ -21,7 +21,7 @@ BUF = {"polys": 0, "lde": 1, "trace_leaves": 2, "trace_nodes": 3, "ceval_i": 4, 
 EXPORTS = ["dst_ctx_create", "dst_ctx_destroy", "dst_last_error", "dst_phase_ms", "dst_trace_upload", "dst_trace_upload_contiguous",
            "dst_commit_trace", "dst_eval_constraints", "dst_compose", "dst_fri_commit_layer", "dst_fri_fold", "dst_pow_grind",
            "dst_build_proof", "dst_prove", "dst_prng_vector", "dst_query_positions", "dst_blake3", "dst_fibonacci_trace",
-           "dst_read_buffer", "dst_bench_mulmod", "dst_bench_mad", "dst_trace_upload_async", "dst_pinned_alloc", "dst_pinned_free", "dst_set_profiling", "dst_kernel_stats", "dst_field_op",
+           "dst_read_buffer", "dst_bench_mulmod", "dst_bench_mad", "dst_bench_code", "dst_trace_upload_async", "dst_pinned_alloc", "dst_pinned_free", "dst_set_profiling", "dst_kernel_stats", "dst_field_op",
            "dst_shard_commit_trace", "dst_shard_eval_constraints", "dst_shard_combine", "dst_shard_fri_layer", "dst_shard_fri_fold",
            "dst_shard_export_size", "dst_shard_export", "dst_shard_import", "dst_shard_read", "dst_shard_fri_begin", "dst_shard_fri_end", "dst_shard_fri_roots", "dst_shard_open", "dst_shard_assemble", "dst_shard_info",
            "dst_comm_unique_id", "dst_comm_init", "dst_comm_init_local", "dst_comm_init_callbacks", "dst_comm_destroy", "dst_comm_last_error", "dst_prove_sharded", "dst_prove_sharded_local"]
@@ -464,6 +464,12 @@ class Context:
         """milliseconds for lanes * iters * 32 multiply-adds v_mad_u64_u32 (the integer-multiplier peak of the device)"""
         ms = ctypes.c_double(0)
         self._check(self.lib.dst_bench_mad(self._h, ctypes.c_uint64(lanes), ctypes.c_uint32(iters), ctypes.byref(ms)))
+        return ms.value
+
+    def bench_code(self, code_kib):
+        """milliseconds for 2^23 lanes to run 16 or 176 KiB of straight-line multiply-adds once (box fingerprint, kernels_probe.hip)"""
+        ms = ctypes.c_double(0)
+        self._check(self.lib.dst_bench_code(self._h, ctypes.c_uint32(code_kib), ctypes.byref(ms)))
         return ms.value
 
     def bench_mulmod(self, lanes=1 << 20, iters=256, portable=False):
