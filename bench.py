@@ -213,7 +213,11 @@ def main():
         raise SystemExit("--gpus must be 1, 2, 4 or 8 (cosets of the LDE domain are split evenly)")
     blowup = 1 << args.log_blowup
     ctx = D.Context(log_n, W_FIB, 1, 0, device=local_rank, rank=rank, world=world, log_blowup=args.log_blowup, num_queries=args.queries)   # defaults = default ProofOptions: blowup 32, 50 queries, grinding 20
-    ctx.upload(cols)                                                # inputs resident in HBM before the timed region
+    c_orchestration = (world > 1 or args.force_sharded) and os.environ.get("DISTAFF_SHARD_ORCH", "c") != "python"
+    if c_orchestration and world > 1:
+        ctx.upload_owned(cols)                                      # dst_prove_sharded splits the interpolation by columns: 1 / world of the trace per GPU
+    else:
+        ctx.upload(cols)                                            # inputs resident in HBM before the timed region
 
     if world == 1 and not args.force_sharded:
         def prove():
@@ -389,8 +393,9 @@ def main():
         "config": {"workload": "Fibonacci program (src/examples/fibonacci.rs), 2^%d-step trace, W=20 registers, full stark::prove with %s"
                                "ProofOptions (blowup %d, %d queries, grinding 20, blake3)" % (log_n, "default " if (blowup, args.queries) == (32, 50) else "", blowup, args.queries),
                    "trace_steps": n, "registers": W_FIB, "blowup": blowup, "queries": args.queries, "grinding": 20,
-                   "parallelism": "1 GPU" if world == 1 else "one proof sharded over %d GPUs by LDE cosets; Merkle trees finished per k-range (all-to-all of boundary nodes, "
-                                  "all-gather of subtree roots), all-gather of constraint evaluations and of the first small FRI layer; %s" % (world, transport)},
+                   "parallelism": "1 GPU" if world == 1 else "one proof sharded over %d GPUs: interpolation by trace columns (coefficients all-gathered), everything on the LDE domain by cosets; "
+                                  "Merkle trees finished per k-range (all-to-all of boundary nodes, all-gather of subtree roots), all-gather of constraint evaluations and of the "
+                                  "first small FRI layer; %s" % (world, transport)},
         "prover_ms": ms_per_step,
         "phase_ms": None if transport.startswith("torch") else {k: round(v / args.steps, 3) for k, v in zip(
             ["lde", "trace_merkle", "constraint_eval", "combine", "constraint_lde_merkle", "deep_composition", "fri", "pow_queries", "openings"], phase_sum)},

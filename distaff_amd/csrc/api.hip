@@ -92,6 +92,9 @@ static void free_all(dst_ctx* c) {
     }
     for (hipEvent_t e : c->upload_done) hipEventDestroy(e);
     if (c->upload_stream) hipStreamDestroy(c->upload_stream);
+    for (hipEvent_t e : c->comm_events) hipEventDestroy(e);
+    if (c->comm_stream) hipStreamDestroy(c->comm_stream);
+    if (c->d_status) hipFree(c->d_status);
     if (c->stream) hipStreamDestroy(c->stream);
 }
 
@@ -196,7 +199,9 @@ static int ctx_init(dst_ctx* c) {
 
     // data buffers
     const size_t n = c->n, Nl = c->Bc * n;
-    if ((r = dev_alloc(c, &c->polys, c->W * n))) return r;
+    // sharded contexts: the coefficient vectors are all-gathered in rounds of `world` registers (dst_prove_sharded), so the array holds
+    // a whole number of rounds
+    if ((r = dev_alloc(c, &c->polys, (c->W + c->prm.world - 1) / c->prm.world * c->prm.world * n))) return r;
     if ((r = dev_alloc(c, &c->lde, c->W * Nl))) return r;
     if (c->j0 == 0 && c->Bc > 1 && !(getenv("DISTAFF_TRACE_BUFFER") && getenv("DISTAFF_TRACE_BUFFER")[0] == '1')) { c->trace = c->lde; c->trace_stride = Nl; }     // see ctx.h; DISTAFF_TRACE_BUFFER=1: separate buffer + copy (tests)
     else { if ((r = dev_alloc(c, &c->trace, c->W * n))) return r; c->trace_stride = n; }
@@ -272,7 +277,22 @@ int dst_trace_upload(dst_ctx* c, const uint8_t* const* cols) {
     { int rd = drain_pending_upload(c); if (rd) return rd; }
     for (size_t i = 0; i < c->W; i++) HIP_TRY(c, hipMemcpyAsync(c->trace + i * c->trace_stride, cols[i], c->n * 16, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->upload_pending = false;
+    c->upload_pending = false; c->trace_owned_only = false;
+    c->have_trace = true; c->committed = c->constraints_done = c->composed = false;
+    return DST_OK;
+}
+// Sharded contexts: uploads only the registers this rank interpolates, r = rank (mod world) -- 1/world of the trace per GPU instead of
+// all of it.  cols[r] of the other registers is not read (may be NULL).  Only dst_prove_sharded accepts a context in this state.
+int dst_trace_upload_owned(dst_ctx* c, const uint8_t* const* cols) {
+    if (!c || !cols) return DST_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    { int rd = drain_pending_upload(c); if (rd) return rd; }
+    for (size_t i = c->prm.rank; i < c->W; i += c->prm.world) {
+        if (!cols[i]) { c->err = "dst_trace_upload_owned: register " + std::to_string(i) + " belongs to this rank but has no data"; return DST_ERR_ARG; }
+        HIP_TRY(c, hipMemcpyAsync(c->trace + i * c->trace_stride, cols[i], c->n * 16, hipMemcpyHostToDevice, c->stream));
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->upload_pending = false; c->trace_owned_only = c->prm.world > 1;
     c->have_trace = true; c->committed = c->constraints_done = c->composed = false;
     return DST_OK;
 }
@@ -281,7 +301,7 @@ int dst_trace_upload_contiguous(dst_ctx* c, const uint8_t* cols) {
     HIP_TRY(c, hipSetDevice(c->device));
     { int rd = drain_pending_upload(c); if (rd) return rd; }
     for (size_t i = 0; i < c->W; i++) HIP_TRY(c, hipMemcpy(c->trace + i * c->trace_stride, cols + i * c->n * 16, c->n * 16, hipMemcpyHostToDevice));
-    c->upload_pending = false;
+    c->upload_pending = false; c->trace_owned_only = false;
     c->have_trace = true; c->committed = c->constraints_done = c->composed = false;
     return DST_OK;
 }
@@ -316,7 +336,7 @@ int dst_trace_upload_async(dst_ctx* c, const uint8_t* const* cols) {
             HIP_TRY(c, hipMemcpyAsync(c->trace + i * c->trace_stride, cols[i], c->n * 16, hipMemcpyHostToDevice, c->upload_stream));
         HIP_TRY(c, hipEventRecord(c->upload_done[g], c->upload_stream));
     }
-    c->upload_pending = true;
+    c->upload_pending = true; c->trace_owned_only = false;
     c->have_trace = true; c->committed = c->constraints_done = c->composed = false;
     return DST_OK;
 }
@@ -325,6 +345,7 @@ int dst_trace_upload_async(dst_ctx* c, const uint8_t* const* cols) {
 int dst_commit_trace(dst_ctx* c, uint8_t trace_root[32]) {
     if (!c || !trace_root) return DST_ERR_ARG;
     if (!c->have_trace) { c->err = "dst_commit_trace: no trace uploaded"; return DST_ERR_STATE; }
+    if (c->trace_owned_only) { c->err = "dst_commit_trace: only this rank's registers were uploaded (dst_trace_upload_owned): use dst_prove_sharded"; return DST_ERR_STATE; }
     HIP_TRY(c, hipSetDevice(c->device));
     c->sharded_layout = false;
     double t0 = wall_ms();

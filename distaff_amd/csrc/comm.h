@@ -17,8 +17,11 @@ struct dst_comm {
     uint32_t rank = 0, world = 1;
     std::string err;
     virtual ~dst_comm() {}
-    // device buffers.  Every call returns when `recv` is complete on this rank and `send` may be overwritten; work queued on `stream`
-    // before the call is ordered before the exchange.
+    // device buffers.  Work queued on `stream` before the call is ordered before the exchange, work queued after it sees `recv` complete
+    // and may overwrite `send`.  A transport that is stream_ordered() only ENQUEUES the exchange (RCCL: the host does not wait, so
+    // collectives overlap with kernels of other streams); the others return when the exchange is complete.  The host synchronises the
+    // stream before it reads results.  all_gather may be in place: send == recv + rank * bytes_per_rank.
+    virtual bool stream_ordered() const { return false; }
     virtual int all_gather(const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream) = 0;      // recv = [world][bytes]
     virtual int all_to_all(const void* send, void* recv, size_t chunk_bytes, hipStream_t stream) = 0;         // chunk g of send -> rank g; chunk r of recv <- rank r
     // small host values (status words, lengths, opening blobs)

@@ -59,10 +59,10 @@ struct RcclComm : dst_comm {
         if (staging) hipFree(staging);
         if (own_stream) hipStreamDestroy(own_stream);
     }
+    bool stream_ordered() const override { return true; }
     int all_gather(const void* send, void* recv, size_t bytes, hipStream_t stream) override {
-        int r = api->AllGather(send, recv, bytes, ncclUint8, comm, stream);
+        int r = api->AllGather(send, recv, bytes, ncclUint8, comm, stream);          // in place when send == recv + rank * bytes
         if (r != ncclSuccess) return fail(r, "ncclAllGather");
-        if (hipStreamSynchronize(stream) != hipSuccess) { err = "all_gather: stream synchronisation failed"; return DST_ERR_HIP; }
         return DST_OK;
     }
     int all_to_all(const void* send, void* recv, size_t chunk, hipStream_t stream) override {
@@ -73,7 +73,6 @@ struct RcclComm : dst_comm {
             if ((r = api->Recv((uint8_t*)recv + (size_t)p * chunk, chunk, ncclUint8, (int)p, comm, stream)) != ncclSuccess) return fail(r, "ncclRecv");
         }
         if ((r = api->GroupEnd()) != ncclSuccess) return fail(r, "ncclGroupEnd");
-        if (hipStreamSynchronize(stream) != hipSuccess) { err = "all_to_all: stream synchronisation failed"; return DST_ERR_HIP; }
         return DST_OK;
     }
     int all_gather_host(const void* send, void* recv, size_t bytes) override {
@@ -131,7 +130,10 @@ struct LocalComm : dst_comm {
         return DST_OK;
     }
     int all_gather(const void* send, void* recv, size_t bytes, hipStream_t stream) override {
-        return exchange(send, stream, false, [&](uint32_t p, const void* src) { return hipMemcpyAsync((uint8_t*)recv + (size_t)p * bytes, src, bytes, hipMemcpyDefault, stream); });
+        return exchange(send, stream, false, [&](uint32_t p, const void* src) {
+            uint8_t* dst = (uint8_t*)recv + (size_t)p * bytes;
+            return dst == src ? hipSuccess : hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, stream);          // in place: the own piece is already there
+        });
     }
     int all_to_all(const void* send, void* recv, size_t chunk, hipStream_t stream) override {
         return exchange(send, stream, false, [&](uint32_t p, const void* src) { return hipMemcpyAsync((uint8_t*)recv + (size_t)p * chunk, (const uint8_t*)src + (size_t)rank * chunk, chunk, hipMemcpyDefault, stream); });

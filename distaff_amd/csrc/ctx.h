@@ -152,6 +152,13 @@ struct dst_ctx {
     std::vector<hipEvent_t> upload_done;
     std::vector<size_t> upload_bounds;  // group g holds registers [upload_bounds[g], upload_bounds[g + 1])
     bool upload_pending = false;
+    // dst_trace_upload_owned: only the registers r = rank (mod world) of the trace are on this device (the sharded prover interpolates
+    // exactly those and all-gathers the coefficient vectors)
+    bool trace_owned_only = false;
+    // dst_prove_sharded: collectives that overlap with compute run on their own stream, ordered by events; status records of all ranks
+    hipStream_t comm_stream = nullptr;
+    std::vector<hipEvent_t> comm_events;
+    uint8_t* d_status = nullptr;
     double phase_ms[9] = {0};
 
     // optional per-kernel timing with HIP events recorded on `stream` (dst_set_profiling / dst_kernel_stats)

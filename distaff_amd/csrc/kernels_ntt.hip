@@ -710,7 +710,7 @@ void k_lde_columns(dst_ctx* c, const fe* polys, fe* lde, size_t ncols) {
     // coset 0 of the extension is the trace itself (T(w_n^k) for the interpolant T): when this rank owns it and the polynomials are
     // the interpolated trace, it is copied instead of transformed (1/B of the extension work)
     const bool of_trace = polys >= c->polys && polys < c->polys + c->W * c->n;          // a group of the interpolated trace registers
-    const uint32_t skip = (c->j0 == 0 && of_trace && c->Bc > 1) ? 1u : 0u;
+    const uint32_t skip = (c->j0 == 0 && of_trace && c->Bc > 1 && !c->trace_owned_only) ? 1u : 0u;      // owned-only: this rank holds 1/world of the trace registers, coset 0 is transformed like the others
     if (skip && c->trace != c->lde)         // a context that owns coset 0 normally keeps the trace in those slots already (ctx.h: trace_stride)
         (void)hipMemcpy2DAsync(lde, c->Bc * c->n * sizeof(fe), c->trace + ((polys - c->polys) / c->n) * c->trace_stride, c->trace_stride * sizeof(fe), c->n * sizeof(fe), ncols, hipMemcpyDeviceToDevice, c->stream);
     // launch granularity: `bcols` registers x `bcos` cosets per pair of passes (the staging buffer holds tmp_capacity_arrays arrays)

@@ -5,6 +5,7 @@
 // collectives themselves are issued by the host (torch.distributed / RCCL in distaff_amd/sharded.py): this file only
 // exports and imports the shards.
 #include <chrono>
+#include <functional>
 #include <set>
 #include <thread>
 #include "ctx.h"
@@ -77,6 +78,7 @@ extern "C" {
 int dst_shard_commit_trace(dst_ctx* c) {
     if (!c) return DST_ERR_ARG;
     if (!c->have_trace) { c->err = "dst_shard_commit_trace: no trace uploaded"; return DST_ERR_STATE; }
+    if (c->trace_owned_only) { c->err = "dst_shard_commit_trace: only this rank's registers were uploaded (dst_trace_upload_owned): use dst_prove_sharded"; return DST_ERR_STATE; }
     HIP_TRY(c, hipSetDevice(c->device));
     int r = ensure_shard_buffers(c);
     if (r) return r;
@@ -644,8 +646,12 @@ int dst_shard_info(dst_ctx* c, uint64_t* op_count, uint32_t* num_fri_layers, uin
 
 
 // ---- the whole sharded proof behind the C-ABI ------------------------------------------------------------------------------------------
-// dst_prove_sharded = stark::prove (prover.rs:17-168) across the ranks of a communicator: the same phases as the host-orchestrated
-// sequence above, with the collectives issued here (RCCL or the in-process transport, comm.hip).  Exchange points:
+// dst_prove_sharded = stark::prove (prover.rs:17-168) across the ranks of a communicator, with the collectives issued here (RCCL or the
+// in-process transport, comm.hip).  What is split and what is exchanged:
+//   * interpolation by trace COLUMNS: rank g interpolates the registers r = g (mod G) and the coefficient vectors are all-gathered in
+//     place, in rounds of G registers (16 n bytes sent per rank and round); on a stream-ordered transport the all-gather of round k + 1
+//     runs on its own stream while round k is extended.  A host that uploads with dst_trace_upload_owned sends each GPU 1/G of the trace;
+//   * everything evaluated on the LDE domain by COSETS: rank g owns the cosets [g B/G, (g+1) B/G) of every register;
 //   * every Merkle tree: after the rank-local levels (one boundary node per k and rank) an ALL-TO-ALL moves the boundary nodes so that
 //     rank g holds those of k in [g*K/G, (g+1)*K/G) of every rank, builds the subtree above them (K - 1 hashes), the G subtree roots
 //     are all-gathered (G x 32 bytes) and only the top log2(G) levels are repeated on every rank.  Per rank and tree: 32*K*(G-1)/G bytes
@@ -653,22 +659,27 @@ int dst_shard_info(dst_ctx* c, uint64_t* op_count, uint32_t* num_fri_layers, uin
 //   * the transition-constraint evaluations (8n/G elements per rank): all-gather before the cross-coset inverse transform;
 //   * the first small FRI layer: all-gather of its evaluations, the commit phase then finishes replicated;
 //   * openings: every rank gathers what it owns; the blobs are all-gathered and every rank fills the same proof template.
-// A status word travels with every phase: when any rank fails, all ranks return an error instead of waiting in the next collective.
+// Failure handling.  A rank that fails locally keeps ISSUING the collectives of the protocol (its peers wait in them) but skips its own
+// work; its status travels with data that is exchanged anyway -- a 64-byte record per rank next to the subtree roots of every tree (no
+// host round trip of its own: the root read-back synchronises once for both), and inside the two host-value exchanges (failing step of
+// the constraint check, opening lengths).  Every rank returns the first failing rank's code.  (Round 2 agreed on a status word through a
+// host-staged all-gather after every phase: ~26 per proof.)
 namespace {
-struct Agree {
+struct StatusRec { int32_t rc; int32_t pad[3]; fe payload[3]; };      // 64 bytes per rank; payload: rank 0's last trace state (op counter, program hash)
+static_assert(sizeof(StatusRec) == 64, "StatusRec is exchanged as 64 bytes");
+
+struct Sharded {
     dst_ctx* c; dst_comm* comm;
-    // every rank contributes its status; returns the first failing rank's code on ALL ranks
-    int operator()(int rc, const char* phase) {
-        std::vector<int32_t> all(comm->world, 0);
-        int32_t mine = rc;
-        int r = comm->all_gather_host(&mine, all.data(), sizeof(int32_t));
-        if (r) { c->err = std::string(phase) + ": " + comm->err; return r; }
-        for (uint32_t g = 0; g < comm->world; g++)
-            if (all[g] != DST_OK) {
-                if (rc == DST_OK) c->err = std::string(phase) + ": rank " + std::to_string(g) + " reported error " + std::to_string(all[g]);
-                return all[g];
-            }
-        return DST_OK;
+    int rc = DST_OK;                       // this rank's own status: sticky, skips its local steps
+    int agreed = DST_OK;                   // first failing rank's code once an exchange has shown one
+    // a rank-local step; collectives are issued regardless (see above)
+    void local(const std::function<int()>& f) { if (rc == DST_OK) { rc = f(); } }           // (this file's functions sit in an extern "C" block: no member templates)
+    void fail(int code, const std::string& msg) { if (rc == DST_OK) { rc = code; c->err = msg; } }
+    // collective errors are not rank-local: the transport failed for everyone (or will hang for everyone)
+    bool coll(int r, const char* what) { if (r != DST_OK) { if (rc == DST_OK) { rc = r; c->err = std::string(what) + ": " + comm->err; } agreed = agreed ? agreed : r; return false; } return true; }
+    void saw(const StatusRec* all, const char* phase) {
+        for (uint32_t g = 0; g < comm->world && agreed == DST_OK; g++)
+            if (all[g].rc != DST_OK) { agreed = all[g].rc; if (rc == DST_OK) c->err = std::string(phase) + ": rank " + std::to_string(g) + " reported error " + std::to_string(all[g].rc); }
     }
 };
 
@@ -688,146 +699,251 @@ int shard_boundary(dst_ctx* c, uint32_t what, uint32_t arg, const digest** src, 
     c->err = "shard_boundary: bad item"; return DST_ERR_ARG;
 }
 
-// finishes a tree from the ranks' boundary nodes and returns its root (replicated)
-int tree_exchange(dst_ctx* c, dst_comm* comm, uint32_t what, uint32_t arg, uint8_t root[32]) {
+// Finishes a tree from the ranks' boundary nodes and returns its root (replicated).  The ranks' status records ride with the subtree
+// roots: on return S.agreed holds the first failing rank's code.  `payload` (rank 0 -> everyone), when given, is three field elements
+// read from rank 0's device memory at `payload_src[i]`.
+void tree_exchange(Sharded& S, uint32_t what, uint32_t arg, uint8_t root[32], const fe* const* payload_src = nullptr, fe* payload_out = nullptr) {
+    dst_ctx* c = S.c; dst_comm* comm = S.comm;
     const size_t G = comm->world;
     const digest* src = nullptr; size_t K = 0;
-    int r = shard_boundary(c, what, arg, &src, &K);
-    if (r) return r;
+    if (shard_boundary(c, what, arg, &src, &K)) { S.fail(DST_ERR_ARG, c->err); S.agreed = DST_ERR_ARG; return; }      // the same on every rank
     digest* upper = what == SH_TRACE_TREE ? c->trace_upper : what == SH_CONSTRAINT_TREE ? c->c_upper : c->fri_upper[arg];
     const int slot = what == SH_TRACE_TREE ? 0 : what == SH_CONSTRAINT_TREE ? 1 : 2 + (int)arg;
     const bool krange = G > 1 && K >= G && K % G == 0 && !getenv("DISTAFF_SHARD_TREE_GATHER");
     c->tree_krange[slot] = krange;
     if (getenv("DISTAFF_SHARD_DEBUG") && comm->rank == 0) fprintf(stderr, "[distaff] tree %u/%u: %zu boundary nodes per rank, %s\n", what, arg, K, krange ? "k-range exchange (all-to-all + root all-gather)" : "all-gather of boundary nodes");
+    if ((krange ? K * 32 : K * 32 * G) > c->gather_bytes) { S.fail(DST_ERR_ARG, "tree_exchange: gather buffer too small"); S.agreed = DST_ERR_ARG; return; }   // the same on every rank
     if (krange) {
         const size_t chunk = K / G;                              // boundary nodes per (sender, owner) pair
-        if (K * 32 > c->gather_bytes) { c->err = "tree_exchange: gather buffer too small"; return DST_ERR_ARG; }
-        if ((r = comm->all_to_all(src, c->gather_buf, chunk * 32, c->stream))) { c->err = "tree_exchange: " + comm->err; return r; }
+        if (!S.coll(comm->all_to_all(src, c->gather_buf, chunk * 32, c->stream), "tree_exchange")) return;
         digest* mid = upper + 2 * G;                             // this rank's subtree heap: mid[1] = its root, mid[K + kl*G + r] = boundary node of rank r at k = g*K/G + kl
-        k_upper_tree(c, (const digest*)c->gather_buf, mid, chunk, (uint32_t)G);
-        if ((r = comm->all_gather(mid + 1, upper + G, 32, c->stream))) { c->err = "tree_exchange: " + comm->err; return r; }
-        k_merkle_upper(c, upper, G);                             // the top log2(G) levels, on every rank
+        S.local([&] { k_upper_tree(c, (const digest*)c->gather_buf, mid, chunk, (uint32_t)G); return DST_OK; });
+        if (!S.coll(comm->all_gather(mid + 1, upper + G, 32, c->stream), "tree_exchange")) return;
+        S.local([&] { k_merkle_upper(c, upper, G); return DST_OK; });                          // the top log2(G) levels, on every rank
     } else {
-        if (K * 32 * G > c->gather_bytes) { c->err = "tree_exchange: gather buffer too small"; return DST_ERR_ARG; }
-        if ((r = comm->all_gather(src, c->gather_buf, K * 32, c->stream))) { c->err = "tree_exchange: " + comm->err; return r; }
-        k_upper_tree(c, (const digest*)c->gather_buf, upper, K, (uint32_t)G);
+        if (!S.coll(comm->all_gather(src, c->gather_buf, K * 32, c->stream), "tree_exchange")) return;
+        S.local([&] { k_upper_tree(c, (const digest*)c->gather_buf, upper, K, (uint32_t)G); return DST_OK; });
     }
-    HIP_TRY(c, hipMemcpyAsync(root, upper + 1, 32, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipGetLastError());
+    // status records (and rank 0's payload) of all ranks: [G] records, this rank's own at index rank (in-place all-gather)
+    StatusRec mine{}; mine.rc = S.rc;
+    StatusRec* recs = reinterpret_cast<StatusRec*>(c->d_status);
+    std::vector<StatusRec> all(G);
+    bool staged = hipMemcpyAsync(recs + comm->rank, &mine, sizeof(mine), hipMemcpyHostToDevice, c->stream) == hipSuccess;
+    if (staged && payload_src && comm->rank == 0 && S.rc == DST_OK)
+        for (int i = 0; i < 3 && staged; i++) staged = hipMemcpyAsync(&recs[0].payload[i], payload_src[i], sizeof(fe), hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
+    if (!staged) S.fail(DST_ERR_HIP, "tree_exchange: staging of the status record failed");
+    if (!S.coll(comm->all_gather(recs + comm->rank, recs, sizeof(StatusRec), c->stream), "tree_exchange")) return;
+    bool ok = hipMemcpyAsync(all.data(), recs, G * sizeof(StatusRec), hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(root, upper + 1, 32, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+    ok = ok && hipStreamSynchronize(c->stream) == hipSuccess && hipGetLastError() == hipSuccess;
+    if (!ok) { S.fail(DST_ERR_HIP, "tree_exchange: root read-back failed"); S.agreed = S.agreed ? S.agreed : DST_ERR_HIP; return; }
+    S.saw(all.data(), what == SH_TRACE_TREE ? "trace tree" : what == SH_CONSTRAINT_TREE ? "constraint tree" : "FRI tree");
+    if (payload_out) for (int i = 0; i < 3; i++) payload_out[i] = all[0].payload[i];
+    if (S.agreed) return;
     if (what == SH_TRACE_TREE) memcpy(c->trace_root, root, 32);
     else if (what == SH_CONSTRAINT_TREE) memcpy(c->constraint_root, root, 32);
     else { if (c->fri_roots.size() <= arg) c->fri_roots.resize(arg + 1); c->fri_roots[arg].assign(root, root + 32); }
-    return DST_OK;
+}
+
+// steps 1-2 up to the rank-local tree levels.  Interpolation is split by COLUMNS: rank g interpolates the registers r = g (mod G); the
+// coefficient vectors of a round of G registers are all-gathered in place (polys[round * G + rank] is this rank's piece), and each round
+// is extended over this rank's cosets as soon as it has arrived.
+void commit_trace_columns(Sharded& S) {
+    dst_ctx* c = S.c; dst_comm* comm = S.comm;
+    const size_t G = comm->world, W = c->W, n = c->n, rounds = (W + G - 1) / G;
+    S.local([&]() -> int {
+        if (!c->have_trace) { c->err = "dst_prove_sharded: no trace uploaded"; return DST_ERR_STATE; }
+        int r = ensure_shard_buffers(c);
+        if (r) return r;
+        if (!c->d_status) HIP_TRY(c, hipMalloc((void**)&c->d_status, 64 * 8 + 64));
+        c->sharded_layout = true;
+        for (bool& b : c->tree_krange) b = false;
+        if (c->upload_pending) {
+            for (size_t g = 0; g + 1 < c->upload_bounds.size(); g++) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->upload_done[g], 0));
+            c->upload_pending = false;
+        }
+        return DST_OK;
+    });
+    // a stream-ordered transport runs the all-gathers on their own stream, ordered against the transforms by events
+    const bool overlap = comm->stream_ordered() && G > 1 && !getenv("DISTAFF_SHARD_NO_OVERLAP");
+    if (overlap) S.local([&]() -> int {
+        if (!c->comm_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
+        while (c->comm_events.size() < 2 * rounds) { hipEvent_t e; HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->comm_events.push_back(e); }
+        return DST_OK;
+    });
+    const bool use_side = overlap && S.rc == DST_OK;
+    if (G == 1) {                                              // one rank: nothing to exchange, all registers in one pair of launches
+        S.local([&]() -> int {
+            k_intt_columns(c, c->trace, c->trace_stride, c->polys, W);
+            k_lde_columns(c, c->polys, c->lde, W);
+            k_trace_leaves(c);
+            k_merkle_levels_to(c, c->trace_leaves, c->trace_nodes, c->Bc * n, n);
+            return DST_OK;
+        });
+        return;
+    }
+    // interpolate the owned register of every round (a rank past the last register of the final round contributes an unused piece)
+    for (size_t k = 0; k < rounds; k++) {
+        const size_t col = k * G + comm->rank;
+        S.local([&]() -> int {
+            if (col < W) k_intt_columns(c, c->trace + col * c->trace_stride, c->trace_stride, c->polys + col * n, 1);
+            if (use_side) { HIP_TRY(c, hipEventRecord(c->comm_events[2 * k], c->stream)); HIP_TRY(c, hipStreamWaitEvent(c->comm_stream, c->comm_events[2 * k], 0)); }
+            return DST_OK;
+        });
+        if (use_side) {
+            if (!S.coll(comm->all_gather(c->polys + col * n, c->polys + k * G * n, n * sizeof(fe), c->comm_stream), "coefficient all-gather")) return;
+            S.local([&]() -> int { HIP_TRY(c, hipEventRecord(c->comm_events[2 * k + 1], c->comm_stream)); return DST_OK; });
+        }
+    }
+    for (size_t k = 0; k < rounds; k++) {
+        const size_t first = k * G, cnt = first + G <= W ? G : W - first;
+        if (use_side) S.local([&]() -> int { HIP_TRY(c, hipStreamWaitEvent(c->stream, c->comm_events[2 * k + 1], 0)); return DST_OK; });
+        else if (!S.coll(comm->all_gather(c->polys + (first + comm->rank) * n, c->polys + first * n, n * sizeof(fe), c->stream), "coefficient all-gather")) return;
+        S.local([&]() -> int { k_lde_columns(c, c->polys + first * n, c->lde + first * c->Bc * n, cnt); return DST_OK; });
+    }
+    S.local([&]() -> int {
+        k_trace_leaves(c);
+        k_merkle_levels_to(c, c->trace_leaves, c->trace_nodes, c->Bc * n, n);
+        return DST_OK;
+    });
 }
 }  // namespace
 
 int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t* proof_out, size_t cap, size_t* proof_len) {
     if (!c || !comm) return DST_ERR_ARG;                      // nothing to agree through: the caller's bug, peers are its to stop
-    // Rank-local pre-flight failures must not leave the peers waiting in the first collective: they travel with the first status word.
-    int pre = DST_OK;
-    if (!pub || !proof_len) { c->err = "dst_prove_sharded: null argument"; pre = DST_ERR_ARG; }
-    else if (comm->world != c->prm.world || comm->rank != c->prm.rank) { c->err = "dst_prove_sharded: the communicator's rank / world differ from the context's"; pre = DST_ERR_ARG; }
-    else if (hipSetDevice(c->device) != hipSuccess) { c->err = "dst_prove_sharded: hipSetDevice failed"; pre = DST_ERR_HIP; }
+    Sharded S{c, comm};
+    // rank-local pre-flight failures must not leave the peers waiting in the first collective: they travel with the first status record
+    if (!pub || !proof_len) S.fail(DST_ERR_ARG, "dst_prove_sharded: null argument");
+    else if (comm->world != c->prm.world || comm->rank != c->prm.rank) S.fail(DST_ERR_ARG, "dst_prove_sharded: the communicator's rank / world differ from the context's");
+    else if (hipSetDevice(c->device) != hipSuccess) S.fail(DST_ERR_HIP, "dst_prove_sharded: hipSetDevice failed");
     const size_t G = comm->world;
-    Agree agree{c, comm};
-    int rc;
+    if (G > 8) return DST_ERR_ARG;                            // contexts cannot be created for more (the same on every rank)
     double t0 = wall_ms_shard();
     auto mark = [&](int i) { const double t = wall_ms_shard(); c->phase_ms[i] = t - t0; t0 = t; };
     // steps 1-2
-    if ((rc = agree(pre ? pre : dst_shard_commit_trace(c), "extension"))) return rc;
+    commit_trace_columns(S);
+    if (S.agreed) return S.agreed;                            // a collective itself failed
     mark(0);
     uint8_t trace_root[32], constraint_root[32];
-    if ((rc = agree(tree_exchange(c, comm, SH_TRACE_TREE, 0, trace_root), "trace tree"))) return rc;
+    {
+        // last state of the un-extended trace (op counter, program hash: evaluator.rs:37,73-74): rank 0 owns coset 0 of the extension,
+        // which IS the trace; the three values ride with the status records
+        const size_t stride = c->Bc * c->n;
+        const fe* from[3] = {c->lde + (c->n - 1), c->lde + stride + (c->n - 1), c->lde + 2 * stride + (c->n - 1)};
+        fe last[3];
+        tree_exchange(S, SH_TRACE_TREE, 0, trace_root, from, last);
+        if (S.agreed) return S.agreed;
+        c->op_count = (uint64_t)fe_to_u128(last[0]);
+        c->program_hash[0] = last[1]; c->program_hash[1] = last[2];
+        c->committed = true; c->constraints_done = c->composed = false;
+    }
     mark(1);
     // step 3
     std::vector<fe> coef(344);
     prng_vector(trace_root, 344, coef.data());
     int64_t bad = -1;
-    rc = dst_shard_eval_constraints(c, pub, (const uint8_t*)coef.data(), &bad);
+    S.local([&] { const int r = dst_shard_eval_constraints(c, pub, (const uint8_t*)coef.data(), &bad); return r == DST_ERR_AIR ? DST_OK : r; });
     {
-        std::vector<int64_t> bads(G, -1);
-        int r2 = comm->all_gather_host(&bad, bads.data(), sizeof(int64_t));
-        if (r2) { c->err = "constraint evaluation: " + comm->err; return r2; }
+        struct BadRec { int64_t bad; int64_t rc; } mine{bad, S.rc};
+        std::vector<BadRec> all(G);
+        if (!S.coll(comm->all_gather_host(&mine, all.data(), sizeof(BadRec)), "constraint evaluation")) return S.agreed;
         int64_t first = -1;
-        for (int64_t b : bads) if (b >= 0 && (first < 0 || b < first)) first = b;
+        for (size_t g = 0; g < G; g++) {
+            if (all[g].rc != DST_OK && S.agreed == DST_OK) { S.agreed = (int)all[g].rc; if (S.rc == DST_OK) c->err = "constraint evaluation: rank " + std::to_string(g) + " reported error " + std::to_string(all[g].rc); }
+            if (all[g].bad >= 0 && (first < 0 || all[g].bad < first)) first = all[g].bad;
+        }
+        if (S.agreed) return S.agreed;
         if (first >= 0) { c->err = "transition constraints were not satisfied at step " + std::to_string(first); return DST_ERR_AIR; }
     }
-    if ((rc = agree(rc == DST_ERR_AIR ? DST_OK : rc, "constraint evaluation"))) return rc;
     mark(2);
     // steps 4-5: the transition evaluations of all ranks, then combination (replicated) and the constraint tree
     {
         size_t bytes = 0;
-        if ((rc = dst_shard_export_size(c, SH_CEVAL, 0, &bytes))) return rc;
+        if (dst_shard_export_size(c, SH_CEVAL, 0, &bytes) || bytes * G > c->gather_bytes) { c->err = "dst_prove_sharded: gather buffer too small for the constraint evaluations"; return DST_ERR_ARG; }   // the same on every rank
         const void* send = dst_internal_boundary_by_evaluation() ? (const void*)c->ceval : (const void*)(c->ceval + 2 * (c->Bc / (c->B / 8)) * c->n);
-        if (bytes * G > c->gather_bytes) { c->err = "dst_prove_sharded: gather buffer too small for the constraint evaluations"; return DST_ERR_ARG; }
-        int r2 = comm->all_gather(send, c->gather_buf, bytes, c->stream);        // the import below rewrites `ceval` only after the exchange has completed
-        if (r2) c->err = "constraint evaluations: " + comm->err;
-        if ((rc = agree(r2 ? r2 : dst_shard_import(c, SH_CEVAL, 0, c->gather_buf, 1, nullptr), "constraint evaluations"))) return rc;
+        if (!S.coll(comm->all_gather(send, c->gather_buf, bytes, c->stream), "constraint evaluations")) return S.agreed;        // the import below rewrites `ceval` only after the exchange
+        S.local([&] { return dst_shard_import(c, SH_CEVAL, 0, c->gather_buf, 1, nullptr); });
     }
-    if ((rc = agree(dst_shard_combine(c), "combination"))) return rc;
+    S.local([&] { return dst_shard_combine(c); });
     mark(3);
-    if ((rc = agree(tree_exchange(c, comm, SH_CONSTRAINT_TREE, 0, constraint_root), "constraint tree"))) return rc;
+    tree_exchange(S, SH_CONSTRAINT_TREE, 0, constraint_root);
+    if (S.agreed) return S.agreed;
     mark(4);
     // step 6
     std::vector<fe> draws(516);
     prng_vector(constraint_root, 516, draws.data());
     std::vector<uint8_t> z1(c->W * 16), z2(c->W * 16);
-    if ((rc = agree(dst_compose(c, (const uint8_t*)draws.data(), z1.data(), z2.data()), "composition"))) return rc;
+    S.local([&] { return dst_compose(c, (const uint8_t*)draws.data(), z1.data(), z2.data()); });
     mark(5);
-    // step 7: sharded layers (leaves + local levels | tree exchange | draw + fold), then the replicated tail from one all-gather of evaluations
-    for (;;) {
-        if (c->fri_committed == c->fri_rep_from) {
-            const int d = c->fri_rep_from;
-            const size_t bytes = c->Bc * fri_nd(c, d) * 16;
-            if (bytes * G > c->gather_bytes) { c->err = "dst_prove_sharded: gather buffer too small for the FRI layer"; return DST_ERR_ARG; }
-            // this rank's cosets of the layer (contiguous, coset-major) -> all cosets in the gather buffer -> natural order, then the rest
-            // of the commit phase on every rank (the natural-order layer overwrites fri_e[d] only after the exchange has completed)
-            uint8_t root[32];
-            int r2 = comm->all_gather(c->fri_e[d], c->gather_buf, bytes, c->stream);
-            if (r2) c->err = "FRI tail: " + comm->err;
-            c->fri_tail_pending = true;
-            if ((rc = agree(r2 ? r2 : fri_replicated_tail(c, c->gather_buf, 1, root), "FRI tail"))) return rc;
-            break;
-        }
+    // step 7: sharded layers (leaves + local levels | tree exchange with status | draw + fold), then the replicated tail from one
+    // all-gather of evaluations.  fri_rep_from is fixed by the parameters: every rank walks the same layers.
+    const int rep_from = c->gather_buf ? c->fri_rep_from : fri_replicated_from(c);
+    for (int d = 0; d < rep_from; d++) {
         int more = 0;
-        if ((rc = agree(dst_shard_fri_layer(c, &more), "FRI layer"))) return rc;
-        const uint32_t d = (uint32_t)c->fri_committed - 1;
+        S.local([&] { return dst_shard_fri_layer(c, &more); });
         uint8_t root[32];
-        if ((rc = agree(tree_exchange(c, comm, SH_FRI_TREE, d, root), "FRI tree"))) return rc;
+        tree_exchange(S, SH_FRI_TREE, (uint32_t)d, root);
+        if (S.agreed) return S.agreed;
         fe x;
         prng_vector(root, 1, &x);                                 // fri/prover.rs:40 field::prng(root)
-        if ((rc = agree(dst_shard_fri_fold(c, (const uint8_t*)&x), "FRI fold"))) return rc;
+        S.local([&] { return dst_shard_fri_fold(c, (const uint8_t*)&x); });
+    }
+    {
+        const int d = rep_from;
+        const size_t bytes = c->Bc * fri_nd(c, d) * 16;
+        if (bytes * G > c->gather_bytes) { c->err = "dst_prove_sharded: gather buffer too small for the FRI layer"; return DST_ERR_ARG; }        // the same on every rank
+        // this rank's cosets of the layer (contiguous, coset-major) -> all cosets in the gather buffer -> natural order, then the rest
+        // of the commit phase on every rank (the natural-order layer overwrites fri_e[d] only after the exchange has completed)
+        uint8_t root[32];
+        if (!S.coll(comm->all_gather(c->fri_e[d], c->gather_buf, bytes, c->stream), "FRI tail")) return S.agreed;
+        S.local([&] { c->fri_tail_pending = true; return fri_replicated_tail(c, c->gather_buf, 1, root); });
     }
     mark(6);
     // step 8 (replicated: every rank grinds the same seed and finds the same first nonce)
-    std::vector<uint8_t> roots;
-    for (int d = 0; d < c->num_fri_layers; d++) roots.insert(roots.end(), c->fri_roots[d].begin(), c->fri_roots[d].end());
-    uint8_t seed0[32], seed1[32];
-    if (!blake3_short(roots.data(), roots.size(), seed0)) { c->err = "too many FRI roots"; return DST_ERR_ARG; }
     uint64_t nonce = 0;
-    if ((rc = agree(dst_pow_grind(c, seed0, c->prm.grinding_factor, seed1, &nonce), "proof of work"))) return rc;
     std::vector<uint64_t> positions;
-    if (query_positions(seed1, c->N, (uint32_t)c->B, c->prm.num_queries, positions)) { c->err = "could not generate enough query positions"; return DST_ERR_ARG; }
+    S.local([&]() -> int {
+        std::vector<uint8_t> roots;
+        for (int d = 0; d < c->num_fri_layers; d++) roots.insert(roots.end(), c->fri_roots[d].begin(), c->fri_roots[d].end());
+        uint8_t seed0[32], seed1[32];
+        if (!blake3_short(roots.data(), roots.size(), seed0)) { c->err = "too many FRI roots"; return DST_ERR_ARG; }
+        int r = dst_pow_grind(c, seed0, c->prm.grinding_factor, seed1, &nonce);
+        if (r) return r;
+        if (query_positions(seed1, c->N, (uint32_t)c->B, c->prm.num_queries, positions)) { c->err = "could not generate enough query positions"; return DST_ERR_ARG; }
+        return DST_OK;
+    });
     mark(7);
-    // step 9
+    // step 9: the lengths of the ranks' opening blobs travel with their status
     std::vector<uint64_t> lens(G, 0);
     size_t mine = 0;
-    if ((rc = agree(dst_shard_open(c, positions.data(), (uint32_t)positions.size(), nullptr, 0, &mine, lens.data()), "openings"))) return rc;
+    S.local([&] { return dst_shard_open(c, positions.data(), (uint32_t)positions.size(), nullptr, 0, &mine, lens.data()); });
+    {
+        struct LenRec { uint64_t len; int64_t rc; } rec{(uint64_t)mine, S.rc};
+        std::vector<LenRec> all(G);
+        if (!S.coll(comm->all_gather_host(&rec, all.data(), sizeof(LenRec)), "openings")) return S.agreed;
+        for (size_t g = 0; g < G; g++) {
+            if (all[g].rc != DST_OK && S.agreed == DST_OK) { S.agreed = (int)all[g].rc; if (S.rc == DST_OK) c->err = "before the openings: rank " + std::to_string(g) + " reported error " + std::to_string(all[g].rc); }
+            lens[g] = all[g].len;            // every rank derives the same plan, so this equals what dst_shard_open computed locally
+        }
+        if (S.agreed) return S.agreed;
+    }
     size_t width = 1;
     for (uint64_t l : lens) if (l > width) width = (size_t)l;
-    std::vector<uint8_t> blob(width, 0), all(width * G);
-    rc = dst_shard_open(c, positions.data(), (uint32_t)positions.size(), blob.data(), width, &mine, nullptr);
-    {
-        int r2 = comm->all_gather_host(blob.data(), all.data(), width);
-        if (r2) { c->err = "openings: " + comm->err; return r2; }
+    std::vector<uint8_t> blob(width + 8, 0), all(( width + 8) * G);
+    S.local([&] { return dst_shard_open(c, positions.data(), (uint32_t)positions.size(), blob.data(), width, &mine, nullptr); });
+    { const int64_t rc64 = S.rc; memcpy(blob.data() + width, &rc64, 8); }                    // the status rides behind the blob
+    if (!S.coll(comm->all_gather_host(blob.data(), all.data(), width + 8), "openings")) return S.agreed;
+    for (size_t g = 0; g < G && S.agreed == DST_OK; g++) {
+        int64_t rc64; memcpy(&rc64, all.data() + g * (width + 8) + width, 8);
+        if (rc64 != DST_OK) { S.agreed = (int)rc64; if (S.rc == DST_OK) c->err = "openings: rank " + std::to_string(g) + " reported error " + std::to_string(rc64); }
     }
-    if ((rc = agree(rc, "openings"))) return rc;
+    if (S.agreed) return S.agreed;
     std::vector<uint8_t> packed;
-    for (size_t g = 0; g < G; g++) packed.insert(packed.end(), all.begin() + g * width, all.begin() + g * width + lens[g]);
-    rc = dst_shard_assemble(c, positions.data(), (uint32_t)positions.size(), nonce, packed.data(), lens.data(), proof_out, cap, proof_len);
+    for (size_t g = 0; g < G; g++) packed.insert(packed.end(), all.begin() + g * (width + 8), all.begin() + g * (width + 8) + lens[g]);
+    // assembly is deterministic host work on identical inputs: it succeeds or fails on every rank alike
+    const int rc = dst_shard_assemble(c, positions.data(), (uint32_t)positions.size(), nonce, packed.data(), lens.data(), proof_out, cap, proof_len);
     mark(8);
-    return agree(rc, "proof assembly");
+    return rc;
 }
 
 // One call for a single-process host that drives all GPUs of the node itself: `world` contexts (rank r of world, one per device, each

@@ -18,7 +18,7 @@ DST_OK, DST_ERR_ARG, DST_ERR_HIP, DST_ERR_AIR, DST_ERR_STATE = 0, -1, -2, -3, -4
 BUF = {"polys": 0, "lde": 1, "trace_leaves": 2, "trace_nodes": 3, "ceval_i": 4, "ceval_f": 5, "ceval_t": 6, "cpoly": 7, "cevals": 8,
        "cnodes": 9, "comp_poly": 10, "comp_evals": 11, "fri_evals": 12, "fri_nodes": 13, "fri_leaves": 14}
 
-EXPORTS = ["dst_ctx_create", "dst_ctx_destroy", "dst_last_error", "dst_phase_ms", "dst_trace_upload", "dst_trace_upload_contiguous",
+EXPORTS = ["dst_ctx_create", "dst_ctx_destroy", "dst_last_error", "dst_phase_ms", "dst_trace_upload", "dst_trace_upload_contiguous", "dst_trace_upload_owned",
            "dst_commit_trace", "dst_eval_constraints", "dst_compose", "dst_fri_commit_layer", "dst_fri_fold", "dst_pow_grind",
            "dst_build_proof", "dst_prove", "dst_prng_vector", "dst_query_positions", "dst_blake3", "dst_fibonacci_trace",
            "dst_read_buffer", "dst_bench_mulmod", "dst_bench_mad", "dst_bench_code", "dst_trace_upload_async", "dst_pinned_alloc", "dst_pinned_free", "dst_set_profiling", "dst_kernel_stats", "dst_field_op",
@@ -268,6 +268,13 @@ class Context:
 
     def release_pinned(self, handle):
         self.lib.dst_pinned_free(handle)
+
+    def upload_owned(self, cols):
+        """dst_trace_upload_owned: only the registers this rank interpolates (r = rank mod world) travel to the device; for prove_sharded"""
+        cols = np.ascontiguousarray(cols, dtype=np.uint64)
+        rank, world = self.params.rank, self.params.world
+        ptrs = (ctypes.c_void_p * self.W)(*[cols[i].ctypes.data if i % world == rank else None for i in range(self.W)])
+        self._check(self.lib.dst_trace_upload_owned(self._h, ptrs))
 
     def upload_async(self, table):
         """dst_trace_upload_async: returns at once, the next commit_trace() / prove() consumes the registers as they arrive"""

@@ -68,6 +68,10 @@ int dst_phase_ms(const dst_ctx* ctx, double out_ms[9]);
 int dst_trace_upload(dst_ctx* ctx, const uint8_t* const* cols);
 /* same, from one contiguous [W][n] buffer */
 int dst_trace_upload_contiguous(dst_ctx* ctx, const uint8_t* cols);
+/* Sharded contexts (world > 1): uploads only the registers this rank interpolates, r = rank (mod world); cols[r] of the other registers is
+ * not read.  dst_prove_sharded all-gathers the coefficient vectors ("trace columns shard across the GPUs"), so every GPU
+ * receives 1/world of the trace from its host.  Only dst_prove_sharded accepts a context in this state. */
+int dst_trace_upload_owned(dst_ctx* ctx, const uint8_t* const* cols);
 /* Asynchronous form for a host-resident trace (what stark::prove receives: prover.rs:17, trace_table.rs:10).  Starts the copies of
  * the W columns on a copy stream and returns at once; the next dst_commit_trace / dst_prove interpolates and extends the registers
  * group by group as their copies land, so that all but the first group's transfer overlaps with the extension.  The host buffers

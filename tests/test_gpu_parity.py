@@ -569,6 +569,41 @@ def test_config5_full_size_on_one_gpu(oracle):
     _accepts_and_rejects(oracle, proof, program_hash, result)
 
 
+def _sharded_local_equals_single_context(log_n, world, **options):
+    """dst_prove_sharded_local (collectives behind the C-ABI, one thread per rank, all ranks sharing the one GPU of the test box) against
+    the single-context proof of the same trace -- which the oracle's verifier judges in the config 4 / config 5 tests"""
+    import distaff_amd as D
+    cols, program_hash, result = _fib(log_n)
+    ctx = D.Context(log_n, 20, 1, 0, **options)
+    ctx.upload(cols)
+    expected = ctx.prove([1, 0], [result], cap=1 << 24)
+    ctx.close()
+    ctxs = []
+    try:
+        for r in range(world):
+            c = D.Context(log_n, 20, 1, 0, rank=r, world=world, **options)
+            c.upload_owned(cols)                                     # 1 / world of the trace per rank: the interpolation is split by columns
+            ctxs.append(c)
+        assert D.prove_sharded_local(ctxs, [1, 0], [result], cap=1 << 24) == expected
+    finally:
+        for c in ctxs:
+            c.close()
+
+
+def test_config4_sharded_over_8_ranks_equals_single_context():
+    """BASELINE config 4 (2^22-step trace, default ProofOptions, 8 ranks): the sharded prover behind the C-ABI with 8 thread-ranks --
+    four LDE cosets per rank, k-range tree exchange of 2^22 boundary nodes per tree, three-pass transforms -- returns the single-context
+    proof.  (On the driver's 8-GPU node the ranks are processes over RCCL; here they share the box's one GPU: ~20 GiB per rank.)"""
+    _sharded_local_equals_single_context(22, 8)
+
+
+def test_config5_shape_sharded_over_8_ranks_equals_single_context():
+    """BASELINE config 5's shape (blowup 16, 100 queries, 8 ranks = two LDE cosets per rank: the constraint tree has no rank-local
+    level) at 2^22 steps.  At the stated 2^24 steps one rank's buffers are ~60 GiB: eight of them do not fit the ONE GPU of this box
+    (the single-context proof at 2^24 is test_config5_full_size_on_one_gpu); the partitioning does not depend on the size."""
+    _sharded_local_equals_single_context(22, 8, log_blowup=4, num_queries=100)
+
+
 def test_sharded_world8_at_bench_size_equals_single_context():
     """Config 3's trace (2^20 steps, default options) through the sharded path with 8 thread-ranks sharing the GPU: every rank must
     return the single-context proof (which the oracle's verifier accepts in test_config3_full_size_proof_is_accepted_and_tamper_evident)."""
@@ -633,7 +668,12 @@ def test_prove_sharded_behind_the_c_abi(oracle, monkeypatch, world, log_n, repli
     ctxs = []
     for r in range(world):
         ctx = D.Context(log_n, t.width, t.ctx_depth, t.loop_depth, rank=r, world=world, grinding=8)
-        ctx.upload(t.columns)
+        # the interpolation is split by columns: a rank needs only the registers r (mod world) of the trace on its device
+        # (dst_trace_upload_owned); a whole trace works as well (every other configuration)
+        if (world + log_n) % 2 == 0:
+            ctx.upload_owned(t.columns)
+        else:
+            ctx.upload(t.columns)
         ctxs.append(ctx)
     for _ in range(2):                                                # twice: the buffers of the first proof are reused
         assert D.prove_sharded_local(ctxs, t.public_inputs, op.outputs) == expected
