@@ -820,10 +820,14 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
     if (G > 8) return DST_ERR_ARG;                            // contexts cannot be created for more (the same on every rank)
     double t0 = wall_ms_shard();
     auto mark = [&](int i) { const double t = wall_ms_shard(); c->phase_ms[i] = t - t0; t0 = t; };
-    // steps 1-2
+    // steps 1-2.  Nothing waits for the extension on the host (the tree exchange is queued behind it): its share of the phase times
+    // comes from two events on the stream
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    const bool timed = hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess && hipEventRecord(ev0, c->stream) == hipSuccess;
     commit_trace_columns(S);
-    if (S.agreed) return S.agreed;                            // a collective itself failed
-    mark(0);
+    if (timed) (void)hipEventRecord(ev1, c->stream);          // after the leaf hashing and the rank-local tree levels
+    if (S.agreed) { if (ev0) hipEventDestroy(ev0); if (ev1) hipEventDestroy(ev1); return S.agreed; }      // a collective itself failed
+    const double t_commit = t0;
     uint8_t trace_root[32], constraint_root[32];
     {
         // last state of the un-extended trace (op counter, program hash: evaluator.rs:37,73-74): rank 0 owns coset 0 of the extension,
@@ -832,12 +836,22 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
         const fe* from[3] = {c->lde + (c->n - 1), c->lde + stride + (c->n - 1), c->lde + 2 * stride + (c->n - 1)};
         fe last[3];
         tree_exchange(S, SH_TRACE_TREE, 0, trace_root, from, last);
-        if (S.agreed) return S.agreed;
+        if (S.agreed) { if (ev0) hipEventDestroy(ev0); if (ev1) hipEventDestroy(ev1); return S.agreed; }
         c->op_count = (uint64_t)fe_to_u128(last[0]);
         c->program_hash[0] = last[1]; c->program_hash[1] = last[2];
         c->committed = true; c->constraints_done = c->composed = false;
     }
-    mark(1);
+    {
+        // phase 0 = interpolation + extension, phase 1 = leaves, tree levels and the exchange: split the wall time of both at the point
+        // the device reached after the rank-local tree levels, less the leaf hashing that ran before it
+        float dev_ms = 0;
+        const double now = wall_ms_shard(), both = now - t_commit;
+        if (timed && hipEventElapsedTime(&dev_ms, ev0, ev1) == hipSuccess && dev_ms < both) { c->phase_ms[0] = dev_ms; c->phase_ms[1] = both - dev_ms; }
+        else { c->phase_ms[0] = 0; c->phase_ms[1] = both; }
+        t0 = now;
+    }
+    if (ev0) hipEventDestroy(ev0);
+    if (ev1) hipEventDestroy(ev1);
     // step 3
     std::vector<fe> coef(344);
     prng_vector(trace_root, 344, coef.data());

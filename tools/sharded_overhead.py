@@ -1,35 +1,29 @@
 #!/usr/bin/env python3
-"""Cost of the sharded orchestration itself on ONE GPU without torch: ShardedProver over a one-rank in-process communicator
-against dst_prove on the same trace (stage times of the sharded run are printed).   python tools/sharded_overhead.py [log_n]"""
+"""Where the sharded code path (dst_prove_sharded with ONE rank over RCCL) spends more than the single-context path on the same box:
+runs `bench.py` both ways and prints the kernels whose time per proof differs by more than 0.03 ms, and the launch counts.
+    python tools/sharded_overhead.py"""
+import json
 import os
+import subprocess
 import sys
-import time
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-import distaff_amd as D
-from distaff_amd import sharded
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
-log_n = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-cols, program_hash, result = D.fibonacci_trace(log_n)
-ctx = D.Context(log_n, 20, 1, 0)
-ctx.upload(cols)
-for _ in range(2):
-    expected = ctx.prove([1, 0], [result])
-t0 = time.perf_counter()
-for _ in range(5):
-    ctx.prove([1, 0], [result])
-single = (time.perf_counter() - t0) / 5 * 1e3
-prover = sharded.ShardedProver(ctx, sharded.LocalComm.create(1)[0])
-for _ in range(2):
-    proof = prover.prove([1, 0], [result])
-assert proof == expected
-stages = {}
-t0 = time.perf_counter()
-for _ in range(5):
-    prover.prove([1, 0], [result])
-    for k, v in prover.stage_ms.items():
-        stages[k] = stages.get(k, 0.0) + v / 5
-shard = (time.perf_counter() - t0) / 5 * 1e3
-print("2^%d: dst_prove %.2f ms, sharded orchestration (1 rank, host-staged exchanges) %.2f ms" % (log_n, single, shard))
-print("   " + ", ".join("%s %.2f" % (k, v) for k, v in stages.items()))
-ctx.close()
+
+def run(extra):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-upload-leg", "--no-verify"] + extra,
+                         stdout=subprocess.PIPE, stderr=subprocess.DEVNULL).stdout.decode()
+    return json.loads([l for l in out.splitlines() if l.startswith("{")][-1])
+
+
+a, b = run([]), run(["--force-sharded"])
+print("single %.3f ms, sharded (1 rank) %.3f ms" % (a["ms_per_step"], b["ms_per_step"]))
+print("phases single :", a["phase_ms"])
+print("phases sharded:", b["phase_ms"])
+ka, kb = a["kernels"], b["kernels"]
+print("launches: single %d, sharded %d; device time %.3f / %.3f ms" % (sum(v["launches"] for v in ka.values()), sum(v["launches"] for v in kb.values()),
+                                                                      sum(v["ms_per_step"] for v in ka.values()), sum(v["ms_per_step"] for v in kb.values())))
+for k in sorted(set(ka) | set(kb), key=lambda k: -abs(kb.get(k, {}).get("ms_per_step", 0) - ka.get(k, {}).get("ms_per_step", 0))):
+    x, y = ka.get(k, {"ms_per_step": 0, "launches": 0}), kb.get(k, {"ms_per_step": 0, "launches": 0})
+    if abs(x["ms_per_step"] - y["ms_per_step"]) >= 0.03:
+        print("  %-40s single %7.3f ms x%-3d   sharded %7.3f ms x%-3d   %+.3f" % (k[:40], x["ms_per_step"], x["launches"], y["ms_per_step"], y["launches"], y["ms_per_step"] - x["ms_per_step"]))
