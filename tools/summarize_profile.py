@@ -36,7 +36,7 @@ def main():
         for row in csv.DictReader(fh):
             stats[row["Name"]] = row
     merged = defaultdict(dict)
-    for sub in ("fetch", "write", "sq1", "sq2"):
+    for sub in ("fetch", "write", "sq1", "sq2", "sq3"):
         for k, cs in read_counters(os.path.join(prof, sub)).items():
             for cname, (total, cnt) in cs.items():
                 merged[k][cname] = total / max(cnt, 1)
