@@ -615,29 +615,54 @@ __global__ void __launch_bounds__(AIR_THREADS, air_waves_per_simd(SD, SLCAP, SEC
         // loop image (WRAP, BREAK)
         acc.emit(19, 2, fe_mul(fe_add(f_wrap, f_break), fe_sub(c_sp[0], c_lp[0])));
         // context stack: BEGIN/LOOP push sponge[0]; TEND/FEND pop; WRAP/BREAK/VOID copy
-        {
-            fe push = fe_add(f_begin, f_loop), pop = fe_add(f_tend, f_fend), cpy = fe_add(fe_add(f_wrap, f_break), f_void);
+        // loop stack: BEGIN/TEND/FEND/WRAP/VOID copy; LOOP shifts right (slot 0 unconstrained); BREAK pops
+        const fe push = fe_add(f_begin, f_loop), pop = fe_add(f_tend, f_fend), ccpy = fe_add(fe_add(f_wrap, f_break), f_void);
+        const fe lcpy = fe_add(fe_add(fe_add(f_begin, f_tend), fe_add(f_fend, f_wrap)), f_void);
+        if constexpr (CL <= 2 && LL <= 1) {
+            // small shapes: the slices are register arrays with constant indices
 #pragma unroll
             for (int i = 0; i < CL; i++) {
                 if (i >= cl) break;
                 fe_acc A; fe_acc_zero(A);
                 fe_acc_mac(A, push, fe_sub(i == 0 ? c_sp[0] : c_ctx[i - 1 < 0 ? 0 : i - 1], n_ctx[i]));
                 fe_acc_mac(A, pop, i + 1 < cl ? fe_sub(c_ctx[i + 1 < CL ? i + 1 : 0], n_ctx[i]) : n_ctx[i]);
-                fe_acc_mac(A, cpy, fe_sub(c_ctx[i], n_ctx[i]));
+                fe_acc_mac(A, ccpy, fe_sub(c_ctx[i], n_ctx[i]));
                 const fe v = fe_acc_reduce(A);
                 acc.emit(20 + i, 2, v);
             }
-        }
-        // loop stack: BEGIN/TEND/FEND/WRAP/VOID copy; LOOP shifts right (slot 0 unconstrained); BREAK pops
-        {
-            fe cpy = fe_add(fe_add(fe_add(f_begin, f_tend), fe_add(f_fend, f_wrap)), f_void);
 #pragma unroll
             for (int i = 0; i < LL; i++) {
                 if (i >= ll) break;
-                fe v = fe_mul(cpy, fe_sub(c_lp[i], n_lp[i]));
+                fe v = fe_mul(lcpy, fe_sub(c_lp[i], n_lp[i]));
                 if (i >= 1) v = fe_add(v, fe_mul(f_loop, fe_sub(c_lp[i - 1 < 0 ? 0 : i - 1], n_lp[i])));
                 v = fe_add(v, fe_mul(f_break, i + 1 < ll ? fe_sub(c_lp[i + 1 < LL ? i + 1 : 0], n_lp[i]) : n_lp[i]));
                 acc.emit(20 + cl + i, 2, v);
+            }
+        } else {
+            // any depth (up to 16 + 8 registers, known at run time): the rows are read from memory inside run-time loops -- register arrays
+            // with run-time indices would live in scratch.  A slice of depth 0 is one zero (trace_state.rs:58-59).
+            auto ctx_cur = [&](int i) { return (uint32_t)i < a.ctx_depth ? CUR(15 + i) : fe_zero(); };
+            auto ctx_nxt = [&](int i) { return (uint32_t)i < a.ctx_depth ? NXT(15 + i) : fe_zero(); };
+            const uint32_t lcol = 15 + a.ctx_depth;
+            auto lp_cur = [&](int i) { return (uint32_t)i < a.loop_depth ? CUR(lcol + i) : fe_zero(); };
+            auto lp_nxt = [&](int i) { return (uint32_t)i < a.loop_depth ? NXT(lcol + i) : fe_zero(); };
+#pragma unroll 1
+            for (int i = 0; i < cl; i++) {
+                const fe ni = ctx_nxt(i);
+                fe_acc A; fe_acc_zero(A);
+                fe_acc_mac(A, push, fe_sub(i == 0 ? c_sp[0] : ctx_cur(i - 1), ni));
+                fe_acc_mac(A, pop, i + 1 < cl ? fe_sub(ctx_cur(i + 1), ni) : ni);
+                fe_acc_mac(A, ccpy, fe_sub(ctx_cur(i), ni));
+                acc.emit(20 + i, 2, fe_acc_reduce(A));
+            }
+#pragma unroll 1
+            for (int i = 0; i < ll; i++) {
+                const fe ni = lp_nxt(i);
+                fe_acc A; fe_acc_zero(A);
+                fe_acc_mac(A, lcpy, fe_sub(lp_cur(i), ni));
+                if (i >= 1) fe_acc_mac(A, f_loop, fe_sub(lp_cur(i - 1), ni));
+                fe_acc_mac(A, f_break, i + 1 < ll ? fe_sub(lp_cur(i + 1), ni) : ni);
+                acc.emit(20 + cl + i, 2, fe_acc_reduce(A));
             }
         }
     }

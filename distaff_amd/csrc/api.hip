@@ -208,8 +208,12 @@ static int ctx_init(dst_ctx* c) {
     // staging buffer of the two-pass transforms: tmp_regs registers x Bc cosets per pair of launches.  Every launch ends with a partly
     // filled last wave of workgroups (4 registers x 31 cosets at n = 2^20: 7.75 waves of 512 resident workgroups), so as many registers per
     // launch as 12 GiB of staging hold (all 20 at n = 2^20: 39.75 waves, one tail instead of five); at least 4.  DISTAFF_TMP_REGS overrides.
+    // The cap follows the free memory of the device at creation (several contexts may share one GPU: thread-ranks, tests): at most 12 GiB
+    // and at most a quarter of what is free after the buffers above.
+    size_t stage_cap = (size_t)12 << 30;
+    { size_t free_b = 0, total_b = 0; if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 4 < stage_cap) stage_cap = free_b / 4; }
     c->tmp_regs = 4;
-    while (c->tmp_regs < c->W && (c->tmp_regs + 1) * (pl.log_n3 ? 2 : 1) * c->Bc * n * sizeof(fe) <= ((size_t)12 << 30)) c->tmp_regs++;
+    while (c->tmp_regs < c->W && (c->tmp_regs + 1) * (pl.log_n3 ? 2 : 1) * c->Bc * n * sizeof(fe) <= stage_cap) c->tmp_regs++;
     if (const char* e = getenv("DISTAFF_TMP_REGS")) { const long k = atol(e); if (k >= 4 && k <= (long)c->W) c->tmp_regs = (size_t)k; }
     if ((r = dev_alloc(c, &c->tmp, c->Bc * c->tmp_regs * n))) return r;
     if (pl.log_n3 && (r = dev_alloc(c, &c->tmp2, c->Bc * c->tmp_regs * n))) return r;

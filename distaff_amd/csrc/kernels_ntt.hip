@@ -19,6 +19,7 @@
 // 256-point tiles of three-pass plans).  A second, register-radix kernel family (ntt_reg_kernel) is kept as an independent
 // implementation that the tests run at every tile length.
 #include "ctx.h"
+#include <mutex>
 #include <type_traits>
 #include "ntt_lds.h"
 
@@ -472,7 +473,10 @@ static uint32_t ntt_coset_fast(size_t groups, size_t cosets) {
     return (cosets > 1 && groups % 8 == 0 && !(e && e[0] == '0')) ? 1u : 0u;
 }
 static void ntt_raise_lds_limit(dst_ctx* c) {                  // tile + stage twiddles exceed the 64 KiB default
+    // contexts of several ranks may run as threads of one process (dst_prove_sharded_local): the once-per-device marks are guarded
+    static std::mutex mu;
     static bool raised[64] = {};
+    std::lock_guard<std::mutex> lock(mu);
     if (c->device < 0 || c->device >= 64 || raised[c->device]) return;
     (void)hipFuncSetAttribute((const void*)ntt_pass_a<512>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ntt_pass_a<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -491,8 +495,10 @@ static void ntt_raise_lds_limit(dst_ctx* c) {                  // tile + stage t
 }
 // DISTAFF_NTT_DEBUG=1 prints, once per distinct launch shape, how many workgroups of the instance are resident per CU
 static void ntt_report_occupancy(const char* name, bool pass_b, int threads, bool eight, size_t lds) {
+    static std::mutex mu;
     static std::map<std::string, bool> seen;
     char key[128]; snprintf(key, sizeof key, "%s/%d/%d/%zu", name, threads, (int)eight, lds);
+    std::lock_guard<std::mutex> lock(mu);
     if (seen[key]) return; seen[key] = true;
     int nb = -1;
     hipError_t e;
