@@ -574,6 +574,25 @@ int dst_fri_commit_layer(dst_ctx* c, uint8_t layer_root[32], int* more) {
     c->phase_ms[6] += wall_ms() - t0;
     return DST_OK;
 }
+// The rest of the FRI commit phase in ONE launch once the next layer to commit is small (k_fri_tail: rows hashed, trees built, x drawn
+// from every root and the folds done by one workgroup; DISTAFF_FRI_TAIL=0 keeps the per-layer launches, tests compare both).  Returns
+// 1 when the tail ran (all remaining roots appended), 0 when the next layer is still too large, < 0 on error.
+#define DST_FRI_TAIL_MAX_SIZE ((size_t)1 << 13)
+int dst_internal_fri_tail(dst_ctx* c, std::vector<uint8_t>& roots) {
+    const int d = c->fri_committed;
+    if (d < 1 || d != c->fri_folded || d >= c->num_fri_layers || c->fri_size[d] > DST_FRI_TAIL_MAX_SIZE) return 0;
+    if (const char* e = getenv("DISTAFF_FRI_TAIL")) if (e[0] == '0') return 0;
+    double t0 = wall_ms();
+    const int count = c->num_fri_layers - d;
+    std::vector<uint8_t> r((size_t)count * 32);
+    int rc = k_fri_tail(c, d, r.data());
+    if (rc) return rc;
+    for (int i = 0; i < count; i++) c->fri_roots.push_back(std::vector<uint8_t>(r.begin() + 32 * i, r.begin() + 32 * (i + 1)));
+    roots.insert(roots.end(), r.begin(), r.end());
+    c->fri_committed = c->num_fri_layers; c->fri_folded = c->num_fri_layers - 1;
+    c->phase_ms[6] += wall_ms() - t0;
+    return 1;
+}
 int dst_fri_fold(dst_ctx* c, const uint8_t special_x[16]) {
     if (!c || !special_x) return DST_ERR_ARG;
     int d = c->fri_folded;
@@ -638,6 +657,8 @@ int dst_prove(dst_ctx* c, const dst_public* pub, uint8_t* proof_out, size_t cap,
     if ((rc = dst_compose(c, (const uint8_t*)draws.data(), z1.data(), z2.data()))) return rc;
     std::vector<uint8_t> roots;
     for (;;) {                                                   // fri::reduce (fri/prover.rs:11-53)
+        // the small layers (at most 2^13 evaluations, natural order) in one launch, Fiat-Shamir draws on the device
+        if (int rt = dst_internal_fri_tail(c, roots)) { if (rt < 0) return rt; break; }
         uint8_t root[32]; int more = 0;
         if ((rc = dst_fri_commit_layer(c, root, &more))) return rc;
         roots.insert(roots.end(), root, root + 32);

@@ -229,6 +229,7 @@ void k_sub_dot_at0(dst_ctx* c, fe* y, const fe* values_dev, const fe* coeffs_dev
 void k_sub_at0(dst_ctx* c, fe* y, const fe* v_dev);                                                   // y[0] -= v[0]
 // FRI
 void k_fri_fold(dst_ctx* c, int layer, fe special_x);
+int k_fri_tail(dst_ctx* c, int first, uint8_t* roots_out);       // natural-order layers first .. last in one launch (kernels_poly.hip)
 // PoW
 int k_pow(dst_ctx* c, const uint8_t seed[32], uint32_t grinding, uint64_t* nonce);
 // gathers for openings

@@ -173,7 +173,11 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
         // (OutB); here that does not pay: in the 128-register instances the four-step twiddles (and the last-stage pairs from global memory)
         // live in the last round spill (13.15 / 13.3 against 13.05 ms), in the spill-free fixed-shape instance it is within the noise
         // (18.85 against 18.95 ms of extension, with the twiddle requested before or after the butterfly).
+#if defined(NTT_RB8)
+        constexpr int RB = WPE > 4 ? NTT_RB8 : THREADS == 512 ? 2 : 4;
+#else
         constexpr int RB = WPE > 4 ? 1 : THREADS == 512 ? 2 : 4;
+#endif
         fe* __restrict__ dst = dst0 + tile * T;          // uniform bases, 32-bit lane offsets
         const tw4_t* __restrict__ tw = tw4 + tile * T;
         for (uint32_t base = 0; base < count; base += RB * THREADS) {
@@ -241,8 +245,13 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_b(NttArgs a, const fe* 
         __syncthreads();
         if (PREFETCH && it + 1 < a.tiles_per_block) NTT_FETCH_B(tile0 + it + 1)
         const OutB out{dst + k1_0, (uint32_t)a.dst_k_stride, log_n2, a.has_scale != 0, a.scale};
-        if constexpr (LOG_LEN != 0) lds_ntt_dif_fixed<THREADS, LOG_LEN, LOG_T, OutB>(L, TW, out);
-        else lds_ntt_dif<THREADS, OutB>(L, TW, log_n2, log_t, 1u, log_n2 + 1u, out);
+#if defined(NTT_TW_GLOBAL_B)
+        const fe_tw* Wuse = a.stage_tw;          // experiment: stage twiddles through the vector cache instead of LDS
+#else
+        const fe_tw* Wuse = TW;
+#endif
+        if constexpr (LOG_LEN != 0) lds_ntt_dif_fixed<THREADS, LOG_LEN, LOG_T, OutB>(L, Wuse, out);
+        else lds_ntt_dif<THREADS, OutB>(L, Wuse, log_n2, log_t, 1u, log_n2 + 1u, out);
     }
 }
 

@@ -380,6 +380,114 @@ void k_fri_fold(dst_ctx* c, int layer, fe special_x) {
     }
 }
 
+// ---- the small FRI layers in ONE launch -------------------------------------------------------------------------------------------------
+// fri::reduce (fri/prover.rs:11-53) from a layer of at most 2^13 evaluations on: per layer hash the rows, build the tree, draw
+// x = field::prng(root) (field.rs:264-275: StdRng = ChaCha20 seeded with the root, Uniform over the field), fold with it.  On the host each
+// of these layers is four launches and a root read-back; here one workgroup walks through all of them and the roots are read back once.
+// The draw is the device statement of host_util.h's StdRng / uniform_field (same word order and rejection rule; the tests compare proofs).
+__device__ void fri_chacha_block(const uint32_t key[8], uint64_t counter, uint32_t out[16]) {
+    uint32_t in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                       (uint32_t)counter, (uint32_t)(counter >> 32), 0u, 0u};
+    uint32_t x[16];
+    for (int i = 0; i < 16; i++) x[i] = in[i];
+    auto rotl = [](uint32_t v, int n) { return (v << n) | (v >> (32 - n)); };
+    auto qr = [&](int a, int b, int c, int d) {
+        x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 16); x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 12);
+        x[a] += x[b]; x[d] = rotl(x[d] ^ x[a], 8);  x[c] += x[d]; x[b] = rotl(x[b] ^ x[c], 7);
+    };
+    for (int r = 0; r < 10; r++) {
+        qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+        qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
+    }
+    for (int i = 0; i < 16; i++) out[i] = x[i] + in[i];
+}
+// Uniform::from(0..p).sample(StdRng::from_seed(root)): v = next u128 (four words, low first); (hi, lo) = v * p; accept hi when lo <= zone,
+// zone = MAX - (MAX - p + 1) % p = p - 1 (2^128 - p < p)
+__device__ fe fri_prng(const uint32_t root[8]) {
+    uint32_t buf[16];
+    for (uint64_t counter = 0;; counter++) {
+        fri_chacha_block(root, counter, buf);
+        for (int w = 0; w < 16; w += 4) {
+            const uint32_t v[4] = {buf[w], buf[w + 1], buf[w + 2], buf[w + 3]};
+            const uint32_t pl[4] = {FE_P0, FE_P1, FE_P2, FE_P3};
+            uint32_t t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int i = 0; i < 4; i++) {
+                uint64_t carry = 0;
+                for (int j = 0; j < 4; j++) { const uint64_t cur = (uint64_t)v[i] * pl[j] + t[i + j] + carry; t[i + j] = (uint32_t)cur; carry = cur >> 32; }
+                t[i + 4] = (uint32_t)carry;
+            }
+            // lo = t[0..3] <= p - 1  <=>  lo < p
+            bool below = false, decided = false;
+            for (int i = 3; i >= 0 && !decided; i--) { if (t[i] != pl[i]) { below = t[i] < pl[i]; decided = true; } }
+            if (decided && below) return fe_make(t[4], t[5], t[6], t[7]);
+        }
+    }
+}
+#define FRI_TAIL_MAX_LAYERS 12
+#define FRI_TAIL_THREADS 1024
+struct FriTailArgs {
+    fe* e[FRI_TAIL_MAX_LAYERS]; digest* leaves[FRI_TAIL_MAX_LAYERS]; digest* nodes[FRI_TAIL_MAX_LAYERS];
+    uint32_t rows[FRI_TAIL_MAX_LAYERS];            // R = size / 4 of layer first + i
+    uint32_t first, count;                         // layers first .. first + count - 1 (the last one is the remainder: not folded)
+    uint32_t* roots;                               // [count][8]
+    FoldArgs fold;                                 // alpha is drawn per layer
+};
+__global__ void __launch_bounds__(FRI_TAIL_THREADS) fri_tail_kernel(FriTailArgs a) {
+    __shared__ fe alpha_sh;
+    const uint32_t tid = threadIdx.x;
+    for (uint32_t li = 0; li < a.count; li++) {
+        const uint32_t R = a.rows[li];
+        const fe* e = a.e[li];
+        digest* leaves = a.leaves[li]; digest* nodes = a.nodes[li];
+        for (uint32_t r = tid; r < R; r += FRI_TAIL_THREADS) {            // fri/utils.rs:16-22 hash_values
+            uint32_t m[16], h[8];
+#pragma unroll
+            for (uint32_t q = 0; q < 4; q++) { const fe v = e[r + q * R]; m[4 * q] = v.v[0]; m[4 * q + 1] = v.v[1]; m[4 * q + 2] = v.v[2]; m[4 * q + 3] = v.v[3]; }
+            b3_hash64(m, h);
+#pragma unroll
+            for (int i = 0; i < 8; i++) leaves[r].w[i] = h[i];
+        }
+        __threadfence_block(); __syncthreads();
+        for (uint32_t cnt = R >> 1; cnt >= 1; cnt >>= 1) {                 // merkle.rs:269-294: nodes[cnt + i] = H(children 2i, 2i + 1 of the level below)
+            const digest* below = (cnt == (R >> 1)) ? leaves : nodes + 2 * cnt;
+            for (uint32_t i = tid; i < cnt; i += FRI_TAIL_THREADS) {
+                uint32_t m[16], h[8];
+#pragma unroll
+                for (int w = 0; w < 8; w++) { m[w] = below[2 * i].w[w]; m[8 + w] = below[2 * i + 1].w[w]; }
+                b3_hash64(m, h);
+#pragma unroll
+                for (int w = 0; w < 8; w++) nodes[cnt + i].w[w] = h[w];
+            }
+            __threadfence_block(); __syncthreads();
+        }
+        if (tid < 8) { nodes[0].w[tid] = 0; a.roots[li * 8 + tid] = nodes[1].w[tid]; }          // merkle.rs:275
+        if (li + 1 == a.count) break;                                      // the remainder layer is committed, not folded
+        if (tid == 0) { uint32_t root[8]; for (int i = 0; i < 8; i++) root[i] = nodes[1].w[i]; alpha_sh = fri_prng(root); }      // fri/prover.rs:40
+        __syncthreads();
+        FoldArgs f = a.fold; f.alpha = alpha_sh;
+        fe* out = a.e[li + 1];
+        const uint32_t log_stride = 2 * (a.first + li);
+        for (uint32_t r = tid; r < R; r += FRI_TAIL_THREADS) out[r] = fold_row(f, e[r], e[r + R], e[r + 2 * R], e[r + 3 * R], (uint64_t)r << log_stride);
+        __threadfence_block(); __syncthreads();
+    }
+}
+// commits (and folds) the natural-order layers first .. num_fri_layers - 1 in one launch; roots_out: (num_fri_layers - first) x 32 bytes
+int k_fri_tail(dst_ctx* c, int first, uint8_t* roots_out) {
+    const int L = c->num_fri_layers, count = L - first;
+    if (first < 1 || count < 1 || count > FRI_TAIL_MAX_LAYERS) { c->err = "k_fri_tail: bad layer range"; return DST_ERR_ARG; }
+    FriTailArgs a{};
+    for (int i = 0; i < count; i++) { a.e[i] = c->fri_e[first + i]; a.leaves[i] = c->fri_leaves[first + i]; a.nodes[i] = c->fri_nodes[first + i]; a.rows[i] = (uint32_t)(c->fri_size[first + i] / 4); }
+    a.first = (uint32_t)first; a.count = (uint32_t)count;
+    a.roots = (uint32_t*)(c->d_u64 + 8);                                   // 12 x 32 bytes behind the small device scalars (d_u64 holds 64 words)
+    a.fold.itw_lo = c->itw_lo; a.fold.itw_hi = c->itw_hi; a.fold.lo_bits = c->tw_lo_bits; a.fold.log_N = c->log_N;
+    a.fold.alpha = fe_zero(); a.fold.iota = c->iota; a.fold.quarter = c->four_inv;
+    { KScope ks_(c, "fri_tail_kernel", 0.0); hipLaunchKernelGGL(fri_tail_kernel, dim3(1), dim3(FRI_TAIL_THREADS), 0, c->stream, a); }
+    HIP_TRY(c, hipMemcpyAsync(roots_out, a.roots, (size_t)count * 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipGetLastError());
+    return DST_OK;
+}
+
 // ---- proof of work ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(PT) pow_kernel(const uint32_t* __restrict__ seed8, uint64_t base, uint32_t grinding, unsigned long long* best) {
     uint64_t nonce = base + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;

@@ -57,7 +57,9 @@ __device__ __forceinline__ void lds_wave_sync() {
 // isolation: 11 % of their time).  XOR-ing bits 3..5 and 6..8 of the index into its low three bits spreads strides 4, 16 and 64 over
 // the banks and leaves unit stride alone.  The workgroup fills the table through the same map.
 __device__ __forceinline__ uint32_t dif_tw_slot(uint32_t e) {
-#if defined(NTT_LAB_PLAIN_TW)
+#if defined(NTT_LAB_TW0)
+    return e & 1u;                       // timing ablation (wrong results): every lane reads one of two twiddles -- what do the twiddle reads cost?
+#elif defined(NTT_LAB_PLAIN_TW) || defined(NTT_TW_GLOBAL_B)
     return e;
 #else
     return e ^ ((e >> 3) & 7u) ^ ((e >> 6) & 7u);
@@ -100,13 +102,20 @@ __device__ __forceinline__ void lds_dif_round(fe* L, const fe_tw* W, uint32_t lo
         fe a0, a1, a2, a3;
         fe_addsub(x0, x2, a0, a2);
         fe_addsub(x1, x3, a1, a3);
-        if (hd != 1) a2 = fe_mul_tw(a2, W[dif_tw_slot(pos << (s - 1))]);          // hd == 1: pos == 0 in every lane
-        a3 = fe_mul_tw(a3, W[dif_tw_slot((pos + hd) << (s - 1))]);
+#if defined(NTT_LAB_TWREG)              // timing ablation (wrong results): ONE twiddle read per round, the rest from registers -- what do the twiddle reads cost?
+        const fe_tw lab_tw = W[0];
+#define NTT_TW_AT(idx) lab_tw
+#else
+#define NTT_TW_AT(idx) W[dif_tw_slot(idx)]
+#endif
+        if (hd != 1) a2 = fe_mul_tw(a2, NTT_TW_AT(pos << (s - 1)));          // hd == 1: pos == 0 in every lane
+        a3 = fe_mul_tw(a3, NTT_TW_AT((pos + hd) << (s - 1)));
         // stage s + 1: (a0, a1) and (a2, a3) with w_d^pos
         fe y0, y1, y2, y3;
         fe_addsub(a0, a1, y0, y1);
         fe_addsub(a2, a3, y2, y3);
-        if (!last && hd != 1) { const fe_tw tw = W[dif_tw_slot(pos << s)]; y1 = fe_mul_tw(y1, tw); y3 = fe_mul_tw(y3, tw); }
+        if (!last && hd != 1) { const fe_tw tw = NTT_TW_AT(pos << s); y1 = fe_mul_tw(y1, tw); y3 = fe_mul_tw(y3, tw); }
+#undef NTT_TW_AT
         if (fin) { out.put(i0, t, y0, k0); out.put(i0 + hd, t, y1, k1); out.put(i0 + d, t, y2, k2); out.put(i0 + d + hd, t, y3, k3); }
         else { *p0 = y0; *p1 = y1; *p2 = y2; *p3 = y3; }
     }

@@ -339,7 +339,17 @@ static int fri_replicated_tail(dst_ctx* c, const void* gathered, int src_is_devi
     fe* nat0 = d0 == 0 ? c->fri_nat0 : c->fri_e[d0];
     k_coset_to_natural_len(c, (const fe*)c->gather_buf, c->B, fri_nd(c, d0), nat0);
     if (c->fri_roots.size() < (size_t)L) c->fri_roots.resize(L);
+    const char* tail_env = getenv("DISTAFF_FRI_TAIL");
     for (int d = d0; d < L; d++) {
+        if (d >= 1 && c->fri_size[d] <= ((size_t)1 << 13) && !(tail_env && tail_env[0] == '0')) {
+            // the small layers in one launch (k_fri_tail, as on a single GPU): the layer's evaluations are in fri_e[d] in natural order
+            std::vector<uint8_t> rs((size_t)(L - d) * 32);
+            int rt = k_fri_tail(c, d, rs.data());
+            if (rt) return rt;
+            for (int i = d; i < L; i++) c->fri_roots[i].assign(rs.begin() + 32 * (i - d), rs.begin() + 32 * (i - d + 1));
+            if (d == d0 && root_out) memcpy(root_out, rs.data(), 32);
+            break;
+        }
         const size_t R = c->fri_size[d] / 4;
         const fe* e = fri_layer_natural(c, d);
         k_fri_leaves_at(c, e, c->fri_leaves[d], R);

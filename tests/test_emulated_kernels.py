@@ -52,6 +52,7 @@ SELECTION = [
     "test_trace_from_pinned_host_memory[w17]",
     "test_synthetic_division_by_power_tables",
     "test_trace_in_its_own_buffer",
+    "test_small_fri_layers_in_one_launch_equal_the_per_layer_path",
 ]
 
 

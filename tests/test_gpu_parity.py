@@ -618,6 +618,28 @@ def test_sharded_world8_at_bench_size_equals_single_context():
     assert all(p == expected for p in proofs)
 
 
+def test_small_fri_layers_in_one_launch_equal_the_per_layer_path(oracle, monkeypatch):
+    """fri::reduce from the first layer of at most 2^13 evaluations on runs as ONE launch (k_fri_tail: rows hashed, trees built,
+    x = field::prng(root) drawn by the device's own ChaCha20 / Uniform, folds) -- the proof must equal the oracle's and the one made with
+    a launch and a root read-back per layer (DISTAFF_FRI_TAIL=0); blowup 16 makes the remainder 128 elements instead of 256."""
+    import distaff_amd as D
+    O = oracle
+    for log_n, log_b in ((8, 5), (10, 5), (9, 4), (12, 5)):
+        t = O.fibonacci_trace(1 << log_n)
+        op = O.Prover.from_trace(t, 1, ext=1 << log_b, grinding=8)
+        expected = op.prove()
+        ctx = D.Context(log_n, t.width, t.ctx_depth, t.loop_depth, log_blowup=log_b, grinding=8)
+        ctx.upload(t.columns)
+        monkeypatch.delenv("DISTAFF_FRI_TAIL", raising=False)
+        ctx.set_profiling(1); ctx.kernel_stats(reset=True)
+        assert ctx.prove(t.public_inputs, op.outputs) == expected
+        assert ctx.kernel_stats(reset=True).get("fri_tail_kernel", {}).get("launches") == 1
+        monkeypatch.setenv("DISTAFF_FRI_TAIL", "0")
+        assert ctx.prove(t.public_inputs, op.outputs) == expected
+        assert "fri_tail_kernel" not in ctx.kernel_stats(reset=True)
+        ctx.close()
+
+
 def test_fibonacci_2_16_proof_bytes_equal_oracle(oracle):
     """Largest size at which the oracle's own prover finishes in about ten seconds: byte-identical proofs, default ProofOptions."""
     import distaff_amd as D
