@@ -52,7 +52,7 @@ struct AirArgs {
     fe* out;                     // [3][Q][n]  (i, f, t), Q = local constraint cosets
     const fe* coef;              // 344 raw draws: [0,94) first-step boundary, [94,188) last-step boundary
     const fe* tc;                // [2][NC] transition coefficients by constraint index: plain then degree-adjusted
-    const fe* periodic;          // [128][23]: 8 sponge ark, 12 hasher ark, 3 masks
+    const fe* periodic;          // [128][AIR_PERIODIC_STRIDE]: 8 sponge ark, 12 hasher ark, 3 masks, cubes of hasher ark 0..5
     const AirConsts* consts;
     fe* partial;                 // [7][Q][n] partial sums between launches
     fe* ev[10];                  // [Q][n] each: partial values of the stack constraints between launches (slots 0..7, two auxiliary)
@@ -531,7 +531,7 @@ __global__ void __launch_bounds__(AIR_THREADS, air_waves_per_simd(SD, SLCAP, SEC
     }
 
     AIR_SYNC();
-    const fe* per = a.periodic + (size_t)(step & 127u) * 23;
+    const fe* per = a.periodic + (size_t)(step & 127u) * AIR_PERIODIC_STRIDE;
     // specialised instances: every group a launch without op bits emits into; with op bits (five groups) only degree 2, which
     // takes ten of its fifteen constraints
     constexpr uint32_t ACC_MASK = !(SD != 0 || SLCAP == 8 || DEEP) ? 0u : ((SECT & 2) ? 0x01u : 0x3Fu);
@@ -579,13 +579,15 @@ __global__ void __launch_bounds__(AIR_THREADS, air_waves_per_simd(SD, SLCAP, SEC
 #pragma unroll
             for (int i = 0; i < 4; i++) os[i] = fe_cube(fe_add(c_sp[i], per[i]));
             matmul<4>(os, c_sponge_mds);
-            fe op_code = ld[0];
-            op_code = fe_add(op_code, fe_double(ld[1]));
-            op_code = fe_add(op_code, fe_mul_small(ld[2], 4));
-            op_code = fe_add(op_code, fe_mul_small(ld[3], 8));
-            op_code = fe_add(op_code, fe_mul_small(ld[4], 16));
-            op_code = fe_add(op_code, fe_mul_small(hd[0], 32));
-            op_code = fe_add(op_code, fe_mul_small(hd[1], 64));
+            // op_code = ld0 + 2 ld1 + 4 ld2 + 8 ld3 + 16 ld4 + 32 hd0 + 64 hd1 (sponge.rs:27-33) as a doubling chain: six doublings and six
+            // additions (144 instructions) instead of five multiplications by small constants
+            fe op_code = hd[1];
+            op_code = fe_add(fe_double(op_code), hd[0]);
+            op_code = fe_add(fe_double(op_code), ld[4]);
+            op_code = fe_add(fe_double(op_code), ld[3]);
+            op_code = fe_add(fe_double(op_code), ld[2]);
+            op_code = fe_add(fe_double(op_code), ld[1]);
+            op_code = fe_add(fe_double(op_code), ld[0]);
             os[0] = fe_add(os[0], op_code);
             os[1] = fe_add(os[1], fe_mul(nw[0], hdf[0]));               // op_value = next.user_stack[0] * push_flag
 #pragma unroll
@@ -690,7 +692,7 @@ __global__ void __launch_bounds__(AIR_THREADS, air_waves_per_simd(SD, SLCAP, SEC
             constexpr int NZ = (SD != 0 && SD < 6) ? SD : 6;         // items that can be non-zero
             fe os[6], ns[6];
 #pragma unroll
-            for (int i = 0; i < 6; i++) os[i] = fe_cube(i < NZ ? fe_add(o[i], per[8 + i]) : per[8 + i]);
+            for (int i = 0; i < 6; i++) os[i] = i < NZ ? fe_cube(fe_add(o[i], per[8 + i])) : per[23 + i];      // an absent item is zero: the constant's cube, from the table
             matmul<6>(os, c_hasher_mds);
             constexpr int NR = NS < 6 ? NS : 6;                      // differences that are used
 #pragma unroll
@@ -953,14 +955,16 @@ __global__ void __launch_bounds__(AIR_THREADS, air_waves_per_simd(SD, SLCAP, SEC
     if (on_trace && k + 1 != a.n) {
         t = fe_zero();
     } else {
-        // x^p with p = 8n - 1 - (n - 1) * degree for degrees 2, 3, 4, 6, 7, 8
+        // x^p with p = 8n - 1 - (n - 1) * degree for degrees 2, 3, 4, 6, 7, 8: res + sum_g adj[g] * x^p_g as ONE sum of products
         const uint32_t degs[6] = {2, 3, 4, 6, 7, 8};
-        t = acc.res;
+        fe_acc T; fe_acc_zero(T);
+        fe_acc_add(T, acc.res);
 #pragma unroll
         for (int g = 0; g < 6; g++) {
             uint64_t p = 8 * n64 - 1 - (n64 - 1) * degs[g];
-            t = fe_add(t, fe_mul(acc.adj[g], dpow(a, (gi * p) & nmask)));
+            fe_acc_mac(T, acc.adj[g], dpow(a, (gi * p) & nmask));
         }
+        t = fe_acc_reduce(T);
     }
     a.out[((size_t)2 * gridDim.y + ql) * a.n + k] = t;
 #undef CUR

@@ -53,7 +53,7 @@ static int dev_upload(dst_ctx* c, T** p, const std::vector<T>& v) {
 // (constraints/utils.rs:87-113; decoder/mod.rs:95-100,219-223; stack/mod.rs:67-70)
 static std::vector<fe> build_periodic_table() {
     const size_t cyc = 128;
-    std::vector<fe> out(cyc * 23);
+    std::vector<fe> out(cyc * AIR_PERIODIC_STRIDE);
     u128 w16 = fe_to_u128(h_root_of_unity(4)), w128 = fe_to_u128(h_root_of_unity(7));
     u128 w16_inv = hf_pow(w16, 15), inv16 = hf_pow(16, FIELD_P - 2);
     static const uint8_t masks[3][16] = {{0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1}, {1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 0}, {0, 1, 1, 1, 1, 1, 1, 1, 0, 1, 1, 1, 1, 1, 1, 1}};
@@ -68,9 +68,13 @@ static std::vector<fe> build_periodic_table() {
         for (size_t s = 0; s < cyc; s++) {
             u128 x = hf_pow(w128, s), acc = 0, pw = 1;
             for (int j = 0; j < 16; j++) { acc = hf_add(acc, hf_mul(coef[j], pw)); pw = hf_mul(pw, x); }
-            out[s * 23 + row] = fe_from_u128(acc);
+            out[s * AIR_PERIODIC_STRIDE + row] = fe_from_u128(acc);
         }
     }
+    // columns 23..28: the cubes of the first hasher constants (rows 8..13) -- what (item + constant)^3 is for a stack item that is not
+    // part of the trace (zero): the constraint kernel of a shallow stack reads them instead of cubing
+    for (size_t s = 0; s < cyc; s++)
+        for (int i = 0; i < 6; i++) { const u128 v = fe_to_u128(out[s * AIR_PERIODIC_STRIDE + 8 + i]); out[s * AIR_PERIODIC_STRIDE + 23 + i] = fe_from_u128(hf_mul(hf_mul(v, v), v)); }
     return out;
 }
 

@@ -22,6 +22,7 @@
 #include "../../include/distaff_hip.h"
 
 struct __attribute__((aligned(16))) digest { uint32_t w[8]; };
+#define AIR_PERIODIC_STRIDE 29         // 8 sponge constants, 12 hasher constants, 3 cycle masks, the cubes of hasher constants 0..5
 
 // Four-step twiddles are streamed from HBM once per element of every first pass: as plain elements (16 bytes, general multiplication,
 // 71 VALU instructions) or as table pairs (32 bytes, fe_mul_tw, 55).  Measured on the 2^20 proof: first passes 13.1 ms with plain
@@ -101,7 +102,7 @@ struct dst_ctx {
     tw4_t *tw4_row_fwd = nullptr, *tw4_row_inv = nullptr;   // three-pass plans: [n2] twiddles w_{n2}^(k2*m3) of the middle pass and inverse
     fe_tw *w3f = nullptr, *w3i = nullptr;        // three-pass plans: stage twiddles of the last pass (length n3)
     fe *tmp2 = nullptr;                          // three-pass plans: second staging buffer
-    fe *periodic = nullptr;                      // [128][23] extended Rescue round constants + cycle masks
+    fe *periodic = nullptr;                      // [128][AIR_PERIODIC_STRIDE] extended Rescue round constants + cycle masks + cubes of six of them
     void *air_consts = nullptr;                  // AirConsts (Rescue MDS matrices) in device memory
     fe c16f[8], c16i[8];                         // w_16^j and w_16^-j, j < 8 (passed to the NTT kernels by value)
     fe_tw n_inv_tw{};                            // 1/n as a table pair
