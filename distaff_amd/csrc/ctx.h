@@ -156,6 +156,9 @@ struct dst_ctx {
     // dst_trace_upload_owned: only the registers r = rank (mod world) of the trace are on this device (the sharded prover interpolates
     // exactly those and all-gathers the coefficient vectors)
     bool trace_owned_only = false;
+    // dst_prove_sharded: the gathered transition evaluations in `ceval` are already inverse-transformed per coset (every rank did its own
+    // cosets before the exchange); dst_shard_combine then only runs the 8-point step across cosets
+    bool ceval_inverted = false;
     // dst_prove_sharded: collectives that overlap with compute run on their own stream, ordered by events; status records of all ranks
     hipStream_t comm_stream = nullptr;
     std::vector<hipEvent_t> comm_events;
@@ -230,6 +233,8 @@ void k_sub_dot_at0(dst_ctx* c, fe* y, const fe* values_dev, const fe* coeffs_dev
 void k_sub_at0(dst_ctx* c, fe* y, const fe* v_dev);                                                   // y[0] -= v[0]
 // FRI
 void k_fri_fold(dst_ctx* c, int layer, fe special_x);
+void k_intt_cosets_local(dst_ctx* c, fe* vals, fe* out, size_t cosets);
+void k_cross8(dst_ctx* c, const fe* work, fe* out8n);
 int k_fri_tail(dst_ctx* c, int first, uint8_t* roots_out);       // natural-order layers first .. last in one launch (kernels_poly.hip)
 // PoW
 int k_pow(dst_ctx* c, const uint8_t seed[32], uint32_t grinding, uint64_t* nonce);

@@ -816,6 +816,13 @@ __global__ void cross8_kernel(const fe* __restrict__ work, fe* __restrict__ out,
     out[m0 + 6 * n] = fe_mul(X6, eight_inv); out[m0 + 7 * n] = fe_mul(X7, eight_inv);
 }
 
+// the two halves of k_intt8_cosets for the sharded prover: a rank inverts the size-n transforms of the evaluation cosets it owns BEFORE the
+// exchange (1/world of them instead of all eight on every rank), the 8-point step across cosets follows on the gathered arrays
+void k_intt_cosets_local(dst_ctx* c, fe* vals, fe* out, size_t cosets) { launch_two_pass(c, vals, 0, c->n, out, 0, c->n, cosets, 1, true, false); }
+void k_cross8(dst_ctx* c, const fe* work, fe* out8n) {
+    { KScope ks_(c, "cross8_kernel", 256.0 * c->n); hipLaunchKernelGGL(cross8_kernel, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream, work, out8n,
+                       c->itw_lo, c->itw_hi, c->tw_lo_bits, c->log_n, c->log_N, c->log_b, c->eight_inv); }
+}
 void k_intt8_cosets(dst_ctx* c, fe* vals, fe* out8n, fe* work) {
     launch_two_pass(c, vals, 0, c->n, work, 0, c->n, 8, 1, true, false);
     { KScope ks_(c, "cross8_kernel", 256.0 * c->n); hipLaunchKernelGGL(cross8_kernel, dim3((unsigned)((c->n + 255) / 256)), dim3(256), 0, c->stream, (const fe*)work, out8n,

@@ -124,33 +124,45 @@ int dst_shard_eval_constraints(dst_ctx* c, const dst_public* pub, const uint8_t*
 
 // steps 4-5 after the constraint evaluations of all ranks were imported (SH_CEVAL): combination (replicated), LDE of the owned
 // cosets and the local levels of the constraint tree
+// parts: 1 = the two boundary combinations and their divisions (need nothing from other ranks), 2 = transition part, sum, extension over
+// the owned cosets and the local tree levels.  dst_prove_sharded runs part 1 while the exchange of the evaluations is in flight.
+static int shard_combine_parts(dst_ctx* c, int parts) {
+    const size_t n = c->n, D = 8 * n;
+    fe* ip = c->cwork; fe* fp = c->cwork + D; fe* tp = c->cwork + 2 * D; fe* work = c->cwork + 3 * D;
+    if (parts & 1) {
+        if (dst_internal_boundary_by_evaluation()) {
+            k_intt8_cosets(c, c->ceval, ip, work);
+            k_intt8_cosets(c, c->ceval + D, fp, work);
+        } else {
+            int rb = dst_internal_boundary_polys(c, c->shard_draws.data(), ip, fp);
+            if (rb) return rb;
+        }
+        k_syn_div(c, ip, D, fe_one());
+        k_syn_div(c, fp, D, c->x_last);
+    }
+    if (parts & 2) {
+        if (c->ceval_inverted) { k_cross8(c, c->ceval + 2 * D, tp); c->ceval_inverted = false; }
+        else k_intt8_cosets(c, c->ceval + 2 * D, tp, work);
+        k_syn_div_expanded(c, tp, c->cpoly, D, n, c->x_last);
+        k_add(c, c->cpoly, ip, D);
+        k_add(c, c->cpoly, fp, D);
+        k_lde_fold8(c, c->cpoly, c->cevals);
+        if (c->Bc >= 4) {                                   // with two cosets per rank the leaves themselves are the boundary (see dst_shard_export)
+            k_constraint_level1(c);
+            k_merkle_local_levels(c, c->cnodes, c->Bc * n / 4, n);
+        }
+        c->constraints_done = true; c->composed = false;
+    }
+    return DST_OK;
+}
 int dst_shard_combine(dst_ctx* c) {
     if (!c) return DST_ERR_ARG;
     if (!c->committed || c->shard_draws.size() != 344) { c->err = "dst_shard_combine: constraints not evaluated (dst_shard_eval_constraints first)"; return DST_ERR_STATE; }
     HIP_TRY(c, hipSetDevice(c->device));
-    const size_t n = c->n, D = 8 * n;
-    fe* ip = c->cwork; fe* fp = c->cwork + D; fe* tp = c->cwork + 2 * D; fe* work = c->cwork + 3 * D;
-    if (dst_internal_boundary_by_evaluation()) {
-        k_intt8_cosets(c, c->ceval, ip, work);
-        k_intt8_cosets(c, c->ceval + D, fp, work);
-    } else {
-        int rb = dst_internal_boundary_polys(c, c->shard_draws.data(), ip, fp);
-        if (rb) return rb;
-    }
-    k_syn_div(c, ip, D, fe_one());
-    k_syn_div(c, fp, D, c->x_last);
-    k_intt8_cosets(c, c->ceval + 2 * D, tp, work);
-    k_syn_div_expanded(c, tp, c->cpoly, D, n, c->x_last);
-    k_add(c, c->cpoly, ip, D);
-    k_add(c, c->cpoly, fp, D);
-    k_lde_fold8(c, c->cpoly, c->cevals);
-    if (c->Bc >= 4) {                                   // with two cosets per rank the leaves themselves are the boundary (see dst_shard_export)
-        k_constraint_level1(c);
-        k_merkle_local_levels(c, c->cnodes, c->Bc * n / 4, n);
-    }
+    int r = shard_combine_parts(c, 3);
+    if (r) return r;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
-    c->constraints_done = true; c->composed = false;
     return DST_OK;
 }
 
@@ -235,6 +247,7 @@ int dst_shard_import(dst_ctx* c, uint32_t what, uint32_t arg, const void* src, i
     if (total > c->gather_bytes) { c->err = "dst_shard_import: gather buffer too small"; return DST_ERR_ARG; }
     if ((r = copy_in(c, c->gather_buf, src, total, src_is_device))) return r;
     if (what == SH_CEVAL) {
+        c->ceval_inverted = false;                                  // dst_prove_sharded sets it after importing arrays it has inverse-transformed
         const size_t Q = c->Bc / (c->B / 8), blk = Q * c->n;        // gathered [G][V][Q][n] -> ceval [3][8][n], V = 3 (i, f, t) or 1 (t)
         const size_t V = dst_internal_boundary_by_evaluation() ? 3 : 1;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -884,11 +897,30 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
     {
         size_t bytes = 0;
         if (dst_shard_export_size(c, SH_CEVAL, 0, &bytes) || bytes * G > c->gather_bytes) { c->err = "dst_prove_sharded: gather buffer too small for the constraint evaluations"; return DST_ERR_ARG; }   // the same on every rank
-        const void* send = dst_internal_boundary_by_evaluation() ? (const void*)c->ceval : (const void*)(c->ceval + 2 * (c->Bc / (c->B / 8)) * c->n);
-        if (!S.coll(comm->all_gather(send, c->gather_buf, bytes, c->stream), "constraint evaluations")) return S.agreed;        // the import below rewrites `ceval` only after the exchange
-        S.local([&] { return dst_shard_import(c, SH_CEVAL, 0, c->gather_buf, 1, nullptr); });
+        const size_t Q = c->Bc / (c->B / 8);
+        const void* send = dst_internal_boundary_by_evaluation() ? (const void*)c->ceval : (const void*)(c->ceval + 2 * Q * c->n);
+        const bool invert_first = !dst_internal_boundary_by_evaluation();
+        if (invert_first) S.local([&]() -> int {
+            // the size-n inverse transforms of this rank's evaluation cosets, before the exchange (in place through the scratch area)
+            fe* mine = c->ceval + 2 * Q * c->n; fe* work = c->cwork + 3 * 8 * c->n;
+            k_intt_cosets_local(c, mine, work, Q);
+            HIP_TRY(c, hipMemcpyAsync(mine, work, Q * c->n * sizeof(fe), hipMemcpyDeviceToDevice, c->stream));
+            return DST_OK;
+        });
+        // On a stream-ordered transport the exchange runs on the collective stream while this rank writes the boundary combinations
+        // (they need nothing from other ranks); otherwise in sequence.  In boundary-by-evaluation mode part 1 reads the gathered arrays.
+        bool part1_done = false;
+        const bool side = comm->stream_ordered() && G > 1 && invert_first && S.rc == DST_OK && c->comm_stream && c->comm_events.size() >= 2 && !getenv("DISTAFF_SHARD_NO_OVERLAP");
+        if (side) {
+            S.local([&]() -> int { HIP_TRY(c, hipEventRecord(c->comm_events[0], c->stream)); HIP_TRY(c, hipStreamWaitEvent(c->comm_stream, c->comm_events[0], 0)); return DST_OK; });
+            if (!S.coll(comm->all_gather(send, c->gather_buf, bytes, c->comm_stream), "constraint evaluations")) return S.agreed;
+            S.local([&]() -> int { HIP_TRY(c, hipEventRecord(c->comm_events[1], c->comm_stream)); return DST_OK; });
+            S.local([&] { part1_done = true; return shard_combine_parts(c, 1); });
+            S.local([&]() -> int { HIP_TRY(c, hipStreamWaitEvent(c->stream, c->comm_events[1], 0)); return DST_OK; });
+        } else if (!S.coll(comm->all_gather(send, c->gather_buf, bytes, c->stream), "constraint evaluations")) return S.agreed;        // the import below rewrites `ceval` only after the exchange
+        S.local([&] { const int r = dst_shard_import(c, SH_CEVAL, 0, c->gather_buf, 1, nullptr); c->ceval_inverted = invert_first && r == DST_OK; return r; });
+        S.local([&] { return shard_combine_parts(c, part1_done ? 2 : 3); });
     }
-    S.local([&] { return dst_shard_combine(c); });
     mark(3);
     tree_exchange(S, SH_CONSTRAINT_TREE, 0, constraint_root);
     if (S.agreed) return S.agreed;
