@@ -152,7 +152,7 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
     if (PREFETCH) NTT_FETCH_A(tile0)
     for (uint32_t it = 0; it < a.tiles_per_block; it++) {
         const uint32_t tile = tile0 + it;
-        if constexpr (LOG_LEN != 0) lane = lds_opaque_lane();           // per-tile index arithmetic is recomputed, not kept live (and spilled) across the loop
+        lane = lds_opaque_lane();                          // per-tile index arithmetic is recomputed, not kept live (and spilled) across the loop
         if (!PREFETCH) NTT_FETCH_A(tile)
         __syncthreads();                                   // the previous tile has left LDS (and TW is complete)
         // DISTAFF_NTT_DIF: pre-scale + DIF instead of the coset DIT
@@ -236,7 +236,7 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_b(NttArgs a, const fe* 
     if (PREFETCH) NTT_FETCH_B(tile0)
     for (uint32_t it = 0; it < a.tiles_per_block; it++) {
         const uint32_t k1_0 = (tile0 + it) * T;
-        if constexpr (LOG_LEN != 0) lane = lds_opaque_lane();
+        lane = lds_opaque_lane();
         if (!PREFETCH) NTT_FETCH_B(tile0 + it)
         __syncthreads();
 #define NTT_PUT_B(e, var) if constexpr ((e) < EPT) { const uint32_t idx = lane + (e) * THREADS; if (idx < count) L[lds_slot(NTT_M2_B(idx), NTT_ROW_B(idx), log_t)] = var; }

@@ -66,6 +66,16 @@ __device__ __forceinline__ uint32_t dif_tw_slot(uint32_t e) {
 #endif
 }
 
+// The same transform for a tile shape known at compile time: the rounds are separate code with literal strides.  The lane index goes
+// through an empty asm statement per call: the slot addresses of all rounds are invariant over the tiles a workgroup walks through, the
+// compiler would compute them once, keep them live across the loop -- and spill them (measured: 1 GB of scratch reloads per launch).
+__device__ __forceinline__ uint32_t lds_opaque_lane() {
+    uint32_t lane = threadIdx.x;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(lane));
+#endif
+    return lane;
+}
 // Consumer of the LAST round's results.  With the default the rounds leave the transformed tile in LDS.  A pass hands in an object
 // whose `pre(row, t)` may start a global load for the element (row, t) before the butterfly's arithmetic (the four-step twiddle: its
 // latency hides behind ~300 instructions) and whose `put(row, t, value, token)` finishes and stores the element: the last round then
@@ -144,18 +154,9 @@ __device__ __forceinline__ void lds_dif_tail(fe* L, uint32_t log_len, uint32_t l
 template <int THREADS, class Out = NttKeepInLds>
 __device__ __forceinline__ void lds_ntt_dif(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s_from, uint32_t s_to, const Out& out = Out()) {
     uint32_t s = s_from;                             // stages [s_from, s_to), s_from odd
-    for (; s + 1 <= log_len && s < s_to; s += 2) lds_dif_round<THREADS, Out>(L, W, log_len, log_t, s, out, threadIdx.x);
-    if (s == log_len && s < s_to) lds_dif_tail<THREADS, Out>(L, log_len, log_t, out, threadIdx.x);
-}
-// The same transform for a tile shape known at compile time: the rounds are separate code with literal strides.  The lane index goes
-// through an empty asm statement per call: the slot addresses of all rounds are invariant over the tiles a workgroup walks through, the
-// compiler would compute them once, keep them live across the loop -- and spill them (measured: 1 GB of scratch reloads per launch).
-__device__ __forceinline__ uint32_t lds_opaque_lane() {
-    uint32_t lane = threadIdx.x;
-#if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(lane));
-#endif
-    return lane;
+    const uint32_t lane = lds_opaque_lane();         // see lds_ntt_dif_fixed: nothing derived from the lane index stays live across the tile loop
+    for (; s + 1 <= log_len && s < s_to; s += 2) lds_dif_round<THREADS, Out>(L, W, log_len, log_t, s, out, lane);
+    if (s == log_len && s < s_to) lds_dif_tail<THREADS, Out>(L, log_len, log_t, out, lane);
 }
 template <int THREADS, int LOG_LEN, int LOG_T, class Out = NttKeepInLds>
 __device__ __forceinline__ void lds_ntt_dif_fixed(fe* L, const fe_tw* W, const Out& out = Out()) {
@@ -221,8 +222,9 @@ __device__ __forceinline__ void lds_dit_tail(fe* L, const fe_tw* W, uint32_t log
 template <int THREADS, class Out = NttKeepInLds>
 __device__ __forceinline__ void lds_ntt_dit(fe* L, const fe_tw* W, uint32_t log_len, uint32_t log_t, uint32_t s_from, uint32_t s_to, const fe_tw* __restrict__ Wlast = nullptr, const Out& out = Out()) {
     uint32_t s = s_from;                             // stages [s_from, s_to), s_from odd
-    for (; s + 1 <= log_len && s < s_to; s += 2) lds_dit_round<THREADS, Out>(L, W, log_len, log_t, s, Wlast, out, threadIdx.x);
-    if (s == log_len && s < s_to) lds_dit_tail<THREADS, Out>(L, W, log_len, log_t, Wlast, out, threadIdx.x);
+    const uint32_t lane = lds_opaque_lane();
+    for (; s + 1 <= log_len && s < s_to; s += 2) lds_dit_round<THREADS, Out>(L, W, log_len, log_t, s, Wlast, out, lane);
+    if (s == log_len && s < s_to) lds_dit_tail<THREADS, Out>(L, W, log_len, log_t, Wlast, out, lane);
 }
 template <int THREADS, int LOG_LEN, int LOG_T, class Out = NttKeepInLds>
 __device__ __forceinline__ void lds_ntt_dit_fixed(fe* L, const fe_tw* W, const fe_tw* __restrict__ Wlast = nullptr, const Out& out = Out()) {
