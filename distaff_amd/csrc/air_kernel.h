@@ -29,12 +29,11 @@
 #ifndef AIR_WAVES_PER_SIMD
 #define AIR_WAVES_PER_SIMD 2      // caps the kernel at 256 registers per lane
 #endif
-// Waves per SIMD the compiler must make room for: two = 256 registers per lane, no scratch for every instance but the per-operation
-// formulation.  Three waves (168 registers, 50-300 bytes of scratch per lane) used to be faster (the third wave filled the wait states the
-// carry chains left open: 8.8 -> 8.4 ms for the three Fibonacci-shape launches); since the arithmetic is written in issue order (fe.h) both
-// forms take the same time on a healthy box (7.37 against 7.35 ms) -- and on one box of the pool the scratch-heavy launch ran three times
-// slower (12.7 against 4.3 ms, every other kernel within 8 %): the product build does not depend on scratch.  -DAIR_WAVES_FORCE=3 builds
-// the three-wave form for comparison.
+// Waves per SIMD the compiler must make room for: two = at most 256 registers per lane.  Since the evaluation is cut by operation group
+// the nested-sum launches need 117 - 206 registers and no scratch (three to four waves per SIMD are resident); only the per-operation
+// instance (tests) reaches the cap.  History: round 2's 172 KB stack launch ran three times slower on one lease and on the driver's box
+// (12.7 - 13.4 against 4.3 - 4.6 ms); it had no scratch, so the size of its straight-line code is the suspect -- no
+// launch is larger than the 64 KiB instruction cache any more.  -DAIR_WAVES_FORCE=3 builds a three-wave form for comparison.
 constexpr int air_waves_per_simd(int sd, int slcap, int sect) {
     (void)sd; (void)slcap; (void)sect;
 #ifdef AIR_WAVES_FORCE

@@ -30,7 +30,7 @@ def demangle(names):
 
 
 def short_name(demangled):
-    """'void air_kernel<2, 1, 4, 8, 88, false, true>(AirArgs)' -> 'air_kernel<2,1,4,8,88,0,1>' (the names the library's kernel statistics use)"""
+    """'void air_kernel<2, 1, 4, 8, 0, 240u, 6>(AirArgs)' -> 'air_kernel<2,1,4,8,0,240,6>' (the names the library's kernel statistics use)"""
     s = re.sub(r"^void\s+", "", demangled)
     depth, cut = 0, len(s)
     for i, ch in enumerate(s):                       # strip the argument list: the first '(' outside template brackets

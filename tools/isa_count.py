@@ -44,7 +44,7 @@ def count_file(path):
 
 
 def air_key(demangled):
-    """'void air_kernel<2, 1, 4, 8, 88, false, true>(AirArgs)' -> 'air_kernel<2,1,4,8,88,0,1>' (the name the library's kernel statistics use)"""
+    """'void air_kernel<2, 1, 4, 8, 0, 240u, 6>(AirArgs)' -> 'air_kernel<2,1,4,8,0,240,6>' (the name the library's kernel statistics use)"""
     m = re.search(r"air_kernel<([^>]*)>", demangled)
     if not m:
         return None
