@@ -788,7 +788,9 @@ void commit_trace_columns(Sharded& S) {
         return DST_OK;
     });
     // a stream-ordered transport runs the all-gathers on their own stream, ordered against the transforms by events
-    const bool overlap = comm->stream_ordered() && G > 1 && !getenv("DISTAFF_SHARD_NO_OVERLAP");
+    // (DISTAFF_SHARD_FORCE_OVERLAP=1: the same stream / event choreography over a blocking transport -- how the tests reach this path
+    // without several RCCL ranks)
+    const bool overlap = (comm->stream_ordered() || getenv("DISTAFF_SHARD_FORCE_OVERLAP")) && G > 1 && !getenv("DISTAFF_SHARD_NO_OVERLAP");
     if (overlap) S.local([&]() -> int {
         if (!c->comm_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
         while (c->comm_events.size() < 2 * rounds) { hipEvent_t e; HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->comm_events.push_back(e); }
@@ -910,7 +912,7 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
         // On a stream-ordered transport the exchange runs on the collective stream while this rank writes the boundary combinations
         // (they need nothing from other ranks); otherwise in sequence.  In boundary-by-evaluation mode part 1 reads the gathered arrays.
         bool part1_done = false;
-        const bool side = comm->stream_ordered() && G > 1 && invert_first && S.rc == DST_OK && c->comm_stream && c->comm_events.size() >= 2 && !getenv("DISTAFF_SHARD_NO_OVERLAP");
+        const bool side = (comm->stream_ordered() || getenv("DISTAFF_SHARD_FORCE_OVERLAP")) && G > 1 && invert_first && S.rc == DST_OK && c->comm_stream && c->comm_events.size() >= 2 && !getenv("DISTAFF_SHARD_NO_OVERLAP");
         if (side) {
             S.local([&]() -> int { HIP_TRY(c, hipEventRecord(c->comm_events[0], c->stream)); HIP_TRY(c, hipStreamWaitEvent(c->comm_stream, c->comm_events[0], 0)); return DST_OK; });
             if (!S.coll(comm->all_gather(send, c->gather_buf, bytes, c->comm_stream), "constraint evaluations")) return S.agreed;

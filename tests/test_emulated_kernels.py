@@ -53,6 +53,7 @@ SELECTION = [
     "test_synthetic_division_by_power_tables",
     "test_trace_in_its_own_buffer",
     "test_small_fri_layers_in_one_launch_equal_the_per_layer_path",
+    "test_prove_sharded_with_collectives_on_their_own_stream[2]",
 ]
 
 

@@ -703,6 +703,29 @@ def test_prove_sharded_behind_the_c_abi(oracle, monkeypatch, world, log_n, repli
         ctx.close()
 
 
+@pytest.mark.parametrize("world", [2, 8])
+def test_prove_sharded_with_collectives_on_their_own_stream(oracle, monkeypatch, world):
+    """The stream / event choreography dst_prove_sharded uses on a stream-ordered transport (RCCL with several ranks: the coefficient
+    all-gathers of round k + 1 on the collective stream while round k is extended, the exchange of the constraint evaluations while the
+    boundary combinations are written) -- forced here over the in-process transport, which a one-GPU box can run with any number of ranks."""
+    import distaff_amd as D
+    O = oracle
+    monkeypatch.setenv("DISTAFF_SHARD_FORCE_OVERLAP", "1")
+    monkeypatch.delenv("DISTAFF_FRI_REPLICATE_LOG", raising=False)
+    t = O.fibonacci_trace(1 << 9)
+    op = O.Prover.from_trace(t, 1, grinding=8)
+    expected = op.prove()
+    ctxs = []
+    for r in range(world):
+        ctx = D.Context(9, t.width, t.ctx_depth, t.loop_depth, rank=r, world=world, grinding=8)
+        ctx.upload_owned(t.columns)
+        ctxs.append(ctx)
+    for _ in range(2):
+        assert D.prove_sharded_local(ctxs, t.public_inputs, op.outputs) == expected
+    for ctx in ctxs:
+        ctx.close()
+
+
 def test_prove_sharded_over_rccl_with_one_rank(oracle):
     """The RCCL transport of dst_prove_sharded (librccl.so bound at run time: ncclCommInitRank, all-gathers of host values and of the
     constraint evaluations / FRI layer, the all-to-all as grouped send / receive) with the one rank a single-GPU box offers; more
