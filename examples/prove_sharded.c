@@ -7,8 +7,9 @@
  *   one process driving every GPU itself (one thread per rank inside the library, device = rank modulo <devices>):
  *       ./prove_sharded local 8 20 8 proof.bin
  *
- * Every rank generates the same trace (standing in for the reference VM, processor::execute) and uploads all of it: a rank
- * interpolates every register and extends them over its own cosets. */
+ * Every rank generates the same trace (standing in for the reference VM, processor::execute) and uploads only the registers it
+ * interpolates, r = rank (mod world) (dst_trace_upload_owned): the library all-gathers the coefficient vectors and every rank extends
+ * all registers over its own cosets. */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -23,7 +24,9 @@ static dst_ctx* make_ctx(unsigned log_n, unsigned rank, unsigned world, int devi
     dst_ctx* ctx = NULL;
     int rc = dst_ctx_create(&p, &ctx);
     if (rc != DST_OK) { fprintf(stderr, "rank %u: dst_ctx_create: %d %s\n", rank, rc, dst_last_error(ctx)); exit(1); }
-    if ((rc = dst_trace_upload_contiguous(ctx, cols)) != DST_OK) { fprintf(stderr, "rank %u: upload: %s\n", rank, dst_last_error(ctx)); exit(1); }
+    const uint8_t* ptrs[20];
+    for (unsigned r = 0; r < 20; r++) ptrs[r] = (r % world == rank) ? cols + ((size_t)r << log_n) * 16 : NULL;      /* the others are not read */
+    if ((rc = dst_trace_upload_owned(ctx, ptrs)) != DST_OK) { fprintf(stderr, "rank %u: upload: %s\n", rank, dst_last_error(ctx)); exit(1); }
     return ctx;
 }
 
