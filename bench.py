@@ -128,9 +128,11 @@ def box_fingerprint(ctx, mad_peak, mulmod_peak):
     except Exception as e:                                           # noqa: BLE001
         box["device_error"] = str(e)
     try:
-        t16, t176 = ctx.bench_code(16), ctx.bench_code(176)
+        t16, t176, t176c = ctx.bench_code(16), ctx.bench_code(176), ctx.bench_code(177)
         box["code_probe"] = {"ms_16KiB": round(t16, 4), "ms_176KiB": round(t176, 4), "per_instruction_ratio": round((t176 / 176.0) / (t16 / 16.0), 3),
-                             "note": "2^23 lanes, 128 per workgroup, two waves per SIMD, every wavefront runs the code once (kernels_probe.hip)"}
+                             "ms_176KiB_convoy": round(t176c, 4), "convoy_per_instruction_ratio": round((t176c / 176.0) / (t16 / 16.0), 3),
+                             "note": "2^23 lanes, 128 per workgroup, two waves per SIMD, every wavefront runs the code once (kernels_probe.hip); "
+                                     "convoy = 256 lanes per workgroup and a workgroup barrier every 16 KiB of code"}
     except Exception as e:                                           # noqa: BLE001
         box["code_probe"] = {"error": str(e)}
     try:

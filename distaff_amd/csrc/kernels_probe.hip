@@ -13,26 +13,34 @@
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];      // the library's one dynamic-LDS array (kernels_ntt.hip)
 
-template <int KIB>
-__global__ void __launch_bounds__(128) code_probe_kernel(uint64_t* out, uint32_t x, uint32_t y) {
-    unsigned char* probe_lds = ntt_smem;                      // 40 KiB per workgroup: two waves per SIMD, like the constraint kernels
+// KIB of code; THREADS lanes per workgroup; CONVOY: a workgroup barrier after every 16 KiB of code keeps the wavefronts of a workgroup at one
+// program counter, so that they share the instruction-cache lines (tools/icache_probe: misses of 256 KiB of code 352 -> 38 MB per launch)
+template <int KIB, int THREADS = 128, bool CONVOY = false>
+__global__ void __launch_bounds__(THREADS) code_probe_kernel(uint64_t* out, uint32_t x, uint32_t y) {
+    unsigned char* probe_lds = ntt_smem;                      // 40 KiB per 128 lanes: two waves per SIMD, like the constraint kernels
     uint64_t a = threadIdx.x, b = blockIdx.x, c = x, d = y;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if constexpr (KIB == 16) PROBE_BODY(512); else PROBE_BODY(5632);
+    if constexpr (KIB == 16) PROBE_BODY(512);
+    else if constexpr (!CONVOY) PROBE_BODY(5632);
+    else {
+#pragma unroll
+        for (int k = 0; k < KIB / 16; k++) { PROBE_BODY(512); __builtin_amdgcn_s_barrier(); }
+    }
 #endif
     if ((a ^ b ^ c ^ d) == 0x1234567 && probe_lds[threadIdx.x]) out[0] = a;       // keeps the chains alive; never true in practice
 }
 
-template <int KIB>
+template <int KIB, int THREADS, bool CONVOY>
 static int run_probe(dst_ctx* c, double* ms) {
     const size_t lanes = (size_t)8 << 20;                     // the constraint kernels' grid at 2^20 steps
-    HIP_TRY(c, hipFuncSetAttribute((const void*)code_probe_kernel<KIB>, hipFuncAttributeMaxDynamicSharedMemorySize, 40 * 1024));
+    const int lds = 40 * 1024 * (THREADS / 128);
+    HIP_TRY(c, hipFuncSetAttribute((const void*)code_probe_kernel<KIB, THREADS, CONVOY>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     hipEvent_t e0, e1;
     HIP_TRY(c, hipEventCreate(&e0)); HIP_TRY(c, hipEventCreate(&e1));
     double best = 1e30;
     for (int rep = 0; rep < 3; rep++) {
         HIP_TRY(c, hipEventRecord(e0, c->stream));
-        hipLaunchKernelGGL((code_probe_kernel<KIB>), dim3((unsigned)(lanes / 128)), dim3(128), 40 * 1024, c->stream, (uint64_t*)c->scratch, 3u, 5u);
+        hipLaunchKernelGGL((code_probe_kernel<KIB, THREADS, CONVOY>), dim3((unsigned)(lanes / THREADS)), dim3(THREADS), lds, c->stream, (uint64_t*)c->scratch, 3u, 5u);
         HIP_TRY(c, hipEventRecord(e1, c->stream));
         HIP_TRY(c, hipEventSynchronize(e1));
         float f = 0; HIP_TRY(c, hipEventElapsedTime(&f, e0, e1));
@@ -43,9 +51,11 @@ static int run_probe(dst_ctx* c, double* ms) {
     return DST_OK;
 }
 
+// code_kib: 16, 176, or 176 + 1 = the convoy form of the 176 KiB kernel (256 lanes per workgroup, a barrier every 16 KiB)
 int k_bench_code(dst_ctx* c, uint32_t code_kib, double* ms) {
-    if (code_kib == 16) return run_probe<16>(c, ms);
-    if (code_kib == 176) return run_probe<176>(c, ms);
-    c->err = "dst_bench_code: code size must be 16 or 176 (KiB)";
+    if (code_kib == 16) return run_probe<16, 128, false>(c, ms);
+    if (code_kib == 176) return run_probe<176, 128, false>(c, ms);
+    if (code_kib == 177) return run_probe<176, 256, true>(c, ms);
+    c->err = "dst_bench_code: code size must be 16, 176 or 177 (= 176 KiB in the convoy form)";
     return DST_ERR_ARG;
 }

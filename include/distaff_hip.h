@@ -168,7 +168,9 @@ int dst_bench_mulmod(dst_ctx* ctx, uint64_t lanes, uint32_t iters, double* ms);
  * `lanes` lanes; returns the elapsed milliseconds (rate = lanes * iters * 32 / time).  The integer-multiplier roofline of the path. */
 int dst_bench_mad(dst_ctx* ctx, uint64_t lanes, uint32_t iters, double* ms);
 /* box fingerprint: milliseconds for 2^23 lanes to run `code_kib` (16 or 176) KiB of straight-line multiply-adds once each.  The ratio
- * of the two times per instruction is 1 on a healthy device; a device on which code beyond the instruction cache is slow shows it here. */
+ * of the two times per instruction is 0.9 on a healthy device; a device on which code beyond the instruction cache is slow shows it here.
+ * code_kib = 177: the 176 KiB kernel in its convoy form (256 lanes per workgroup, a workgroup barrier every 16 KiB: the wavefronts share
+ * their instruction-cache lines) -- whether that form would help on the device at hand. */
 int dst_bench_code(dst_ctx* ctx, uint32_t code_kib, double* ms);
 /* element-wise device field arithmetic on caller data (tests): op 0 add, 1 sub, 2 mul, 3 mul (portable formulation), 4 inv(a), 5 a^b */
 int dst_field_op(dst_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t count);
