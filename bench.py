@@ -6,7 +6,7 @@ DEEP composition + FRI + proof-of-work + openings, default ProofOptions) over on
 resident in HBM (`value`); a second timed region starts from the trace in pinned host memory, the upload overlapped with the
 extension (`prover_ms_incl_upload`, the PCIe-inclusive figure).  Prints ONE JSON line on rank 0.
 
-    python bench.py --gpus 1 --steps 5 --warmup 2
+    python bench.py --gpus 1 --steps 20 --warmup 5
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 """
 import argparse
@@ -172,8 +172,8 @@ def kernel_rooflines(stats, steps, default_workload, top=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)         # the driver's own values: a proof is 37 ms, and the first steps after a cold
+    ap.add_argument("--warmup", type=int, default=5)         # start run up to 8 % slower (clock ramp; step_ms shows the spread)
     ap.add_argument("--log-n", type=int, default=int(os.environ.get("BENCH_LOG_N", "20")))
     ap.add_argument("--cpu-log-n", type=int, default=int(os.environ.get("BENCH_CPU_LOG_N", "16")))
     ap.add_argument("--log-blowup", type=int, default=5, help="log2 of the extension factor (default ProofOptions: 5; BASELINE config 5: 4)")
