@@ -124,3 +124,31 @@ def test_bench_reads_the_stamped_counter_summary():
     stats = {k: {"launches": v["launches"], "ms": v["ms_per_step"]} for k, v in line["kernels"].items()}
     v = bench.valu_issue(stats, line["ms_per_step"], 1)
     assert 0.5 < v["proof_frac"] < 1.0 and all(0.3 < f < 1.0 for f in v["kernel_frac"].values()) and not v["not_counted"]
+
+
+def test_kernel_gate_on_the_built_library():
+    """What build() enforces (__graft_entry__._kernel_gate): every kernel of the product library is at most 64 KiB of code (the instruction
+    cache of a gfx950 CU pair), spills no vector register and uses no scratch -- except the kernels listed with their reason.  Read from
+    the code objects of the built .so (tools/codeobj_info.py), no GPU needed.  The constraint launches of the bench path are named."""
+    import os, re, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tools"))
+    import __graft_entry__ as G
+    import codeobj_info
+    so = os.path.join(root, "distaff_amd", "libdistaff_hip.so")
+    if not os.path.exists(so):
+        G.build()
+    kernels = codeobj_info.kernels_of(so)
+    assert len(kernels) > 60
+    assert G._kernel_gate(kernels) == []
+    for pat in G.GATE_EXCEPTIONS:                                     # no stale exception
+        assert any(re.match(re.escape(pat), k) for k in kernels), pat
+    bench_path = [k for k in kernels if k.startswith("air_kernel<2,1,4,8,") and not k.startswith("air_kernel<2,1,4,8,1,")]
+    assert len(bench_path) == 5
+    for k in bench_path:
+        assert kernels[k]["code_bytes"] <= G.CODE_LIMIT and kernels[k]["vgpr_spill"] == 0 and kernels[k]["scratch_bytes"] == 0, (k, kernels[k])
+    # the gate itself: a kernel over the limit, a spill and scratch are each reported
+    fake = {"some_kernel<1>": {"code_bytes": G.CODE_LIMIT + 4, "vgpr_spill": 0, "scratch_bytes": 0},
+            "other": {"code_bytes": 100, "vgpr_spill": 3, "scratch_bytes": 16}}
+    bad = G._kernel_gate(fake)
+    assert len(bad) == 2 and "bytes of code" in bad[1] and "spilled" in bad[0] and "scratch" in bad[0]
