@@ -256,6 +256,7 @@ static const fe* as_fe(const uint8_t* p) { return reinterpret_cast<const fe*>(p)
 static std::vector<fe> copy_fe(const uint8_t* p, size_t count) { std::vector<fe> v(count); memcpy(v.data(), p, count * 16); return v; }
 
 extern "C" int dst_internal_build_proof(dst_ctx* c, const uint64_t* positions, uint32_t num_positions, uint64_t pow_nonce, std::vector<uint8_t>& proof);   // shard.hip
+extern "C" int dst_internal_shard_buffers(dst_ctx* c);      // shard.hip: exchange buffers of a sharded context
 
 extern "C" {
 
@@ -264,6 +265,7 @@ int dst_ctx_create(const dst_params* params, dst_ctx** out) {
     dst_ctx* c = new dst_ctx();
     c->prm = *params;
     int r = ctx_init(c);
+    if (r == DST_OK && c->prm.world > 1) r = dst_internal_shard_buffers(c);       // a rank can join every collective from its first proof on
     if (r != DST_OK) { g_create_error = c->err; free_all(c); delete c; *out = nullptr; return r; }
     *out = c;
     return DST_OK;

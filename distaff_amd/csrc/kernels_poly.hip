@@ -475,6 +475,10 @@ __global__ void __launch_bounds__(FRI_TAIL_THREADS) fri_tail_kernel(FriTailArgs 
 int k_fri_tail(dst_ctx* c, int first, uint8_t* roots_out) {
     const int L = c->num_fri_layers, count = L - first;
     if (first < 1 || count < 1 || count > FRI_TAIL_MAX_LAYERS) { c->err = "k_fri_tail: bad layer range"; return DST_ERR_ARG; }
+    static_assert(FRI_TAIL_THREADS == 1024, "fri_tail_kernel is ONE workgroup: its barriers are the only ordering between the layers");
+    static_assert(8 + 4 * FRI_TAIL_MAX_LAYERS <= 64, "the roots sit behind the first 8 of the 64 words of d_u64");
+    for (int i = 0; i < count; i++)
+        if (c->fri_size[first + i] / 4 < 2) { c->err = "k_fri_tail: a layer of fewer than two rows has no tree level to build"; return DST_ERR_ARG; }      // root = leaf never occurs: layers hold >= 64 evaluations
     FriTailArgs a{};
     for (int i = 0; i < count; i++) { a.e[i] = c->fri_e[first + i]; a.leaves[i] = c->fri_leaves[first + i]; a.nodes[i] = c->fri_nodes[first + i]; a.rows[i] = (uint32_t)(c->fri_size[first + i] / 4); }
     a.first = (uint32_t)first; a.count = (uint32_t)count;

@@ -41,7 +41,8 @@ static const fe* fri_layer_natural(const dst_ctx* c, int d) { return (d == 0 && 
 static bool fri_layer_replicated(const dst_ctx* c, int d) { return c->sharded_layout && d >= c->fri_rep_from; }
 
 static int ensure_shard_buffers(dst_ctx* c) {
-    if (c->gather_buf) return DST_OK;
+    if (c->gather_buf && c->d_status) return DST_OK;
+    if (c->gather_buf) { HIP_TRY(c, hipMalloc((void**)&c->d_status, 64 * 8 + 64)); return DST_OK; }
     const size_t n = c->n, G = c->prm.world;
     c->fri_rep_from = fri_replicated_from(c);
     size_t need = 32 * n * G;
@@ -56,8 +57,13 @@ static int ensure_shard_buffers(dst_ctx* c) {
         size_t nb = c->fri_size[d] / c->B / 4;             // boundary nodes per rank = rows per coset
         HIP_TRY(c, hipMalloc((void**)&c->fri_upper[d], (2 * nb * G > 2 ? 2 * nb * G : 2) * sizeof(digest)));
     }
+    HIP_TRY(c, hipMalloc((void**)&c->d_status, 64 * 8 + 64));     // status records of dst_prove_sharded (one per rank)
     return DST_OK;
 }
+// Every buffer a collective of the sharded protocol touches exists from context creation on (api.hip, world > 1): a rank that fails
+// locally at proving time (no trace uploaded, a bad argument) can still take part in every exchange and report its status through
+// them, instead of leaving its peers in a collective it never enters.
+extern "C" int dst_internal_shard_buffers(dst_ctx* c) { return ensure_shard_buffers(c); }
 static double wall_ms_shard() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static int copy_in(dst_ctx* c, void* dst, const void* src, size_t bytes, int src_is_device) {
     if (src_is_device && dst == src) return DST_OK;              // dst_prove_sharded gathers straight into the landing buffer
@@ -776,9 +782,6 @@ void commit_trace_columns(Sharded& S) {
     const size_t G = comm->world, W = c->W, n = c->n, rounds = (W + G - 1) / G;
     S.local([&]() -> int {
         if (!c->have_trace) { c->err = "dst_prove_sharded: no trace uploaded"; return DST_ERR_STATE; }
-        int r = ensure_shard_buffers(c);
-        if (r) return r;
-        if (!c->d_status) HIP_TRY(c, hipMalloc((void**)&c->d_status, 64 * 8 + 64));
         c->sharded_layout = true;
         for (bool& b : c->tree_krange) b = false;
         if (c->upload_pending) {
@@ -838,11 +841,16 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
     if (!c || !comm) return DST_ERR_ARG;                      // nothing to agree through: the caller's bug, peers are its to stop
     Sharded S{c, comm};
     // rank-local pre-flight failures must not leave the peers waiting in the first collective: they travel with the first status record
+    // A communicator of another shape than the context's cannot take part at all: the exchange sizes follow comm->world, the buffers
+    // prm.world (in-place all-gathers would run past them).  Returned before the first collective; the caller built both handles.
+    if (comm->world != c->prm.world || comm->rank != c->prm.rank) { c->err = "dst_prove_sharded: the communicator's rank / world differ from the context's"; return DST_ERR_ARG; }
+    if (comm->world > 8) return DST_ERR_ARG;                  // contexts cannot be created for more
+    // without its device or its exchange buffers (allocated at context creation; only a failed allocation there leaves them missing)
+    // a rank has nothing to hand to a collective: also returned before the first one
+    if (hipSetDevice(c->device) != hipSuccess) { c->err = "dst_prove_sharded: hipSetDevice failed"; return DST_ERR_HIP; }
+    { const int rb = ensure_shard_buffers(c); if (rb) return rb; }
     if (!pub || !proof_len) S.fail(DST_ERR_ARG, "dst_prove_sharded: null argument");
-    else if (comm->world != c->prm.world || comm->rank != c->prm.rank) S.fail(DST_ERR_ARG, "dst_prove_sharded: the communicator's rank / world differ from the context's");
-    else if (hipSetDevice(c->device) != hipSuccess) S.fail(DST_ERR_HIP, "dst_prove_sharded: hipSetDevice failed");
     const size_t G = comm->world;
-    if (G > 8) return DST_ERR_ARG;                            // contexts cannot be created for more (the same on every rank)
     double t0 = wall_ms_shard();
     auto mark = [&](int i) { const double t = wall_ms_shard(); c->phase_ms[i] = t - t0; t0 = t; };
     // steps 1-2.  Nothing waits for the extension on the host (the tree exchange is queued behind it): its share of the phase times

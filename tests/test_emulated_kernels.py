@@ -38,6 +38,7 @@ SELECTION = [
     "test_prove_sharded_behind_the_c_abi[8-8-9-False]",
     "test_prove_sharded_behind_the_c_abi[4-10-9-True]",
     "test_prove_sharded_reports_an_invalid_trace_on_every_rank",
+    "test_prove_sharded_rank_without_a_trace_on_fresh_contexts",
     "test_deep_stacks_and_nested_blocks[]",
     "test_deep_stacks_and_nested_blocks[generic]",
     "test_general_constraint_instances_on_the_fibonacci_trace[small]",

@@ -761,6 +761,42 @@ def test_prove_sharded_reports_an_invalid_trace_on_every_rank(oracle):
         ctx.close()
 
 
+def test_prove_sharded_rank_without_a_trace_on_fresh_contexts(oracle):
+    """A rank that fails before its first sharded proof (nothing uploaded on a context that has never proved) still takes part in
+    every exchange -- its buffers exist from context creation on -- and every rank returns its error instead of waiting for it."""
+    import distaff_amd as D
+    O = oracle
+    t = O.fibonacci_trace(128)
+    op = O.Prover.from_trace(t, 1, grinding=8)
+    expected = op.prove()
+    for missing in (0, 2):
+        ctxs = []
+        for r in range(4):
+            ctx = D.Context(7, t.width, t.ctx_depth, t.loop_depth, rank=r, world=4, grinding=8)
+            if r != missing:
+                ctx.upload(t.columns)
+            ctxs.append(ctx)
+        with pytest.raises(D.DistaffError) as e:
+            D.prove_sharded_local(ctxs, t.public_inputs, op.outputs)
+        assert e.value.code == D.DST_ERR_STATE, str(e.value)
+        assert "no trace uploaded" in str(e.value) and "rank %d reported error -4" % missing in str(e.value)
+        # the same contexts prove once the rank has its trace
+        ctxs[missing].upload(t.columns)
+        assert D.prove_sharded_local(ctxs, t.public_inputs, op.outputs) == expected
+        for ctx in ctxs:
+            ctx.close()
+    # a communicator of another shape than the context's is refused before any collective
+    ctx = D.Context(7, t.width, t.ctx_depth, t.loop_depth, rank=1, world=2, grinding=8)
+    ctx.upload(t.columns)
+    comms = D.Comm.local(4)
+    with pytest.raises(D.DistaffError) as e:
+        ctx.prove_sharded(comms[1], t.public_inputs, op.outputs)
+    assert e.value.code == D.DST_ERR_ARG and "rank / world" in str(e.value)
+    for cm in comms:
+        cm.close()
+    ctx.close()
+
+
 def test_plain_c_host_produces_the_oracle_proof(oracle, tmp_path):
     """examples/prove_fibonacci.c (C99, only include/distaff_hip.h and the shared library) writes the same bytes as the oracle."""
     import subprocess
