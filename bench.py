@@ -58,7 +58,8 @@ def cpu_baseline(log_n, blowup=32, queries=50):
     return {"value": (1 << log_n) * t.width / dt, "unit": "trace-cells/s", "cores": 1, "kind": "port",
             "sample": "one full prove() of a 2^%d-step Fibonacci trace (same program and ProofOptions), %.1f s, oracle/liboracle.so -O3, 1 of %d host cores"
                       % (log_n, dt, os.cpu_count() or 1),
-            "prove_ms": dt * 1e3, "phase_ms": [round(x, 1) for x in p.phase_ms]}
+            "prove_ms": dt * 1e3, "phase_ms": [round(x, 1) for x in p.phase_ms], "reference_published": REFERENCE_PUBLISHED,
+            "same_size_note": "a 2^%d sample beside a 2^%d headline: the CPU's cost per cell grows with n (log n transforms, caches), so this rate flatters the CPU at the headline size" % (log_n, int(os.environ.get("BENCH_LOG_N", "20")))}
 
 
 def pmc_row(kernel):
@@ -169,12 +170,105 @@ def kernel_rooflines(stats, steps, default_workload, top=5):
     return rows
 
 
+REFERENCE_PUBLISHED = {
+    "source": "/root/reference/README.md:147-161 ('very informal benchmarks'): Fibonacci program, default ProofOptions, execute + prove, Intel Core i5-7300U @ 2.60 GHz, single thread",
+    "execute_plus_prove_seconds_by_log2_operations": {"8": 0.19, "10": 0.35, "12": 1.0, "14": 4.5, "16": 18.0, "18": 78.0, "20": 1080.0},
+    "note_2^20": "18 min on a machine that ran out of RAM at 5.6 GB; the author's estimate with ~20 GB is ~5 min (README.md:161)",
+    "trace_cells_per_sec_2^16": (1 << 16) * W_FIB / 18.0, "trace_cells_per_sec_2^20_as_published": (1 << 20) * W_FIB / 1080.0,
+    "trace_cells_per_sec_2^20_author_estimate": (1 << 20) * W_FIB / 300.0,
+    "hardware_differs": "another CPU than this box's: quoted beside cpu_baseline as the only figures the reference publishes, not as vs_baseline",
+}
+
+
+def fibonacci_trace_cached(D, log_n):
+    """the benchmark input (host-side VM: 14 s at 2^20, minutes at 2^24 -- one thread, the sponge is a chain).  BENCH_TRACE_CACHE=<dir>
+    keeps generated traces as .npy files so that several invocations on one box (bench lines + rocprofv3 passes) generate them once."""
+    d = os.environ.get("BENCH_TRACE_CACHE")
+    if not d:
+        return D.fibonacci_trace(log_n)
+    f = os.path.join(d, "fibonacci_%d.npz" % log_n)
+    if os.path.exists(f):
+        z = np.load(f)
+        return z["cols"], z["program_hash"].tobytes(), int.from_bytes(z["result"].tobytes(), "little")
+    cols, ph, res = D.fibonacci_trace(log_n)
+    if int(os.environ.get("RANK", "0")) == 0:
+        tmp = f + ".tmp.%d.npz" % os.getpid()
+        try:
+            os.makedirs(d, exist_ok=True)
+            np.savez(tmp, cols=cols, program_hash=np.frombuffer(ph, dtype=np.uint8), result=np.frombuffer(res.to_bytes(16, "little"), dtype=np.uint8))
+            os.replace(tmp, f)
+        except OSError:                                              # no room: the next invocation generates the trace again
+            if os.path.exists(tmp):
+                os.remove(tmp)
+    return cols, ph, res
+
+
+def splitmix_columns(log_n, W):
+    """BASELINE config 2's input: W columns of 2^log_n elements uniform in [0, p): two 64-bit draws per element from
+    splitmix64(seed = 0x44697374616666 + column), low word first, values >= p rejected.  uint64 [W, n, 2]."""
+    n = 1 << log_n
+    P = 2**128 - 45 * 2**40 + 1
+    p_lo, p_hi = np.uint64(P & (2**64 - 1)), np.uint64(P >> 64)
+    cols = np.zeros((W, n, 2), dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        for c in range(W):
+            m = 2 * n + 64                                             # rejections are ~2^-82 per element: never in practice, handled anyway
+            x = np.uint64(0x44697374616666 + c) + np.uint64(0x9E3779B97F4A7C15) * np.arange(1, m + 1, dtype=np.uint64)
+            z = (x ^ (x >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+            lo, hi = z[0::2], z[1::2]
+            ok = (hi < p_hi) | ((hi == p_hi) & (lo < p_lo))
+            cols[c, :, 0], cols[c, :, 1] = lo[ok][:n], hi[ok][:n]
+    return cols
+
+
+def cpu_baseline_commit(cols, blowup):
+    """config 2's CPU leg: the oracle's TraceTable::extend + build_merkle_tree (prover.rs:22-35) on the same columns"""
+    import oracle as O
+    p = O.Prover(cols, 1, 0, [], [], ext=blowup)
+    t0 = time.time(); p.step(1); t1 = time.time(); p.step(2); t2 = time.time()
+    W, n = cols.shape[0], cols.shape[1]
+    return {"value": n * W / (t2 - t0), "unit": "trace-cells/s", "cores": 1, "kind": "port",
+            "sample": "extend + trace Merkle tree of the SAME %d x 2^%d columns, %.1f s, oracle/liboracle.so -O3, 1 of %d host cores" % (W, n.bit_length() - 1, t2 - t0, os.cpu_count() or 1),
+            "prove_ms": (t2 - t0) * 1e3, "phase_ms": [round((t1 - t0) * 1e3, 1), round((t2 - t1) * 1e3, 1)], "root_hex": p.get_bytes("roots")[:32].hex(),
+            "reference_published": REFERENCE_PUBLISHED}
+
+
+_STATE = {"rank": 0, "stage": "start", "args": None}
+
+
+def error_line(message):
+    """the contract's ONE JSON line also when the run fails: rank 0 says what failed and where instead of leaving the driver with a hang
+    or a bare traceback"""
+    a = _STATE["args"]
+    if _STATE["rank"] == 0:
+        print(json.dumps({"metric": "trace_cells_per_sec", "value": None, "unit": "trace-cells/s", "n_gpus": getattr(a, "gpus", None), "steps": getattr(a, "steps", None),
+                          "warmup": getattr(a, "warmup", None), "error": str(message)[-2000:], "stage": _STATE["stage"]}), flush=True)
+
+
+def start_watchdog(seconds):
+    """a collective that never returns (a rank died, RCCL cannot reach a peer) must end the run with an error line, not hang the driver"""
+    import threading
+
+    def fire():
+        error_line("no progress for %d s in stage '%s' (BENCH_TIMEOUT_S): giving up instead of hanging" % (seconds, _STATE["stage"]))
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(3)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)         # the driver's own values: a proof is 37 ms, and the first steps after a cold
     ap.add_argument("--warmup", type=int, default=5)         # start run up to 8 % slower (clock ramp; step_ms shows the spread)
-    ap.add_argument("--log-n", type=int, default=int(os.environ.get("BENCH_LOG_N", "20")))
+    ap.add_argument("--workload", choices=["prove", "commit"], default="prove",
+                    help="prove: full stark::prove of the Fibonacci trace (BASELINE configs 3-5, the metric); commit: LDE + trace Merkle tree only on random columns (BASELINE config 2)")
+    ap.add_argument("--log-n", type=int, default=None, help="log2 of the trace length (default 20; 16 for --workload commit)")
     ap.add_argument("--cpu-log-n", type=int, default=int(os.environ.get("BENCH_CPU_LOG_N", "16")))
     ap.add_argument("--log-blowup", type=int, default=5, help="log2 of the extension factor (default ProofOptions: 5; BASELINE config 5: 4)")
     ap.add_argument("--queries", type=int, default=50, help="number of queries (default ProofOptions: 50; BASELINE config 5: 100)")
@@ -183,7 +277,28 @@ def main():
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the second timed region (trace starting in pinned host memory)")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (multi-GPU) code path even with one rank")
     args = ap.parse_args()
+    if args.log_n is None:
+        args.log_n = int(os.environ.get("BENCH_LOG_N", "16" if args.workload == "commit" else "20"))
+    _STATE["args"] = args
+    _STATE["rank"] = int(os.environ.get("RANK", "0"))
+    watchdog = start_watchdog(int(os.environ.get("BENCH_TIMEOUT_S", "1500")))
+    try:
+        run(args)
+    except SystemExit as e:
+        if e.code not in (None, 0):
+            error_line(e.code)
+        raise
+    except BaseException as e:                                       # noqa: BLE001 -- the line first, then the traceback
+        import traceback
+        traceback.print_exc()
+        error_line("%s: %s" % (type(e).__name__, e))
+        sys.stdout.flush()
+        os._exit(1)                                                  # peers may sit in a collective: do not wait for their clean-up
+    finally:
+        watchdog.cancel()
 
+
+def run(args):
     import torch
     import distaff_amd as D
 
@@ -194,14 +309,34 @@ def main():
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP prover has no CPU fallback")
-    torch.cuda.set_device(local_rank)
+    if world > 8 or (world & (world - 1)):
+        raise SystemExit("--gpus must be 1, 2, 4 or 8 (cosets of the LDE domain are split evenly)")
+    if args.workload == "commit" and (world > 1 or args.force_sharded):
+        raise SystemExit("--workload commit is the single-GPU config 2 (LDE + Merkle only)")
+    # More ranks than visible devices: the ranks SHARE devices (a one-GPU box exercising the N-process path).  RCCL refuses two ranks on
+    # one device, so the library's collectives then travel through the callback transport over a gloo group (host-staged).  Functional
+    # run: the JSON line says so and is no scaling measurement.
+    ndev = max(1, torch.cuda.device_count())
+    shared_devices = world > ndev
+    device = local_rank % ndev
+    torch.cuda.set_device(device)
+    want = os.environ.get("DISTAFF_SHARD_TRANSPORT", "rccl")         # rccl | callbacks
+    if want not in ("rccl", "callbacks"):
+        raise SystemExit("DISTAFF_SHARD_TRANSPORT must be rccl or callbacks")
+    host_group = shared_devices or os.environ.get("DISTAFF_SHARD_BACKEND") == "gloo"
+    if shared_devices:
+        want = "callbacks"
     dist = None
+    _STATE["stage"] = "process group"
     if world > 1 or args.force_sharded:
+        import datetime
         import torch.distributed as dist
-        if "MASTER_ADDR" in os.environ:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1, device_id=torch.device("cuda", local_rank))
+        kw = {"timeout": datetime.timedelta(seconds=int(os.environ.get("BENCH_PG_TIMEOUT_S", "600")))}
+        if not host_group:
+            kw["device_id"] = torch.device("cuda", device)
+        if "MASTER_ADDR" not in os.environ:
+            kw.update(init_method="tcp://127.0.0.1:29517", rank=0, world_size=1)
+        dist.init_process_group("gloo" if host_group else "nccl", **kw)
 
     def barrier():
         if dist is not None:
@@ -210,42 +345,75 @@ def main():
 
     log_n = args.log_n
     n = 1 << log_n
-    cols, program_hash, result = D.fibonacci_trace(log_n)          # host: VM trace of `begin repeat.K swap dup.2 drop add end end`
-    if world > 8 or (world & (world - 1)):
-        raise SystemExit("--gpus must be 1, 2, 4 or 8 (cosets of the LDE domain are split evenly)")
+    _STATE["stage"] = "trace"
+    if args.workload == "commit":
+        cols, program_hash, result = splitmix_columns(log_n, W_FIB), None, None
+    else:
+        cols, program_hash, result = fibonacci_trace_cached(D, log_n)   # host: VM trace of `begin repeat.K swap dup.2 drop add end end`
     blowup = 1 << args.log_blowup
-    ctx = D.Context(log_n, W_FIB, 1, 0, device=local_rank, rank=rank, world=world, log_blowup=args.log_blowup, num_queries=args.queries)   # defaults = default ProofOptions: blowup 32, 50 queries, grinding 20
+    _STATE["stage"] = "context"
+    ctx = D.Context(log_n, W_FIB, 1, 0, device=device, rank=rank, world=world, log_blowup=args.log_blowup, num_queries=args.queries)   # defaults = default ProofOptions: blowup 32, 50 queries, grinding 20
     c_orchestration = (world > 1 or args.force_sharded) and os.environ.get("DISTAFF_SHARD_ORCH", "c") != "python"
     if c_orchestration and world > 1:
         ctx.upload_owned(cols)                                      # dst_prove_sharded splits the interpolation by columns: 1 / world of the trace per GPU
     else:
         ctx.upload(cols)                                            # inputs resident in HBM before the timed region
 
-    if world == 1 and not args.force_sharded:
+    _STATE["stage"] = "communicator"
+    stage_of = None
+    transport_note = None
+    if args.workload == "commit":
+        def prove():
+            return ctx.commit_trace()
+        transport = "none"
+    elif world == 1 and not args.force_sharded:
         def prove():
             return ctx.prove([1, 0], [result])
         transport = "none"
     else:
         # ONE proof sharded over the GPUs by cosets of the LDE domain.  Default: the whole exchange sequence behind the C-ABI
         # (dst_prove_sharded: RCCL all-to-all / all-gather issued by the library; torch.distributed only carries the 128-byte unique id
-        # and the timing barrier).  DISTAFF_SHARD_ORCH=python keeps the host-orchestrated sequence of distaff_amd/sharded.py
+        # and the timing barrier).  DISTAFF_SHARD_TRANSPORT=callbacks: the same library code with its collectives handed to the host's
+        # channel (dst_comm_init_callbacks over the torch.distributed group) -- also the fallback when the library's RCCL binding cannot
+        # be brought up on some rank.  DISTAFF_SHARD_ORCH=python keeps the host-orchestrated sequence of distaff_amd/sharded.py
         # (torch.distributed collectives around dst_shard_*) as a cross-check.
         if os.environ.get("DISTAFF_SHARD_ORCH", "c") != "python":
-            ids = [D.Comm.unique_id() if rank == 0 else None]
-            dist.broadcast_object_list(ids, src=0)
-            comm = D.Comm.rccl(ids[0], rank, world, local_rank)
-            transport = "dst_prove_sharded over RCCL"
+            comm = None
+            if want == "rccl":
+                failure = None
+                try:
+                    ids = [D.Comm.unique_id() if rank == 0 else None]
+                    dist.broadcast_object_list(ids, src=0)
+                    comm = D.Comm.rccl(ids[0], rank, world, device)
+                except Exception as e:                               # noqa: BLE001 -- agreed on below
+                    failure = "%s: %s" % (type(e).__name__, e)
+                failures = [None] * world
+                dist.all_gather_object(failures, failure)
+                if any(failures):
+                    if comm is not None:
+                        comm.close()
+                    comm = None
+                    transport_note = "the library's RCCL communicator could not be created (%s): collectives carried by the torch.distributed group instead" % next(f for f in failures if f)
+                    if rank == 0:
+                        print("[bench] " + transport_note, file=sys.stderr, flush=True)
+                else:
+                    transport = "dst_prove_sharded over RCCL"
+            if comm is None:
+                comm = D.Comm.over_torch(dist)
+                transport = "dst_prove_sharded over the callback transport (torch.distributed %s%s)" % (
+                    dist.get_backend(), ", host-staged, ranks sharing %d device(s)" % ndev if shared_devices else "")
 
-            class _Stages:
-                stage_ms = {}
-            prover = _Stages()
+            def stage_of():
+                return ctx.shard_stage_ms()
 
             def prove():
                 return ctx.prove_sharded(comm, [1, 0], [result])
         else:
             from distaff_amd import sharded
-            device_path = os.environ.get("DISTAFF_SHARD_TRANSPORT", "device") == "device"
-            comm = sharded.TorchComm(dist, torch.device("cuda", local_rank), device_path=device_path)
+            # hand-off between the library's buffers and the collective's tensors: "device" = through the tensors' data pointers (device tensors
+            # of an nccl group), "host" = staged through host arrays (the only form a gloo group of ranks sharing a GPU can take)
+            device_path = (os.environ.get("DISTAFF_SHARD_HANDOFF") or ("host" if host_group else "device")) == "device"
+            tcomm = sharded.TorchComm(dist, torch.device("cuda", device), device_path=device_path)
             if device_path:
                 # self-check of the direct hand-off between the library's buffers and torch tensors; fall back to host staging
                 ok = True
@@ -253,26 +421,31 @@ def main():
                     ctx.shard_commit_trace()
                     host = np.empty(ctx.shard_export_size(0), dtype=np.uint8)
                     ctx.shard_export(0, 0, host.ctypes.data, False)
-                    big = torch.zeros(ctx.shard_export_size(0), dtype=torch.uint8, device=comm.device)
+                    big = torch.zeros(ctx.shard_export_size(0), dtype=torch.uint8, device=tcomm.device)
                     torch.cuda.synchronize()
                     ctx.shard_export(0, 0, big.data_ptr(), True)
                     ok = bool((big.cpu().numpy() == host).all())
                 except Exception:                                       # noqa: BLE001
                     ok = False
-                flags = comm.all_gather_object(ok)
+                flags = tcomm.all_gather_object(ok)
                 if not all(flags):
-                    comm.device_path = False
-            transport = "torch.distributed, " + ("device" if comm.device_path else "host-staged")
-            prover = sharded.ShardedProver(ctx, comm)
+                    tcomm.device_path = False
+            transport = "torch.distributed, " + ("device" if tcomm.device_path else "host-staged")
+            prover = sharded.ShardedProver(ctx, tcomm)
+
+            def stage_of():
+                return prover.stage_ms
 
             def prove():
                 return prover.prove([1, 0], [result])
 
+    _STATE["stage"] = "warm-up"
     proof = None
     for _ in range(args.warmup):
         proof = prove()
     # timed region: HIP events around the heavy kernels only (NTT passes, constraint kernel, leaf hashing: the dominant kernel is one
     # of them); bracketing all ~300 launches of a proof costs ~5 % and is done on one extra, untimed step for the kernel table
+    _STATE["stage"] = "timed region"
     ctx.set_profiling(2)
     ctx.kernel_stats(reset=True)
     barrier()
@@ -286,15 +459,16 @@ def main():
         step_ms.append((time.perf_counter() - ts) * 1e3)               # prove() returns the finished proof: no extra synchronisation
         for i, v in enumerate(ctx.phase_ms()):
             phase_sum[i] += v
-        if transport != "none":
-            for k, v in prover.stage_ms.items():
+        if stage_of is not None:
+            for k, v in stage_of().items():
                 stage_sum[k] = stage_sum.get(k, 0.0) + v
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_group else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    _STATE["stage"] = "kernel table"
     stats = ctx.kernel_stats(reset=True)
     ctx.set_profiling(1)
     prove()                                                        # untimed: every launch bracketed, for the "kernels" table
@@ -305,14 +479,15 @@ def main():
     # the upload is asynchronous DMA and the registers are extended group by group as they arrive
     incl_upload_ms = None
     if transport == "none" and not args.no_upload_leg:
+        _STATE["stage"] = "upload leg"
         table, handle = ctx.pinned_trace(cols)
         for _ in range(max(1, args.warmup)):
-            ctx.upload_async(table); proof_u = ctx.prove([1, 0], [result])
+            ctx.upload_async(table); proof_u = prove()
         barrier()
         t1 = time.perf_counter()
         for _ in range(args.steps):
             ctx.upload_async(table)
-            proof_u = ctx.prove([1, 0], [result])
+            proof_u = prove()
         barrier()
         incl_upload_ms = (time.perf_counter() - t1) / args.steps * 1e3
         ctx.release_pinned(handle)
@@ -321,8 +496,10 @@ def main():
 
     if rank != 0:
         if dist is not None:
+            dist.barrier()                                             # rank 0 may still verify / time the CPU leg: leave together
             dist.destroy_process_group()
         return
+    _STATE["stage"] = "report"
 
     ms_per_step = elapsed / args.steps * 1e3
     cells = n * W_FIB
@@ -330,9 +507,11 @@ def main():
     # kernels by device time, measured with HIP events on the launch stream inside the timed region.  `roofline` is the kernel with the
     # largest total time IN THIS RUN; `roofline_transform` is always the first pass of the transforms (the kernel profiles/README.md
     # describes), so that the two can be told apart when another kernel is dominant on some box; `rooflines` lists the top five.
-    default_workload = log_n == 20 and world == 1 and (blowup, args.queries) == (32, 50)     # what the committed PMC passes were taken on
+    default_workload = args.workload == "prove" and log_n == 20 and world == 1 and (blowup, args.queries) == (32, 50)     # what the committed PMC passes were taken on
     rooflines = kernel_rooflines(stats, args.steps, default_workload)
-    note = "the path is 128-bit modular integer arithmetic on the VALU: see valu_issue_frac, alu_roofline and DESIGN.md"
+    note = ("the path is 128-bit modular integer arithmetic on the VALU (valu_issue_frac, alu_roofline, DESIGN.md section 3), not HBM-bound; `frac` is the per-KERNEL figure: "
+            "its algorithmic bytes include the staging array the two-pass transform writes in pass A and re-reads in pass B, which SURVEY section 8(d) does not count -- "
+            "the phase-level fraction with section 8(d)'s bytes counted once is phase_hbm.lde (and phase_hbm.proof for the whole proof)")
     roofline = dict(rooflines[0], note=note) if rooflines else None
     transform = [r for r in kernel_rooflines(stats, args.steps, default_workload, top=len(stats)) if r["kernel"].startswith("ntt_pass_a")]
     roofline_transform = dict(transform[0], note=note) if transform else None
@@ -342,6 +521,8 @@ def main():
     phase_hbm = None
     if transport == "none":
         pb = phase_algorithmic_bytes(n, W_FIB, blowup)
+        if args.workload == "commit":
+            pb = {k: pb[k] for k in ("lde", "trace_merkle")}
         phase_hbm = {}
         for k, v in zip(phase_names, phase_sum):
             if k in pb and v > 0:
@@ -349,7 +530,7 @@ def main():
                 phase_hbm[k] = {"algorithmic_GiB": round(pb[k] / 2**30, 3), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
         total_b = sum(pb.values())
         gbs = total_b / (ms_per_step * 1e-3) / 1e9
-        phase_hbm["proof"] = {"algorithmic_GiB": round(total_b / 2**30, 3), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
+        phase_hbm["proof" if args.workload == "prove" else "commit"] = {"algorithmic_GiB": round(total_b / 2**30, 3), "GBps": round(gbs, 1), "frac": round(gbs / HBM_PEAK_GBS, 4)}
     # integer-multiplier roofline: the peak of v_mad_u64_u32 (the 32x32+64 multiply-add every field multiplication is made of) measured
     # on this device, against the multiply-adds the kernels execute: NTT launches count theirs (18 per table-pair multiplication), the
     # constraint kernels are priced with the static instruction counts of the current build (distaff_amd/_build_info.json)
@@ -388,19 +569,23 @@ def main():
     # ALU ceiling: dependent-chain modular multiplications per second measured on this device with the same fe_mul
     mm_ms = ctx.bench_mulmod(1 << 21, 512)
     mulmod_peak = (1 << 21) * 512 * 4 / (mm_ms * 1e-3)
+    if args.workload == "commit":
+        workload = ("BASELINE config 2: LDE (iNTT + coset NTTs) + BLAKE3 row hashing + Merkle tree of %d uniform random columns (splitmix64, SURVEY.md 8(d)) of 2^%d steps, "
+                    "blowup %d: TraceTable::extend + build_merkle_tree (prover.rs:22-35) only" % (W_FIB, log_n, blowup))
+    else:
+        workload = ("Fibonacci program (src/examples/fibonacci.rs), 2^%d-step trace, W=20 registers, full stark::prove with %sProofOptions (blowup %d, %d queries, grinding 20, blake3)"
+                    % (log_n, "default " if (blowup, args.queries) == (32, 50) else "", blowup, args.queries))
     out = {
         "metric": "trace_cells_per_sec", "value": value, "unit": "trace-cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
         "dtype": "u128 (prime field 2^128-45*2^40+1, 4x u32 limbs)", "data": "synthetic",
-        "config": {"workload": "Fibonacci program (src/examples/fibonacci.rs), 2^%d-step trace, W=20 registers, full stark::prove with %s"
-                               "ProofOptions (blowup %d, %d queries, grinding 20, blake3)" % (log_n, "default " if (blowup, args.queries) == (32, 50) else "", blowup, args.queries),
+        "config": {"workload": workload,
                    "trace_steps": n, "registers": W_FIB, "blowup": blowup, "queries": args.queries, "grinding": 20,
                    "parallelism": "1 GPU" if world == 1 else "one proof sharded over %d GPUs: interpolation by trace columns (coefficients all-gathered), everything on the LDE domain by cosets; "
                                   "Merkle trees finished per k-range (all-to-all of boundary nodes, all-gather of subtree roots), all-gather of constraint evaluations and of the "
                                   "first small FRI layer; %s" % (world, transport)},
         "prover_ms": ms_per_step,
-        "phase_ms": None if transport.startswith("torch") else {k: round(v / args.steps, 3) for k, v in zip(
-            ["lde", "trace_merkle", "constraint_eval", "combine", "constraint_lde_merkle", "deep_composition", "fri", "pow_queries", "openings"], phase_sum)},
+        "phase_ms": None if transport.startswith("torch") else {k: round(v / args.steps, 3) for k, v in zip(phase_names, phase_sum) if args.workload == "prove" or k in ("lde", "trace_merkle")},
         "proof_bytes": len(proof),
         "shard_stage_ms_rank0": {k: round(v / args.steps, 3) for k, v in stage_sum.items()} or None,
         "roofline": roofline,
@@ -416,18 +601,35 @@ def main():
                     for k, v in sorted(all_stats.items(), key=lambda kv: -kv[1]["ms"])},
         "kernels_note": "one extra untimed proof with every launch bracketed by events; the roofline kernel is timed inside the timed region",
     }
-    if not args.no_verify:
+    if world > 1 or args.force_sharded:
+        out["devices"] = {"visible": ndev, "ranks": world, "shared": shared_devices,
+                          "note": ("%d ranks share %d device(s): a FUNCTIONAL run of the N-process path on this box, not a scaling measurement" % (world, ndev)) if shared_devices else None}
+        if transport_note:
+            out["transport_note"] = transport_note
+    _STATE["stage"] = "verification"
+    if args.workload == "commit":
+        out["proof_bytes"] = None
+        out["trace_root_hex"] = proof.hex()
+    elif not args.no_verify:
         # the checker, outside every timed region: the oracle's restatement of the reference verifier must accept the timed proof
         import oracle as O
         ok, err = O.verify(proof, program_hash, [1, 0], [result])
         if not ok:
             raise SystemExit("the oracle's verifier rejects the timed proof: " + err)
         out["proof_verified"] = "accepted by oracle/verifier.hpp (restatement of stark::verify) after the timed regions"
+    _STATE["stage"] = "cpu baseline"
     if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(args.cpu_log_n, blowup, args.queries)
+        if args.workload == "commit":
+            out["cpu_baseline"] = cpu_baseline_commit(cols, blowup)
+            if out["cpu_baseline"]["root_hex"] != proof.hex():
+                raise SystemExit("the oracle's trace root differs from the GPU's on the same columns")
+            out["proof_verified"] = "trace root equals the oracle's (same columns, CPU leg of this run)"
+        else:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_log_n, blowup, args.queries)
     print(json.dumps(out), flush=True)
     ctx.close()
     if dist is not None:
+        dist.barrier()
         dist.destroy_process_group()
 
 

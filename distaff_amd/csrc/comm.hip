@@ -208,4 +208,14 @@ int dst_comm_init_callbacks(uint32_t rank, uint32_t world, dst_comm_fn fn, void*
 
 void dst_comm_destroy(dst_comm* comm) { delete comm; }
 
+// For hosts whose own transport (dst_comm_init_callbacks) stages through memory the library did not allocate: one synchronous copy
+// between any two of {host memory, memory of the current device}; the direction follows from the pointers.
+int dst_comm_copy(void* dst, const void* src, size_t bytes) {
+    if ((!dst || !src) && bytes) { g_comm_error = "dst_comm_copy: null pointer"; return DST_ERR_ARG; }
+    if (bytes == 0 || dst == src) return DST_OK;
+    const hipError_t e = hipMemcpy(dst, src, bytes, hipMemcpyDefault);
+    if (e != hipSuccess) { g_comm_error = std::string("dst_comm_copy: ") + hipGetErrorString(e); return DST_ERR_HIP; }
+    return DST_OK;
+}
+
 }  // extern "C"

@@ -164,6 +164,8 @@ struct dst_ctx {
     std::vector<hipEvent_t> comm_events;
     uint8_t* d_status = nullptr;
     double phase_ms[9] = {0};
+    double shard_ms[2] = {0, 0};           // dst_prove_sharded: host milliseconds inside the transport's calls / waiting for tree roots
+    uint32_t shard_trees = 0;              // tree exchanges of the last sharded proof
 
     // optional per-kernel timing with HIP events recorded on `stream` (dst_set_profiling / dst_kernel_stats)
     int profile = 0;                       // dst_set_profiling: 0 off, 1 every kernel launch, 2 only the heavy kernels (NTT passes, constraint kernel, leaf hashing)

@@ -46,7 +46,9 @@ __device__ __forceinline__ constexpr bool lds_wave_local() {
 // compiler must not move accesses across it), a workgroup barrier in the host-emulated test build (its work-items are fibers)
 __device__ __forceinline__ void lds_wave_sync() {
 #if defined(__HIP_DEVICE_COMPILE__)
-    static_assert(__AMDGCN_WAVEFRONT_SIZE == 64, "the rows a wavefront owns (own_rows in the rounds below) are counted for 64 lanes");
+#if !defined(__gfx950__)
+#error "the rows a wavefront owns (own_rows in the rounds below) are counted for the 64-lane wavefronts of gfx950"
+#endif
     // wave_barrier keeps the scheduler from moving instructions across this point but is no memory fence to the compiler: the empty
     // statement with a memory clobber is (no load is hoisted above it, no store sunk below it, nothing forwarded across it)
     asm volatile("" ::: "memory");

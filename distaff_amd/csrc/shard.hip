@@ -19,7 +19,7 @@ extern "C" void dst_internal_transition_coefficients(const dst_ctx* c, const fe*
 
 enum { SH_TRACE_TREE = 0, SH_CONSTRAINT_TREE = 1, SH_FRI_TREE = 2, SH_CEVAL = 3, SH_FRI_LAST = 4, SH_FRI_SEND_CAP = 5 };
 enum { RD_TRACE_LEAF = 0, RD_TRACE_NODE = 1, RD_TRACE_UPPER = 2, RD_CEVAL = 3, RD_C_NODE = 4, RD_C_UPPER = 5, RD_FRI_E = 6, RD_FRI_LEAF = 7,
-       RD_FRI_NODE = 8, RD_FRI_UPPER = 9, RD_LDE_ROW = 10,
+       RD_FRI_NODE = 8, RD_FRI_UPPER = 9, RD_LDE_ROW = 10, RD_TEVAL = 11,
        RD_MID_OFFSET = 32 };            // RD_*_UPPER + RD_MID_OFFSET: the rank's subtree heap of a k-range tree (behind the 2G entries of the top heap)
 
 static size_t fri_nd(const dst_ctx* c, int d) { return c->fri_size[d] / c->B; }     // elements per coset in layer d
@@ -300,6 +300,7 @@ int dst_shard_read(dst_ctx* c, uint32_t buffer, uint32_t arg, const uint64_t* id
         case RD_FRI_NODE: if ((int)arg >= c->num_fri_layers) return DST_ERR_ARG; src = c->fri_nodes[arg]; break;
         case RD_FRI_UPPER: if ((int)arg >= c->num_fri_layers) return DST_ERR_ARG; src = fri_layer_replicated(c, (int)arg) ? c->fri_nodes[arg] : c->fri_upper[arg]; break;
         case RD_LDE_ROW: break;
+        case RD_TEVAL: src = c->ceval + 2 * (c->Bc / (c->B / 8)) * c->n; item = 16; break;        // transition combination, this rank's evaluation cosets [Q][n]
         default: c->err = "dst_shard_read: unknown buffer"; return DST_ERR_ARG;
     }
     size_t idx_bytes = ((size_t)count * 8 + 15) / 16 * 16;
@@ -665,6 +666,14 @@ int dst_shard_assemble(dst_ctx* c, const uint64_t* positions, uint32_t num_posit
     return DST_OK;
 }
 
+// host-side view of the last dst_prove_sharded on this rank: [0] milliseconds inside the transport's calls, [1] milliseconds waiting for
+// the tree roots (the only points where the host waits for the device), [2] number of tree exchanges
+int dst_shard_stage_ms(const dst_ctx* c, double out[3]) {
+    if (!c || !out) return DST_ERR_ARG;
+    out[0] = c->shard_ms[0]; out[1] = c->shard_ms[1]; out[2] = (double)c->shard_trees;
+    return DST_OK;
+}
+
 int dst_shard_info(dst_ctx* c, uint64_t* op_count, uint32_t* num_fri_layers, uint32_t* stack_depth) {
     if (!c) return DST_ERR_ARG;
     if (op_count) *op_count = c->op_count;
@@ -703,6 +712,8 @@ struct Sharded {
     int agreed = DST_OK;                   // first failing rank's code once an exchange has shown one
     // a rank-local step; collectives are issued regardless (see above)
     void local(const std::function<int()>& f) { if (rc == DST_OK) { rc = f(); } }           // (this file's functions sit in an extern "C" block: no member templates)
+    // host time inside the transport's calls (an enqueue on a stream-ordered transport, the whole exchange on a blocking one)
+    int timed(const std::function<int()>& f) { const double t = wall_ms_shard(); const int r = f(); c->shard_ms[0] += wall_ms_shard() - t; return r; }
     void fail(int code, const std::string& msg) { if (rc == DST_OK) { rc = code; c->err = msg; } }
     // collective errors are not rank-local: the transport failed for everyone (or will hang for everyone)
     bool coll(int r, const char* what) { if (r != DST_OK) { if (rc == DST_OK) { rc = r; c->err = std::string(what) + ": " + comm->err; } agreed = agreed ? agreed : r; return false; } return true; }
@@ -738,19 +749,20 @@ void tree_exchange(Sharded& S, uint32_t what, uint32_t arg, uint8_t root[32], co
     if (shard_boundary(c, what, arg, &src, &K)) { S.fail(DST_ERR_ARG, c->err); S.agreed = DST_ERR_ARG; return; }      // the same on every rank
     digest* upper = what == SH_TRACE_TREE ? c->trace_upper : what == SH_CONSTRAINT_TREE ? c->c_upper : c->fri_upper[arg];
     const int slot = what == SH_TRACE_TREE ? 0 : what == SH_CONSTRAINT_TREE ? 1 : 2 + (int)arg;
+    c->shard_trees++;
     const bool krange = G > 1 && K >= G && K % G == 0 && !getenv("DISTAFF_SHARD_TREE_GATHER");
     c->tree_krange[slot] = krange;
     if (getenv("DISTAFF_SHARD_DEBUG") && comm->rank == 0) fprintf(stderr, "[distaff] tree %u/%u: %zu boundary nodes per rank, %s\n", what, arg, K, krange ? "k-range exchange (all-to-all + root all-gather)" : "all-gather of boundary nodes");
     if ((krange ? K * 32 : K * 32 * G) > c->gather_bytes) { S.fail(DST_ERR_ARG, "tree_exchange: gather buffer too small"); S.agreed = DST_ERR_ARG; return; }   // the same on every rank
     if (krange) {
         const size_t chunk = K / G;                              // boundary nodes per (sender, owner) pair
-        if (!S.coll(comm->all_to_all(src, c->gather_buf, chunk * 32, c->stream), "tree_exchange")) return;
+        if (!S.coll(S.timed([&] { return comm->all_to_all(src, c->gather_buf, chunk * 32, c->stream); }), "tree_exchange")) return;
         digest* mid = upper + 2 * G;                             // this rank's subtree heap: mid[1] = its root, mid[K + kl*G + r] = boundary node of rank r at k = g*K/G + kl
         S.local([&] { k_upper_tree(c, (const digest*)c->gather_buf, mid, chunk, (uint32_t)G); return DST_OK; });
-        if (!S.coll(comm->all_gather(mid + 1, upper + G, 32, c->stream), "tree_exchange")) return;
+        if (!S.coll(S.timed([&] { return comm->all_gather(mid + 1, upper + G, 32, c->stream); }), "tree_exchange")) return;
         S.local([&] { k_merkle_upper(c, upper, G); return DST_OK; });                          // the top log2(G) levels, on every rank
     } else {
-        if (!S.coll(comm->all_gather(src, c->gather_buf, K * 32, c->stream), "tree_exchange")) return;
+        if (!S.coll(S.timed([&] { return comm->all_gather(src, c->gather_buf, K * 32, c->stream); }), "tree_exchange")) return;
         S.local([&] { k_upper_tree(c, (const digest*)c->gather_buf, upper, K, (uint32_t)G); return DST_OK; });
     }
     // status records (and rank 0's payload) of all ranks: [G] records, this rank's own at index rank (in-place all-gather)
@@ -761,10 +773,12 @@ void tree_exchange(Sharded& S, uint32_t what, uint32_t arg, uint8_t root[32], co
     if (staged && payload_src && comm->rank == 0 && S.rc == DST_OK)
         for (int i = 0; i < 3 && staged; i++) staged = hipMemcpyAsync(&recs[0].payload[i], payload_src[i], sizeof(fe), hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
     if (!staged) S.fail(DST_ERR_HIP, "tree_exchange: staging of the status record failed");
-    if (!S.coll(comm->all_gather(recs + comm->rank, recs, sizeof(StatusRec), c->stream), "tree_exchange")) return;
+    if (!S.coll(S.timed([&] { return comm->all_gather(recs + comm->rank, recs, sizeof(StatusRec), c->stream); }), "tree_exchange")) return;
+    const double t_wait = wall_ms_shard();
     bool ok = hipMemcpyAsync(all.data(), recs, G * sizeof(StatusRec), hipMemcpyDeviceToHost, c->stream) == hipSuccess;
     ok = ok && hipMemcpyAsync(root, upper + 1, 32, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
     ok = ok && hipStreamSynchronize(c->stream) == hipSuccess && hipGetLastError() == hipSuccess;
+    c->shard_ms[1] += wall_ms_shard() - t_wait;                 // the host waits here for everything queued before the root: kernels and exchanges
     if (!ok) { S.fail(DST_ERR_HIP, "tree_exchange: root read-back failed"); S.agreed = S.agreed ? S.agreed : DST_ERR_HIP; return; }
     S.saw(all.data(), what == SH_TRACE_TREE ? "trace tree" : what == SH_CONSTRAINT_TREE ? "constraint tree" : "FRI tree");
     if (payload_out) for (int i = 0; i < 3; i++) payload_out[i] = all[0].payload[i];
@@ -819,14 +833,14 @@ void commit_trace_columns(Sharded& S) {
             return DST_OK;
         });
         if (use_side) {
-            if (!S.coll(comm->all_gather(c->polys + col * n, c->polys + k * G * n, n * sizeof(fe), c->comm_stream), "coefficient all-gather")) return;
+            if (!S.coll(S.timed([&] { return comm->all_gather(c->polys + col * n, c->polys + k * G * n, n * sizeof(fe), c->comm_stream); }), "coefficient all-gather")) return;
             S.local([&]() -> int { HIP_TRY(c, hipEventRecord(c->comm_events[2 * k + 1], c->comm_stream)); return DST_OK; });
         }
     }
     for (size_t k = 0; k < rounds; k++) {
         const size_t first = k * G, cnt = first + G <= W ? G : W - first;
         if (use_side) S.local([&]() -> int { HIP_TRY(c, hipStreamWaitEvent(c->stream, c->comm_events[2 * k + 1], 0)); return DST_OK; });
-        else if (!S.coll(comm->all_gather(c->polys + (first + comm->rank) * n, c->polys + first * n, n * sizeof(fe), c->stream), "coefficient all-gather")) return;
+        else if (!S.coll(S.timed([&] { return comm->all_gather(c->polys + (first + comm->rank) * n, c->polys + first * n, n * sizeof(fe), c->stream); }), "coefficient all-gather")) return;
         S.local([&]() -> int { k_lde_columns(c, c->polys + first * n, c->lde + first * c->Bc * n, cnt); return DST_OK; });
     }
     S.local([&]() -> int {
@@ -852,6 +866,7 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
     if (!pub || !proof_len) S.fail(DST_ERR_ARG, "dst_prove_sharded: null argument");
     const size_t G = comm->world;
     double t0 = wall_ms_shard();
+    c->shard_ms[0] = c->shard_ms[1] = 0; c->shard_trees = 0;
     auto mark = [&](int i) { const double t = wall_ms_shard(); c->phase_ms[i] = t - t0; t0 = t; };
     // steps 1-2.  Nothing waits for the extension on the host (the tree exchange is queued behind it): its share of the phase times
     // comes from two events on the stream
@@ -893,7 +908,7 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
     {
         struct BadRec { int64_t bad; int64_t rc; } mine{bad, S.rc};
         std::vector<BadRec> all(G);
-        if (!S.coll(comm->all_gather_host(&mine, all.data(), sizeof(BadRec)), "constraint evaluation")) return S.agreed;
+        if (!S.coll(S.timed([&] { return comm->all_gather_host(&mine, all.data(), sizeof(BadRec)); }), "constraint evaluation")) return S.agreed;
         int64_t first = -1;
         for (size_t g = 0; g < G; g++) {
             if (all[g].rc != DST_OK && S.agreed == DST_OK) { S.agreed = (int)all[g].rc; if (S.rc == DST_OK) c->err = "constraint evaluation: rank " + std::to_string(g) + " reported error " + std::to_string(all[g].rc); }
@@ -923,11 +938,11 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
         const bool side = (comm->stream_ordered() || getenv("DISTAFF_SHARD_FORCE_OVERLAP")) && G > 1 && invert_first && S.rc == DST_OK && c->comm_stream && c->comm_events.size() >= 2 && !getenv("DISTAFF_SHARD_NO_OVERLAP");
         if (side) {
             S.local([&]() -> int { HIP_TRY(c, hipEventRecord(c->comm_events[0], c->stream)); HIP_TRY(c, hipStreamWaitEvent(c->comm_stream, c->comm_events[0], 0)); return DST_OK; });
-            if (!S.coll(comm->all_gather(send, c->gather_buf, bytes, c->comm_stream), "constraint evaluations")) return S.agreed;
+            if (!S.coll(S.timed([&] { return comm->all_gather(send, c->gather_buf, bytes, c->comm_stream); }), "constraint evaluations")) return S.agreed;
             S.local([&]() -> int { HIP_TRY(c, hipEventRecord(c->comm_events[1], c->comm_stream)); return DST_OK; });
             S.local([&] { part1_done = true; return shard_combine_parts(c, 1); });
             S.local([&]() -> int { HIP_TRY(c, hipStreamWaitEvent(c->stream, c->comm_events[1], 0)); return DST_OK; });
-        } else if (!S.coll(comm->all_gather(send, c->gather_buf, bytes, c->stream), "constraint evaluations")) return S.agreed;        // the import below rewrites `ceval` only after the exchange
+        } else if (!S.coll(S.timed([&] { return comm->all_gather(send, c->gather_buf, bytes, c->stream); }), "constraint evaluations")) return S.agreed;        // the import below rewrites `ceval` only after the exchange
         S.local([&] { const int r = dst_shard_import(c, SH_CEVAL, 0, c->gather_buf, 1, nullptr); c->ceval_inverted = invert_first && r == DST_OK; return r; });
         S.local([&] { return shard_combine_parts(c, part1_done ? 2 : 3); });
     }
@@ -961,7 +976,7 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
         // this rank's cosets of the layer (contiguous, coset-major) -> all cosets in the gather buffer -> natural order, then the rest
         // of the commit phase on every rank (the natural-order layer overwrites fri_e[d] only after the exchange has completed)
         uint8_t root[32];
-        if (!S.coll(comm->all_gather(c->fri_e[d], c->gather_buf, bytes, c->stream), "FRI tail")) return S.agreed;
+        if (!S.coll(S.timed([&] { return comm->all_gather(c->fri_e[d], c->gather_buf, bytes, c->stream); }), "FRI tail")) return S.agreed;
         S.local([&] { c->fri_tail_pending = true; return fri_replicated_tail(c, c->gather_buf, 1, root); });
     }
     mark(6);
@@ -986,7 +1001,7 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
     {
         struct LenRec { uint64_t len; int64_t rc; } rec{(uint64_t)mine, S.rc};
         std::vector<LenRec> all(G);
-        if (!S.coll(comm->all_gather_host(&rec, all.data(), sizeof(LenRec)), "openings")) return S.agreed;
+        if (!S.coll(S.timed([&] { return comm->all_gather_host(&rec, all.data(), sizeof(LenRec)); }), "openings")) return S.agreed;
         for (size_t g = 0; g < G; g++) {
             if (all[g].rc != DST_OK && S.agreed == DST_OK) { S.agreed = (int)all[g].rc; if (S.rc == DST_OK) c->err = "before the openings: rank " + std::to_string(g) + " reported error " + std::to_string(all[g].rc); }
             lens[g] = all[g].len;            // every rank derives the same plan, so this equals what dst_shard_open computed locally
@@ -998,7 +1013,7 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
     std::vector<uint8_t> blob(width + 8, 0), all(( width + 8) * G);
     S.local([&] { return dst_shard_open(c, positions.data(), (uint32_t)positions.size(), blob.data(), width, &mine, nullptr); });
     { const int64_t rc64 = S.rc; memcpy(blob.data() + width, &rc64, 8); }                    // the status rides behind the blob
-    if (!S.coll(comm->all_gather_host(blob.data(), all.data(), width + 8), "openings")) return S.agreed;
+    if (!S.coll(S.timed([&] { return comm->all_gather_host(blob.data(), all.data(), width + 8); }), "openings")) return S.agreed;
     for (size_t g = 0; g < G && S.agreed == DST_OK; g++) {
         int64_t rc64; memcpy(&rc64, all.data() + g * (width + 8) + width, 8);
         if (rc64 != DST_OK) { S.agreed = (int)rc64; if (S.rc == DST_OK) c->err = "openings: rank " + std::to_string(g) + " reported error " + std::to_string(rc64); }

@@ -24,7 +24,7 @@ EXPORTS = ["dst_ctx_create", "dst_ctx_destroy", "dst_last_error", "dst_phase_ms"
            "dst_read_buffer", "dst_bench_mulmod", "dst_bench_mad", "dst_bench_code", "dst_trace_upload_async", "dst_pinned_alloc", "dst_pinned_free", "dst_set_profiling", "dst_kernel_stats", "dst_field_op",
            "dst_shard_commit_trace", "dst_shard_eval_constraints", "dst_shard_combine", "dst_shard_fri_layer", "dst_shard_fri_fold",
            "dst_shard_export_size", "dst_shard_export", "dst_shard_import", "dst_shard_read", "dst_shard_fri_begin", "dst_shard_fri_end", "dst_shard_fri_roots", "dst_shard_open", "dst_shard_assemble", "dst_shard_info",
-           "dst_comm_unique_id", "dst_comm_init", "dst_comm_init_local", "dst_comm_init_callbacks", "dst_comm_destroy", "dst_comm_last_error", "dst_prove_sharded", "dst_prove_sharded_local"]
+           "dst_comm_unique_id", "dst_comm_init", "dst_comm_init_local", "dst_comm_init_callbacks", "dst_comm_destroy", "dst_comm_last_error", "dst_comm_copy", "dst_prove_sharded", "dst_prove_sharded_local", "dst_shard_stage_ms"]
 
 
 class DistaffError(RuntimeError):
@@ -201,6 +201,65 @@ class Comm:
         c._keep = cb                                                  # the trampoline must outlive the handle
         return c
 
+    @classmethod
+    def over_torch(cls, dist, group=None):
+        """dst_prove_sharded's collectives carried by an initialised torch.distributed process group through the callback transport
+        (dst_comm_init_callbacks): the host's own channel instead of the library's RCCL binding.  With a gloo group the device buffers
+        are staged through host memory (dst_comm_copy), so the ranks may be processes that SHARE one GPU -- which RCCL refuses --
+        or sit on hosts without RCCL; with an nccl group the exchange runs on device tensors.  The callbacks block until the
+        exchange is complete, as the transport's contract asks."""
+        import numpy as np
+        import torch
+        lib = load()
+        lib.dst_comm_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        on_device = str(dist.get_backend(group)).lower() == "nccl"
+
+        def copy(dst, src, nbytes):
+            if lib.dst_comm_copy(ctypes.c_void_p(dst), ctypes.c_void_p(src), ctypes.c_size_t(nbytes)) != DST_OK:
+                lib.dst_comm_last_error.restype = ctypes.c_char_p
+                raise DistaffError(DST_ERR_HIP, lib.dst_comm_last_error(None).decode())
+
+        def staged(src, nbytes):
+            """`nbytes` at address `src` as a tensor the process group can send"""
+            t = torch.empty(nbytes, dtype=torch.uint8, device="cuda" if on_device else "cpu")
+            copy(t.data_ptr(), src, nbytes)
+            return t
+
+        def fn(kind, send, recv, nbytes):
+            if nbytes == 0:
+                return 0
+            if kind == 1:                                             # all-to-all: chunk g of `send` goes to rank g
+                mine = staged(send, nbytes * world)
+                out = torch.empty_like(mine)
+                if on_device:
+                    dist.all_to_all_single(out, mine, group=group)
+                    torch.cuda.synchronize()
+                else:                                                 # gloo has no all-to-all on CPU tensors: gather and slice
+                    every = [torch.empty_like(mine) for _ in range(world)]
+                    dist.all_gather(every, mine, group=group)
+                    out = torch.cat([e[rank * nbytes:(rank + 1) * nbytes] for e in every])
+                copy(recv, out.data_ptr(), nbytes * world)
+                return 0
+            if kind == 2 and not on_device:                           # host values
+                mine = torch.from_numpy(np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(send)).copy())
+            else:
+                mine = staged(send, nbytes)                           # (an in-place all-gather hands in send == recv + rank * nbytes: staged first)
+            if on_device:
+                out = torch.empty(nbytes * world, dtype=torch.uint8, device="cuda")
+                dist.all_gather_into_tensor(out, mine, group=group)
+                torch.cuda.synchronize()
+            else:
+                every = [torch.empty_like(mine) for _ in range(world)]
+                dist.all_gather(every, mine, group=group)
+                out = torch.cat(every)
+            if kind == 2 and not on_device:
+                ctypes.memmove(recv, out.data_ptr(), nbytes * world)
+            else:
+                copy(recv, out.data_ptr(), nbytes * world)
+            return 0
+        return cls.callbacks(rank, world, fn)
+
     def close(self):
         if getattr(self, "_h", None):
             self.lib.dst_comm_destroy(self._h)
@@ -287,6 +346,12 @@ class Context:
         ln = ctypes.c_size_t(0)
         self._check(self.lib.dst_prove_sharded(self._h, comm._h, ctypes.byref(pub), buf, ctypes.c_size_t(cap), ctypes.byref(ln)))
         return buf.raw[:ln.value]
+
+    def shard_stage_ms(self):
+        """host-side view of the last prove_sharded: ms inside the transport's calls, ms waiting for tree roots, tree exchanges"""
+        v = (ctypes.c_double * 3)()
+        self._check(self.lib.dst_shard_stage_ms(self._h, v))
+        return {"transport_calls": v[0], "root_waits": v[1], "tree_exchanges": int(v[2])}
 
     def commit_trace(self):
         root = ctypes.create_string_buffer(32)
@@ -398,7 +463,7 @@ class Context:
 
     def shard_read(self, buffer, arg, indices):
         idx = np.asarray(indices, dtype=np.uint64)
-        item = self.W * 16 if buffer == 10 else (16 if buffer in (3, 6) else 32)
+        item = self.W * 16 if buffer == 10 else (16 if buffer in (3, 6, 11) else 32)
         out = np.zeros(len(indices) * item, dtype=np.uint8)
         self._check(self.lib.dst_shard_read(self._h, ctypes.c_uint32(buffer), ctypes.c_uint32(arg), _ptr(idx), ctypes.c_uint32(len(indices)), _ptr(out)))
         return out.tobytes()

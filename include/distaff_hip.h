@@ -136,7 +136,9 @@ int dst_shard_export(dst_ctx* ctx, uint32_t what, uint32_t arg, void* dst, int d
 int dst_shard_import(dst_ctx* ctx, uint32_t what, uint32_t arg, const void* src, int src_is_device, uint8_t root_out[32]);
 /* openings: `count` items by LOCAL index from buffer 0 trace leaves, 1 trace local nodes, 2 trace upper nodes, 3 constraint
  * evaluations (elements), 4 constraint local nodes, 5 constraint upper nodes, 6 FRI layer `arg` evaluations (elements), 7 FRI leaves,
- * 8 FRI local nodes, 9 FRI upper nodes, 10 LDE rows (idx = natural positions owned by this rank, W elements each). */
+ * 8 FRI local nodes, 9 FRI upper nodes, 10 LDE rows (idx = natural positions owned by this rank, W elements each), 11 transition
+ * evaluations of the last dst_eval_constraints / dst_shard_eval_constraints (elements; this rank's cosets of the 8n-point domain,
+ * coset-major: index q * n + k is the point 8k + q on one GPU).  The element buffers 3, 6 (sharded layers) and 11 are coset-major. */
 int dst_shard_read(dst_ctx* ctx, uint32_t buffer, uint32_t arg, const uint64_t* idx, uint32_t count, uint8_t* out);
 /* The FRI commit phase (fri/prover.rs:11-53): call dst_shard_fri_begin, all-gather the *bytes it wrote into `send` (same size
  * on every rank), call dst_shard_fri_end with the gathered bytes (rank-major); repeat while *more.  Large layers stay sharded:
@@ -204,8 +206,15 @@ int dst_comm_init_local(uint32_t world, dst_comm** out /* [world] */);
 typedef int (*dst_comm_fn)(void* user, int kind, const void* send, void* recv, size_t bytes);
 int dst_comm_init_callbacks(uint32_t rank, uint32_t world, dst_comm_fn fn, void* user, dst_comm** out);
 void dst_comm_destroy(dst_comm* comm);
+/* helper for callback transports that stage through their own buffers: one synchronous copy of `bytes` between host memory and memory of
+ * the calling thread's current device, in either direction or device to device (the direction follows from the pointers) */
+int dst_comm_copy(void* dst, const void* src, size_t bytes);
 const char* dst_comm_last_error(const dst_comm* comm);   /* comm may be NULL: the creation-time error */
 int dst_prove_sharded(dst_ctx* ctx, dst_comm* comm, const dst_public* pub, uint8_t* proof, size_t cap, size_t* len);
+/* host-side view of the last dst_prove_sharded on this rank: out[0] = milliseconds inside the transport's calls (enqueue time on RCCL, the
+ * whole exchange on a blocking transport), out[1] = milliseconds waiting for tree roots (the only host waits of the protocol), out[2] =
+ * number of tree exchanges */
+int dst_shard_stage_ms(const dst_ctx* ctx, double out[3]);
 int dst_prove_sharded_local(dst_ctx** ctxs, uint32_t world, const dst_public* pub, uint8_t* proof, size_t cap, size_t* len);
 
 #ifdef __cplusplus

@@ -172,6 +172,30 @@ void orc_periodic_tables(size_t ext, u128* out) {
     }
 }
 
+// The evaluator at ONE point of the constraint evaluation domain (evaluator.rs:139-162 evaluate_transition, :181-326 evaluate_boundaries,
+// as driven by prover.rs:53-64): `step` = index in the 8n-point domain, x = w_{8n}^step, cur / nxt = the LDE rows at positions
+// step * (B/8) and step * (B/8) + B.  out = [transition combination, first-step boundary combination, last-step boundary combination,
+// 1 when all transition constraints vanish (only meaningful on trace steps)].  For sampled parity at sizes the whole-domain loop of the
+// oracle cannot finish in seconds.
+int orc_evaluate_at(size_t trace_length, size_t ctx, size_t lp, size_t st, const u128* coeffs344, const u128* prog_hash2, const u128* op_count,
+                    const u128* inputs, size_t nin, const u128* outputs, size_t nout, size_t step, const u128* x,
+                    const u128* cur_row, const u128* nxt_row, u128* out4) {
+    try {
+        ConstraintCoefficients cc;
+        cc.init(vec(coeffs344, coeffs344 + 2 * NUM_CONSTRAINTS), ctx, lp, st);
+        Evaluator ev(trace_length, MAX_CONSTRAINT_DEGREE, ctx, lp, st, trace_length * MAX_CONSTRAINT_DEGREE, cc,
+                     vec(prog_hash2, prog_hash2 + PROGRAM_DIGEST_SIZE), *op_count, vec(inputs, inputs + nin), vec(outputs, outputs + nout));
+        const size_t w = 15 + ctx + lp + st;
+        TraceState c = TraceState::from_vec(ctx, lp, st, vec(cur_row, cur_row + w));
+        TraceState n = TraceState::from_vec(ctx, lp, st, vec(nxt_row, nxt_row + w));
+        bool ok = true;
+        out4[0] = ev.evaluate_transition(c, n, *x, step, &ok);
+        ev.evaluate_boundaries(c, *x, out4[1], out4[2]);
+        out4[3] = ok ? 1 : 0;
+        return 0;
+    } catch (const std::exception& e) { return fail(e); }
+}
+
 // ---- prover object ------------------------------------------------------------------------------------------------------
 struct ProverHandle { Prover* p; StarkProof proof; std::vector<uint8_t> proof_bytes; bool has_proof = false; };
 

@@ -330,6 +330,21 @@ def constraint_piece(which, ctx, lp, st, cur_row, nxt_row, consts=(), flag=1):
     return to_ints(out[:k])
 
 
+def evaluate_at(trace_length, ctx, lp, st, coeffs344, program_hash2, op_count, inputs, outputs, step, x, cur_row, nxt_row):
+    """The evaluator at one point of the 8n-point constraint evaluation domain (evaluator.rs:139-162, 181-326): returns
+    (transition combination, first-step boundary combination, last-step boundary combination, constraints_vanish)."""
+    out = np.zeros((4, 2), dtype=np.uint64)
+    i = to_arr(list(inputs)) if len(inputs) else np.zeros((1, 2), dtype=np.uint64)
+    o = to_arr(list(outputs)) if len(outputs) else np.zeros((1, 2), dtype=np.uint64)
+    r = lib().orc_evaluate_at(ctypes.c_size_t(trace_length), ctypes.c_size_t(ctx), ctypes.c_size_t(lp), ctypes.c_size_t(st), _p(_c(coeffs344)),
+                              _p(to_arr(list(program_hash2))), _p(_el(op_count)), _p(i), ctypes.c_size_t(len(inputs)), _p(o), ctypes.c_size_t(len(outputs)),
+                              ctypes.c_size_t(step), _p(_el(x)), _p(to_arr(list(cur_row))), _p(to_arr(list(nxt_row))), _p(out))
+    if r != 0:
+        raise RuntimeError(last_error())
+    v = to_ints(out)
+    return v[0], v[1], v[2], bool(v[3])
+
+
 def periodic_tables(ext):
     out = np.zeros((16 * ext, 23, 2), dtype=np.uint64)
     lib().orc_periodic_tables(ctypes.c_size_t(ext), _p(out))

@@ -12,6 +12,7 @@ import torch
 import torch.distributed as dist
 
 torch.cuda.is_available = lambda: True
+torch.cuda.device_count = lambda: 0
 torch.cuda.set_device = lambda d: None
 torch.cuda.synchronize = lambda *a, **k: None
 
@@ -42,32 +43,9 @@ D.Context.bench_mulmod = lambda self, lanes, iters: 1.0          # the ALU calib
 D.Context.bench_mad = lambda self, lanes, iters: 1.0
 
 
-def _gloo_comm(unique_id, rank, world, device):
-    """stands in for the RCCL communicator of dst_prove_sharded: the library's collectives through the callback transport, carried by
-    gloo on the host pointers of the emulated build"""
-    import ctypes
-    import numpy as np
-
-    def view(addr, nbytes):
-        return np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(addr))
-
-    def fn(kind, send, recv, nbytes):
-        if kind == 1:                                                # all-to-all: gloo has none on CPU tensors, gather and slice
-            mine = torch.from_numpy(view(send, nbytes * world).copy())
-            out = [torch.empty(nbytes * world, dtype=torch.uint8) for _ in range(world)]
-            dist.all_gather(out, mine)
-            view(recv, nbytes * world)[:] = np.concatenate([o.numpy()[rank * nbytes:(rank + 1) * nbytes] for o in out])
-        else:
-            mine = torch.from_numpy(view(send, nbytes).copy())
-            out = [torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
-            dist.all_gather(out, mine)
-            view(recv, nbytes * world)[:] = np.concatenate([o.numpy() for o in out])
-        return 0
-    return D.Comm.callbacks(rank, world, fn)
-
-
-D.Comm.unique_id = staticmethod(lambda: bytes(128))
-D.Comm.rccl = staticmethod(_gloo_comm)
+# bench.py finds no device here (torch.cuda.device_count() == 0 counts as one), so with N > 1 ranks it takes its "ranks share a device"
+# route by itself: a gloo group and the library's collectives through the callback transport (distaff_amd.Comm.over_torch) -- the same
+# code a one-GPU box runs with N processes; dst_comm_copy of the emulated build is a memcpy.
 _comm_init = sharded.TorchComm.__init__
 
 

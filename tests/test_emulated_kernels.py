@@ -39,6 +39,14 @@ SELECTION = [
     "test_prove_sharded_behind_the_c_abi[4-10-9-True]",
     "test_prove_sharded_reports_an_invalid_trace_on_every_rank",
     "test_prove_sharded_rank_without_a_trace_on_fresh_contexts",
+    "test_prove_sharded_in_separate_processes_sharing_the_gpu[2-12]",
+    "test_prove_sharded_in_separate_processes_sharing_the_gpu[8-12]",
+    "test_bench_with_n_processes_on_one_device[2]",
+    "test_bench_with_n_processes_on_one_device[8]",
+    "test_bench_prints_an_error_line_instead_of_hanging",
+    "test_bench_config2_line",
+    "test_sampled_oracle_parity_small[7-5]",
+    "test_sampled_oracle_parity_small[10-4]",
     "test_deep_stacks_and_nested_blocks[]",
     "test_deep_stacks_and_nested_blocks[generic]",
     "test_general_constraint_instances_on_the_fibonacci_trace[small]",
@@ -66,7 +74,8 @@ def emulated_library():
 
 
 def _run(emulated_library, args, timeout=900):
-    env = dict(os.environ, DISTAFF_HIP_LIB=emulated_library, DISTAFF_HIP_RUNTIME="none")
+    env = dict(os.environ, DISTAFF_HIP_LIB=emulated_library, DISTAFF_HIP_RUNTIME="none", DISTAFF_EMU_THREADS="2",
+               DISTAFF_BENCH_ENTRY=os.path.join(EMU_DIR, "bench_harness.py"))           # the tests that launch bench.py go through the CPU stand-ins
     return subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", "-m", "gpu"] + args,
                           cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
 
@@ -135,7 +144,7 @@ def test_tensor_hand_off_path_over_gloo(emulated_library, tmp_path, world, repli
     assert all("ok" in o for o in outs)
 
 
-@pytest.mark.parametrize("ranks,orch", [(1, "c"), (2, "c"), (2, "python")])
+@pytest.mark.parametrize("ranks,orch", [(1, "c"), (2, "python")])      # (N, "c") for N = 2, 8: test_bench_with_n_processes_on_one_device in the selection above
 def test_bench_control_flow_on_cpu_stand_ins(emulated_library, ranks, orch):
     """bench.py's own main() launched exactly as the driver launches it for N > 1 (`python -m torch.distributed.run ...`), with gloo,
     CPU tensors and the emulated build standing in for RCCL, device tensors and the GPU (tests/emu/bench_harness.py): one JSON line
@@ -145,7 +154,8 @@ def test_bench_control_flow_on_cpu_stand_ins(emulated_library, ranks, orch):
     import json
     import socket
     sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
-    env = dict(os.environ, DISTAFF_HIP_LIB=emulated_library, DISTAFF_HIP_RUNTIME="none", DISTAFF_EMU_THREADS="2", DISTAFF_SHARD_ORCH=orch)
+    env = dict(os.environ, DISTAFF_HIP_LIB=emulated_library, DISTAFF_HIP_RUNTIME="none", DISTAFF_EMU_THREADS="2", DISTAFF_SHARD_ORCH=orch,
+               DISTAFF_SHARD_HANDOFF="device")       # CPU tensors and the emulated build's host pointers: the tensor hand-off bench.py uses with device tensors on GPUs
     harness = os.path.join(EMU_DIR, "bench_harness.py")
     args = ["--gpus", str(ranks), "--steps", "1", "--warmup", "1", "--log-n", "8", "--cpu-log-n", "7"]
     if ranks == 1:

@@ -529,7 +529,11 @@ def _fib(log_n):
     if log_n not in _FIB_CACHE:
         if log_n >= 22:
             _FIB_CACHE.clear()                                        # 1.3 GiB at 2^22: keep one
-        _FIB_CACHE[log_n] = D.fibonacci_trace(log_n)
+        import os
+        import sys
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        _FIB_CACHE[log_n] = bench.fibonacci_trace_cached(D, log_n)     # BENCH_TRACE_CACHE=<dir>: shared with bench.py runs on the same box
     return _FIB_CACHE[log_n]
 
 
@@ -541,6 +545,129 @@ def _accepts_and_rejects(O, proof, program_hash, result):
     bad = bytearray(proof); bad[len(proof) // 2] ^= 1
     ok, err = O.verify(bytes(bad), program_hash, [1, 0], [result])
     assert not ok
+
+
+def _sampled_parity(O, D, log_n, log_blowup=5, num_queries=50, points=32, horner_rows=32, deep_registers=20, seed=1):
+    """Oracle POINT computations against intermediates of a full-size proof (sizes at which the oracle's whole-domain loops take hours):
+      * trace polynomials: Horner at trace-domain points = the trace (interpolation), at LDE points = sampled LDE rows (trace_table.rs:143-169);
+      * the reference evaluator on sampled row pairs of the 8n-point domain = the transition combination the constraint kernels
+        wrote (evaluator.rs:139-162), incl. trace steps (must vanish) and the excepted last step;
+      * the constraint polynomial at those points, rebuilt from the oracle's boundary / transition values and the divisors of
+        combine_polys (constraint_table.rs:54-88), = the constraint LDE;
+      * DEEP values = Horner at z and z*g; the composition (trace_table.rs:206-261, constraint_poly.rs:39-52) at sampled LDE points,
+        rebuilt with Python integers from those rows, = the composition LDE;
+      * every FRI layer: sampled rows hashed by the oracle's BLAKE3 = the leaf, folded by the oracle's quartic interpolation /
+        evaluation at x = prng(root) (fri/prover.rs:25-49, quartic.rs:20-60) = the entry of the next layer.
+    Challenges are the library's own Fiat-Shamir draws (pinned against the oracle's PRNG in test_host_logic)."""
+    P = O.P
+    cols, program_hash, result = _fib(log_n)
+    n, B, W = 1 << log_n, 1 << log_blowup, 20
+    N = n * B
+    rng = np.random.default_rng(seed)
+    ctx = D.Context(log_n, W, 1, 0, log_blowup=log_blowup, num_queries=num_queries)
+    ctx.upload(cols)
+    ints = lambda a: [int(lo) | (int(hi) << 64) for lo, hi in np.asarray(a, dtype=np.uint64).reshape(-1, 2)]      # noqa: E731
+    elems = lambda b: ints(np.frombuffer(b, dtype=np.uint64))                                                     # noqa: E731
+    cm = lambda pos: (pos % B) * n + pos // B            # natural LDE position -> coset-major index                 # noqa: E731
+    g_n, g_N, g_8n = O.root_of_unity(n), O.root_of_unity(N), O.root_of_unity(8 * n)
+
+    # ---- steps 1-2
+    root = ctx.commit_trace()
+    polys = ctx.read_elements("polys").reshape(W, n, 2)
+    for c, k in ((0, 0), (4, 1), (19, n - 1), (int(rng.integers(W)), int(rng.integers(n)))):
+        assert O.poly_eval(polys[c], O.exp(g_n, k)) == ints(cols[c, k])[0], ("interpolation", c, k)
+    steps = [0, 8, 3, 8 * n - 8, 8 * n - 1, 8 * n - 5, 8 * 17 + 5] + [int(v) for v in rng.integers(0, 8 * n, size=max(points - 7, 0))]
+    steps = steps[:max(points, 7)]
+    pos = [s_ * (B // 8) for s_ in steps]
+    rows_cur = np.frombuffer(ctx.shard_read(10, 0, pos), dtype=np.uint64).reshape(len(pos), W, 2)
+    rows_nxt = np.frombuffer(ctx.shard_read(10, 0, [(p_ + B) % N for p_ in pos]), dtype=np.uint64).reshape(len(pos), W, 2)
+    checked = 0
+    for i in range(len(pos)):                                          # Horner over n coefficients per (row, register)
+        for rows, p_ in ((rows_cur, pos[i]), (rows_nxt, (pos[i] + B) % N)):
+            if checked >= horner_rows:
+                break
+            x = O.exp(g_N, p_)
+            for c in range(W):
+                assert O.poly_eval(polys[c], x) == ints(rows[i, c])[0], ("LDE row", p_, c)
+            checked += 1
+
+    # ---- steps 3-5
+    coeffs = D.prng_vector(root, 344)
+    croot = ctx.eval_constraints([1, 0], [result], coeffs)
+    tv = elems(ctx.shard_read(11, 0, [(s_ % 8) * n + s_ // 8 for s_ in steps]))
+    cv = elems(ctx.shard_read(3, 0, [cm(p_) for p_ in pos]))
+    op_count, ph = ints(cols[0, n - 1])[0], [ints(cols[1, n - 1])[0], ints(cols[2, n - 1])[0]]
+    x_last = pow(g_n, n - 1, P)
+    for i, s_ in enumerate(steps):
+        x = O.exp(g_8n, s_)
+        t, bi, bf, ok = O.evaluate_at(n, 1, 0, 4, coeffs, ph, op_count, [1, 0], [result], s_, x, ints(rows_cur[i]), ints(rows_nxt[i]))
+        assert ok and t == tv[i], ("transition combination", s_)
+        if s_ % 8:                                                     # off the trace domain the divisors are invertible
+            c_x = (bi * pow(x - 1, -1, P) + bf * pow(x - x_last, -1, P) + t * (x - x_last) % P * pow(pow(x, n, P) - 1, -1, P)) % P
+            assert c_x == cv[i], ("constraint polynomial", s_)
+    cpoly = ctx.read_elements("cpoly")
+    for i in (1, 2):
+        assert O.poly_eval(cpoly, O.exp(g_N, pos[i])) == cv[i], ("constraint LDE", pos[i])
+
+    # ---- step 6
+    draws = D.prng_vector(croot, 516)
+    z1, z2 = ctx.compose(draws)
+    dr = ints(draws)
+    z, k1, k2, k3 = dr[0], dr[513], dr[514], dr[515]
+    zg = z * g_n % P
+    z1i, z2i = ints(z1), ints(z2)
+    for c in list(range(W))[:deep_registers]:
+        assert O.poly_eval(polys[c], z) == z1i[c] and O.poly_eval(polys[c], zg) == z2i[c], ("DEEP value", c)
+    c_z = O.poly_eval(cpoly, z)
+    comp = elems(ctx.shard_read(6, 0, [cm(p_) for p_ in pos]))
+    inc = 6 * n + 1                                                    # utils/mod.rs:20 get_incremental_trace_degree
+    for i, p_ in enumerate(pos):
+        x = pow(g_N, p_, P)
+        row = ints(rows_cur[i])
+        a = sum(dr[1 + c] * (row[c] - z1i[c]) for c in range(W)) % P
+        b = sum(dr[257 + c] * (row[c] - z2i[c]) for c in range(W)) % P
+        t1 = (a * pow(x - z, -1, P) + b * pow(x - zg, -1, P)) % P
+        want = (t1 * (k1 + k2 * pow(x, inc, P)) + k3 * (cv[i] - c_z) % P * pow(x - z, -1, P)) % P
+        assert want == comp[i], ("composition", p_)
+    del polys, cpoly
+
+    # ---- step 7
+    d, size = 0, N
+    while True:
+        lroot, more = ctx.fri_commit_layer()
+        R = size // 4
+        rs = [0, 1, R - 1] + [int(v) for v in rng.integers(0, R, size=5)]
+        idx = [r_ + q * R for r_ in rs for q in range(4)]
+        vals = elems(ctx.shard_read(6, d, [cm(v) for v in idx] if d == 0 else idx))
+        leaves = ctx.shard_read(7, d, rs)
+        for j, r_ in enumerate(rs):
+            row4 = vals[4 * j:4 * j + 4]
+            assert O.blake3(b"".join(v.to_bytes(16, "little") for v in row4)) == leaves[32 * j:32 * j + 32], ("FRI leaf", d, r_)
+        if not more:
+            break
+        x = ints(D.prng_vector(lroot, 1))[0]
+        ctx.fri_fold(x)
+        nxt = elems(ctx.shard_read(6, d + 1, rs))
+        for j, r_ in enumerate(rs):
+            xs = [pow(g_N, (4 ** d) * (r_ + q * R), P) for q in range(4)]
+            poly = O.quartic_interpolate_batch(O.to_arr([xs]), O.to_arr([vals[4 * j:4 * j + 4]]))
+            assert O.to_ints(O.quartic_evaluate_batch(poly, x))[0] == nxt[j], ("FRI fold", d, r_)
+        d, size = d + 1, R
+    ctx.close()
+
+
+@pytest.mark.parametrize("log_n,log_blowup", [(7, 5), (10, 4)])
+def test_sampled_oracle_parity_small(oracle, log_n, log_blowup):
+    """the sampled checks of the full-size tests at sizes where every intermediate is ALSO compared in full (test_fibonacci_all_phases):
+    pins the sampling arithmetic itself, and runs on the CPU-emulated build"""
+    import distaff_amd as D
+    _sampled_parity(oracle, D, log_n, log_blowup=log_blowup, points=24, horner_rows=48)
+
+
+def test_config3_sampled_oracle_parity_at_full_size(oracle):
+    """BASELINE config 3 (2^20 steps, default options): 32 sampled points of every phase against oracle point computations."""
+    import distaff_amd as D
+    _sampled_parity(oracle, D, 20, points=32, horner_rows=32)
 
 
 def test_config4_trace_full_size_on_one_gpu(oracle):
@@ -555,18 +682,32 @@ def test_config4_trace_full_size_on_one_gpu(oracle):
     _accepts_and_rejects(oracle, proof, program_hash, result)
 
 
+def test_config4_sampled_oracle_parity_at_full_size(oracle):
+    """BASELINE config 4's trace (2^22 steps, three-pass transforms): sampled points of every phase against oracle point computations
+    (32 evaluator points; 8 LDE rows and 8 DEEP registers by Horner -- 4 M coefficients each)."""
+    import distaff_amd as D
+    _sampled_parity(oracle, D, 22, points=32, horner_rows=8, deep_registers=8, seed=2)
+
+
 def test_config5_full_size_on_one_gpu(oracle):
     """BASELINE config 5 (2^24 steps, blowup 16, 100 queries = 120-bit security) on ONE GPU (~190 GiB of the 288): the proof is accepted
     by the oracle's restatement of the reference verifier and rejected after tampering.  Most of the test's time is the host-side VM
     that generates the 2^24-step trace."""
     import distaff_amd as D
-    cols, program_hash, result = D.fibonacci_trace(24)
+    cols, program_hash, result = _fib(24)                               # kept for the sampled test below (the VM takes minutes at 2^24)
     ctx = D.Context(24, 20, 1, 0, log_blowup=4, num_queries=100, grinding=20)
     ctx.upload(cols)
     del cols
     proof = ctx.prove([1, 0], [result], cap=1 << 24)
     ctx.close()
     _accepts_and_rejects(oracle, proof, program_hash, result)
+
+
+def test_config5_sampled_oracle_parity_at_full_size(oracle):
+    """BASELINE config 5 (2^24 steps, blowup 16, 100 queries): sampled points of every phase against oracle point computations
+    (32 evaluator points; 2 LDE rows and 4 DEEP registers by Horner -- 16 M coefficients each)."""
+    import distaff_amd as D
+    _sampled_parity(oracle, D, 24, log_blowup=4, num_queries=100, points=32, horner_rows=2, deep_registers=4, seed=3)
 
 
 def _sharded_local_equals_single_context(log_n, world, **options):
@@ -886,6 +1027,133 @@ def test_sharded_prover_two_processes_over_gloo(tmp_path):
     ctx.close()
     for r in range(2):
         assert (tmp_path / ("proof_%d.bin" % r)).read_bytes() == expected
+
+
+_CALLBACK_WORKER = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch.distributed as dist
+import distaff_amd as D
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+log_n = int(sys.argv[1])
+cols, program_hash, result = D.fibonacci_trace(log_n)
+ctx = D.Context(log_n, 20, 1, 0, device=0, rank=rank, world=world)       # every rank on GPU 0
+if rank %% 2:
+    ctx.upload(cols)
+else:
+    ctx.upload_owned(cols)                                                  # only the registers this rank interpolates
+comm = D.Comm.over_torch(dist)                                              # dst_comm_init_callbacks, gloo carrying the library's collectives
+for k in range(2):                                                          # twice: buffers of the first proof are reused
+    proof = ctx.prove_sharded(comm, [1, 0], [result])
+    open(os.path.join(sys.argv[2], "proof_%%d_%%d.bin" %% (rank, k)), "wb").write(proof)
+stages = ctx.shard_stage_ms()
+assert stages["tree_exchanges"] >= 2 and stages["transport_calls"] > 0
+ctx.close(); comm.close()
+dist.barrier()
+dist.destroy_process_group()
+print("ok")
+"""
+
+
+@pytest.mark.parametrize("world,log_n", [(2, 12), (4, 12), (2, 16), (4, 16), (8, 12)])
+def test_prove_sharded_in_separate_processes_sharing_the_gpu(tmp_path, world, log_n):
+    """`world` OS processes, each with its own HIP runtime, context and communicator handle, all on GPU 0, each calling
+    dst_prove_sharded: the library's own orchestration (column-split interpolation, k-range tree exchange, status records) with its
+    all-gathers / all-to-alls on DEVICE buffers carried between the processes by gloo through the callback transport
+    (dst_comm_init_callbacks + dst_comm_copy).  RCCL refuses several ranks on one device, so this is the closest a one-GPU box gets to
+    the driver's N-process run; every rank must write the single-context proof, twice."""
+    import os
+    import socket
+    import subprocess
+    import sys
+    import distaff_amd as D
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    script = tmp_path / "worker.py"
+    script.write_text(_CALLBACK_WORKER % root)
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), str(log_n), str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=600)[0].decode() for p in procs]
+    assert all(p.returncode == 0 for p in procs), outs
+    cols, program_hash, result = D.fibonacci_trace(log_n)
+    ctx = D.Context(log_n, 20, 1, 0)
+    ctx.upload(cols)
+    expected = ctx.prove([1, 0], [result])
+    ctx.close()
+    for r in range(world):
+        for k in range(2):
+            assert (tmp_path / ("proof_%d_%d.bin" % (r, k))).read_bytes() == expected, (r, k)
+
+
+@pytest.mark.parametrize("ranks", [2, 8])
+def test_bench_with_n_processes_on_one_device(ranks):
+    """bench.py launched exactly as the driver launches it for N > 1 (`python -m torch.distributed.run ...`) on a box with ONE GPU: the
+    ranks share the device, the collectives of dst_prove_sharded travel through the callback transport over gloo, and rank 0 prints one
+    well-formed line that says so (a functional run of the N-process path, not a scaling measurement)."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    harness = os.environ.get("DISTAFF_BENCH_ENTRY", os.path.join(root, "bench.py"))      # the CPU run of this test goes through tests/emu/bench_harness.py
+    env = dict(os.environ, BENCH_LOG_N="12", BENCH_CPU_LOG_N="8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), harness, "--gpus", str(ranks), "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout.decode()[-2000:]
+    d = json.loads(lines[0])
+    assert "error" not in d, d
+    assert d["n_gpus"] == ranks and d["steps"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["proof_verified"]
+    assert d["devices"]["shared"] and d["devices"]["ranks"] == ranks and "callback transport" in d["config"]["parallelism"]
+    assert set(d["phase_ms"]) >= {"lde", "trace_merkle", "constraint_eval", "fri", "openings"} and all(v >= 0 for v in d["phase_ms"].values())
+    st = d["shard_stage_ms_rank0"]
+    assert st and st["transport_calls"] > 0 and st["tree_exchanges"] >= 2
+    assert abs(d["value"] - d["config"]["trace_steps"] * 20 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+
+
+def test_bench_prints_an_error_line_instead_of_hanging():
+    """a run that cannot proceed (here: a size the library refuses) ends with ONE JSON line carrying `error` and the stage, and a
+    non-zero exit code; a stalled run is ended the same way by the watchdog (BENCH_TIMEOUT_S)"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    entry = os.environ.get("DISTAFF_BENCH_ENTRY", os.path.join(root, "bench.py"))
+    r = subprocess.run([sys.executable, entry, "--gpus", "1", "--steps", "1", "--warmup", "0", "--log-n", "7", "--log-blowup", "9", "--no-cpu-baseline"],
+                       cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert r.returncode != 0 and len(lines) == 1, (r.returncode, r.stdout.decode()[-1000:], r.stderr.decode()[-1000:])
+    d = json.loads(lines[0])
+    assert d["value"] is None and "extension factor" in d["error"] and d["stage"] == "context"
+    env = dict(os.environ, BENCH_TIMEOUT_S="1", BENCH_LOG_N="12")
+    r = subprocess.run([sys.executable, entry, "--gpus", "1", "--steps", "2000", "--warmup", "0", "--no-cpu-baseline"], cwd=root, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    lines = [ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")]
+    assert r.returncode == 3 and len(lines) == 1 and "no progress" in json.loads(lines[0])["error"], (r.returncode, r.stdout.decode()[-1000:])
+
+
+def test_bench_config2_line(tmp_path):
+    """`bench.py --workload commit`: BASELINE config 2 (LDE + Merkle commit only on random columns) as a bench line of its own, the
+    trace root checked against the oracle's on the same columns in the CPU leg"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    entry = os.environ.get("DISTAFF_BENCH_ENTRY", os.path.join(root, "bench.py"))
+    r = subprocess.run([sys.executable, entry, "--workload", "commit", "--log-n", "10", "--steps", "2", "--warmup", "1"], cwd=root, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert "config 2" in d["config"]["workload"] and set(d["phase_ms"]) == {"lde", "trace_merkle"} and d["cpu_baseline"]["root_hex"] == d["trace_root_hex"]
+    assert d["roofline"]["bound"] == "hbm" and "commit" in d["phase_hbm"] and d["cpu_baseline"]["reference_published"]
 
 
 @pytest.mark.parametrize("instance", ["small", "deep", "generic"])
