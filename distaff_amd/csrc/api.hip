@@ -99,6 +99,8 @@ static void free_all(dst_ctx* c) {
     for (hipEvent_t e : c->comm_events) hipEventDestroy(e);
     if (c->comm_stream) hipStreamDestroy(c->comm_stream);
     if (c->d_status) hipFree(c->d_status);
+    if (c->h_stage) hipHostFree(c->h_stage);
+    for (hipEvent_t e : c->ph_ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
 }
 
@@ -122,6 +124,8 @@ static int ctx_init(dst_ctx* c) {
     c->device = p.device;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamCreate(&c->stream));
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_stage, 65536, hipHostMallocDefault));
+    for (hipEvent_t& e : c->ph_ev) HIP_TRY(c, hipEventCreate(&e));
 
     // NTT plan: n = n1 * n2 in two HBM passes, tiles bounded by 64 KiB of LDS; from n = 2^21 (measured cross-over) three passes n = n1 * nm * n3 with
     // 16-column tiles (256-byte HBM segments) instead of 4096-point tiles that hold one or two columns
@@ -359,6 +363,7 @@ int dst_commit_trace(dst_ctx* c, uint8_t trace_root[32]) {
     HIP_TRY(c, hipSetDevice(c->device));
     c->sharded_layout = false;
     double t0 = wall_ms();
+    HIP_TRY(c, hipEventRecord(c->ph_ev[4], c->stream));
     if (c->upload_pending) {
         // registers arrive in groups (dst_trace_upload_async): each group is interpolated and extended as soon as its copy has landed
         for (size_t g = 0; g + 1 < c->upload_bounds.size(); g++) {
@@ -372,8 +377,7 @@ int dst_commit_trace(dst_ctx* c, uint8_t trace_root[32]) {
         k_intt_columns(c, c->trace, c->trace_stride, c->polys, c->W);   // interpolate_fft_twiddles (trace_table.rs:159)
         k_lde_columns(c, c->polys, c->lde, c->W);                    // eval_fft_twiddles over the LDE domain (trace_table.rs:166)
     }
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    double t1 = wall_ms();
+    HIP_TRY(c, hipEventRecord(c->ph_ev[5], c->stream));         // end of the extension: the host does not wait here
     k_trace_leaves(c);                                           // trace_table.rs:174-185
     k_merkle_levels(c, c->trace_leaves, c->trace_nodes, c->Bc * c->n);
     HIP_TRY(c, hipMemcpyAsync(c->trace_root, c->trace_nodes + 1, 32, hipMemcpyDeviceToHost, c->stream));
@@ -385,7 +389,13 @@ int dst_commit_trace(dst_ctx* c, uint8_t trace_root[32]) {
     c->op_count = (uint64_t)fe_to_u128(last[0]);
     c->program_hash[0] = last[1]; c->program_hash[1] = last[2];
     memcpy(trace_root, c->trace_root, 32);
-    c->phase_ms[0] = t1 - t0; c->phase_ms[1] = wall_ms() - t1;
+    {
+        // extension = what the stream spent up to the event; the rest of the call's wall time is the tree (and the host's share)
+        float lde_ms = 0;
+        const double total = wall_ms() - t0;
+        if (hipEventElapsedTime(&lde_ms, c->ph_ev[4], c->ph_ev[5]) != hipSuccess || lde_ms > total) lde_ms = 0;
+        c->phase_ms[0] = lde_ms; c->phase_ms[1] = total - lde_ms;
+    }
     c->committed = true; c->constraints_done = c->composed = false;
     return DST_OK;
 }
@@ -419,7 +429,7 @@ void dst_internal_transition_coefficients(const dst_ctx* c, const fe* draws344, 
 // evaluated and nothing is interpolated: ip / fp (8n coefficients each, before the divisions) are written directly.
 // DISTAFF_BOUNDARY=eval keeps the evaluate-and-interpolate route (the tests compare its evaluation vectors with the oracle's).
 bool dst_internal_boundary_by_evaluation() { const char* e = getenv("DISTAFF_BOUNDARY"); return e && !strcmp(e, "eval"); }
-int dst_internal_boundary_polys(dst_ctx* c, const fe* draws344, fe* ip, fe* fp) {
+int dst_internal_boundary_polys(dst_ctx* c, const fe* draws344, fe* ip, fe* fp, fe* o0, fe* o1, fe* o2, fe* o3) {
     const size_t n = c->n, D = 8 * n, W = c->W, p = 6 * n + 2;
     const uint32_t ctx_depth = c->prm.ctx_depth, loop_depth = c->prm.loop_depth;
     const size_t sd = c->stack_depth;
@@ -455,14 +465,48 @@ int dst_internal_boundary_polys(dst_ctx* c, const fe* draws344, fe* ip, fe* fp) 
     for (size_t i = 0; i < 4 * W; i++) up[i] = fe_from_u128(w[i]);
     for (int i = 0; i < 4; i++) up[4 * W + i] = fe_from_u128(g[i]);
     fe* d_w = (fe*)c->d_stage;                           // staging area is free until the openings
-    HIP_TRY(c, hipMemcpyAsync(d_w, up.data(), up.size() * sizeof(fe), hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemsetAsync(ip, 0, D * sizeof(fe), c->stream));
-    HIP_TRY(c, hipMemsetAsync(fp, 0, D * sizeof(fe), c->stream));
-    fe* outs[4] = {ip, ip + p, fp, fp + p};               // [pass][adj]
+    // through the page-locked staging area: the copy is queued and the host moves on (the weights fit: 4 W + 4 elements < 64 KiB / 2)
+    fe* h_w = reinterpret_cast<fe*>(c->h_stage);
+    memcpy(h_w, up.data(), up.size() * sizeof(fe));
+    HIP_TRY(c, hipMemcpyAsync(d_w, h_w, up.size() * sizeof(fe), hipMemcpyHostToDevice, c->stream));
+    fe* outs[4] = {o0, o1, o2, o3};                       // [pass][adj]
+    if (ip) {                                            // the 8n-coefficient polynomials themselves (DISTAFF_COMBINE=steps)
+        HIP_TRY(c, hipMemsetAsync(ip, 0, D * sizeof(fe), c->stream));
+        HIP_TRY(c, hipMemsetAsync(fp, 0, D * sizeof(fe), c->stream));
+        outs[0] = ip; outs[1] = ip + p; outs[2] = fp; outs[3] = fp + p;
+    }
     k_lincomb4(c, c->polys, W, n, d_w, outs[0], outs[1], outs[2], outs[3]);
     for (int q = 0; q < 4; q++) k_sub_at0(c, outs[q], d_w + 4 * W + q);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));         // `up` leaves scope
     return DST_OK;
+}
+
+// DISTAFF_COMBINE=steps: combine_polys and the DEEP composition as the reference's sequence of whole-array steps (boundary polynomials of
+// 8n coefficients, their divisions, additions; copy / division / multiply-adds of the composition) instead of the fused passes.  Tests
+// run both; the boundary-by-evaluation route implies it.
+bool dst_internal_combine_by_steps() { const char* e = getenv("DISTAFF_COMBINE"); return (e && !strcmp(e, "steps")) || dst_internal_boundary_by_evaluation(); }
+
+// What the fused combination (k_combine_fused) reads of the two boundary constraints: I = A + x^p A', F = C + x^p C' (see
+// dst_internal_boundary_polys), p = 6n + 2, each of A, A', C, C' a linear combination of the trace polynomials with n coefficients.  Written
+// behind a leading zero and divided in place -- A, A' by (x - 1), C, C' by (x - x_last) -- so that q4[k][0] is the sum / the value at
+// x_last and q4[k][1 + i] the quotient coefficient i.  Four divisions over n + 1 coefficients instead of two over 8n.
+int dst_internal_boundary_quotients(dst_ctx* c, const fe* draws344, fe* q4, size_t stride) {
+    const size_t n = c->n;
+    HIP_TRY(c, hipMemsetAsync(q4, 0, 4 * stride * sizeof(fe), c->stream));
+    // ip = q4[0] (A at offset 0) ... dst_internal_boundary_polys writes A, A', C, C' at (ip, ip + p, fp, fp + p): hand it views whose
+    // "+ p" lands on the next array
+    int r = dst_internal_boundary_polys(c, draws344, nullptr, nullptr, q4 + 1, q4 + stride + 1, q4 + 2 * stride + 1, q4 + 3 * stride + 1);
+    if (r) return r;
+    k_syn_div(c, q4, n + 1, fe_one());
+    k_syn_div(c, q4 + stride, n + 1, fe_one());
+    k_syn_div(c, q4 + 2 * stride, n + 1, c->x_last);
+    k_syn_div(c, q4 + 3 * stride, n + 1, c->x_last);
+    return DST_OK;
+}
+
+// milliseconds between two phase-boundary events of the last proof (recorded on the stream: no host wait at the boundary itself)
+static double event_ms(dst_ctx* c, int from, int to) {
+    float ms = 0;
+    return hipEventElapsedTime(&ms, c->ph_ev[from], c->ph_ev[to]) == hipSuccess ? (double)ms : 0.0;
 }
 
 int dst_eval_constraints(dst_ctx* c, const dst_public* pub, const uint8_t* coeffs, uint8_t constraint_root[32], int64_t* bad_step) {
@@ -472,50 +516,84 @@ int dst_eval_constraints(dst_ctx* c, const dst_public* pub, const uint8_t* coeff
     if (c->prm.world != 1) { c->err = "dst_eval_constraints: multi-GPU combination is driven by the host (see distaff_amd/sharded.py)"; return DST_ERR_ARG; }
     HIP_TRY(c, hipSetDevice(c->device));
     c->pub = *pub;
-    double t0 = wall_ms();
+    const double t0 = wall_ms();
+    HIP_TRY(c, hipEventRecord(c->ph_ev[0], c->stream));
     std::vector<fe> draws = copy_fe(coeffs, 344), tc;
     dst_internal_transition_coefficients(c, draws.data(), tc);
     fe* d_coef = c->scratch + c->scratch_elems - 1024;           // tail of the scratch area
     fe* d_tc = d_coef + 344;
     HIP_TRY(c, hipMemcpyAsync(d_coef, draws.data(), 344 * 16, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(d_tc, tc.data(), tc.size() * 16, hipMemcpyHostToDevice, c->stream));
-    int r = k_eval_constraints(c, d_coef, d_tc, bad_step);        // prover.rs:53-64
+    // The host does not wait for the evaluation's verdict (evaluator.rs:152-158) before it queues the combination: the flag travels back
+    // with the constraint root, and a trace that fails is reported then (the work queued behind it is wasted only in that case).
+    const bool steps = dst_internal_combine_by_steps();
+    int r = k_eval_constraints(c, d_coef, d_tc, bad_step, /*defer_check=*/!steps);   // prover.rs:53-64
     if (r == DST_ERR_AIR) { c->err = "transition constraints were not satisfied"; return r; }
     if (r != DST_OK) return r;
-    double t1 = wall_ms();
+    HIP_TRY(c, hipEventRecord(c->ph_ev[1], c->stream));
     // combine_polys (constraint_table.rs:54-88)
     const size_t n = c->n, D = 8 * n;
-    fe* ip = c->cwork; fe* fp = c->cwork + D; fe* tp = c->cwork + 2 * D; fe* work = c->cwork + 3 * D;
-    if (dst_internal_boundary_by_evaluation()) {
-        k_intt8_cosets(c, c->ceval, ip, work);
-        k_intt8_cosets(c, c->ceval + D, fp, work);
-    } else if ((r = dst_internal_boundary_polys(c, draws.data(), ip, fp))) return r;
-    k_syn_div(c, ip, D, fe_one());
-    k_syn_div(c, fp, D, c->x_last);
-    k_intt8_cosets(c, c->ceval + 2 * D, tp, work);
-    k_syn_div_expanded(c, tp, c->cpoly, D, n, c->x_last);
-    k_add(c, c->cpoly, ip, D);
-    k_add(c, c->cpoly, fp, D);
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    double t2 = wall_ms();
+    fe* work = c->cwork + 3 * D;
+    if (steps) {
+        fe* ip = c->cwork; fe* fp = c->cwork + D; fe* tp = c->cwork + 2 * D;
+        if (dst_internal_boundary_by_evaluation()) {
+            k_intt8_cosets(c, c->ceval, ip, work);
+            k_intt8_cosets(c, c->ceval + D, fp, work);
+        } else if ((r = dst_internal_boundary_polys(c, draws.data(), ip, fp))) return r;
+        k_syn_div(c, ip, D, fe_one());
+        k_syn_div(c, fp, D, c->x_last);
+        k_intt8_cosets(c, c->ceval + 2 * D, tp, work);
+        k_syn_div_expanded(c, tp, c->cpoly, D, n, c->x_last);
+        k_add(c, c->cpoly, ip, D);
+        k_add(c, c->cpoly, fp, D);
+    } else {
+        // boundary quotients (4 x (n + 1) coefficients), the eight inverse coset transforms, then ONE pass: 8-point step across cosets,
+        // division of the transition part, sum (k_combine_fused)
+        fe* q4 = c->cwork; const size_t qs = n + 16;
+        if ((r = dst_internal_boundary_quotients(c, draws.data(), q4, qs))) return r;
+        k_intt_cosets_local(c, c->ceval + 2 * D, work, 8);
+        k_combine_fused(c, work, q4, qs, c->cpoly);
+    }
+    HIP_TRY(c, hipEventRecord(c->ph_ev[2], c->stream));
     // constraint_poly.eval + Merkle tree over raw evaluation pairs (prover.rs:82-86)
     k_lde_fold8(c, c->cpoly, c->cevals);
     k_constraint_tree(c);
     HIP_TRY(c, hipMemcpyAsync(c->constraint_root, c->cnodes + 1, 32, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipEventRecord(c->ph_ev[3], c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
+    if (!steps) {
+        c->air_flag_host = *reinterpret_cast<unsigned long long*>(c->h_stage + 65536 - 64);
+        if ((r = k_constraint_check(c, bad_step)) != DST_OK) { c->err = "transition constraints were not satisfied"; return r; }
+    }
     memcpy(constraint_root, c->constraint_root, 32);
-    c->phase_ms[2] = t1 - t0; c->phase_ms[3] = t2 - t1; c->phase_ms[4] = wall_ms() - t2;
+    // phase times from the stream's own clock; what the host spent before the first and after the last event goes to the outer phases
+    const double total = wall_ms() - t0, e1 = event_ms(c, 0, 1), e2 = event_ms(c, 1, 2), e3 = event_ms(c, 2, 3);
+    const double rest = total > e1 + e2 + e3 ? total - (e1 + e2 + e3) : 0.0;
+    c->phase_ms[2] = e1 + rest / 2; c->phase_ms[3] = e2; c->phase_ms[4] = e3 + rest / 2;
     c->constraints_done = true; c->composed = false;
     return DST_OK;
 }
 
 // ---- step 6 ---------------------------------------------------------------------------------------------------------------------
+// the DeepValues land in page-locked memory; a caller that did not wait (dst_prove) picks them up at its next synchronisation
+static void finish_deep_values(dst_ctx* c) {
+    if (!c->deep_pending) return;
+    const size_t W = c->W;
+    c->deep_z1.assign(c->h_stage + 32768, c->h_stage + 32768 + W * 16);
+    c->deep_z2.assign(c->h_stage + 32768 + 2048, c->h_stage + 32768 + 2048 + W * 16);
+    c->deep_pending = false;
+}
+static int compose_impl(dst_ctx* c, const uint8_t* draws_bytes, uint8_t* trace_at_z1, uint8_t* trace_at_z2, bool wait);
 int dst_compose(dst_ctx* c, const uint8_t* draws_bytes, uint8_t* trace_at_z1, uint8_t* trace_at_z2) {
     if (!c || !draws_bytes || !trace_at_z1 || !trace_at_z2) return DST_ERR_ARG;
+    return compose_impl(c, draws_bytes, trace_at_z1, trace_at_z2, true);
+}
+static int compose_impl(dst_ctx* c, const uint8_t* draws_bytes, uint8_t* trace_at_z1, uint8_t* trace_at_z2, bool wait) {
     if (!c->constraints_done) { c->err = "dst_compose: constraints not evaluated"; return DST_ERR_STATE; }
     HIP_TRY(c, hipSetDevice(c->device));
     double t0 = wall_ms();
+    HIP_TRY(c, hipEventRecord(c->ph_ev[0], c->stream));         // device-side extent of the composition (dst_prove does not wait for it)
     const size_t n = c->n, D = 8 * n, W = c->W;
     std::vector<fe> draws = copy_fe(draws_bytes, 516);
     const fe z = draws[0];
@@ -529,31 +607,45 @@ int dst_compose(dst_ctx* c, const uint8_t* draws_bytes, uint8_t* trace_at_z1, ui
     k_horner(c, c->polys, W, n, next_z, d_tz2);
     fe* t1 = c->cwork; fe* t2 = c->cwork + n; fe* cp = c->cwork + D;
     k_lincomb2(c, c->polys, W, n, d_draws + 1, 256, t1, t2);          // both combinations in one pass over the trace polynomials
-    k_sub_dot_at0(c, t1, d_tz1, d_draws + 1, W);
-    k_sub_dot_at0(c, t2, d_tz2, d_draws + 257, W);
-    k_syn_div(c, t1, n, z);
-    k_syn_div(c, t2, n, next_z);
-    k_add(c, t1, t2, n);
-    HIP_TRY(c, hipMemsetAsync(c->comp_poly, 0, D * 16, c->stream));
     const size_t inc = 6 * n + 1;                                // get_incremental_trace_degree (utils/mod.rs:20)
-    k_axpy(c, c->comp_poly, t1, k1, n);
-    k_axpy(c, c->comp_poly + inc, t1, k2, n);
-    // constraint_poly.rs:39-52 merge_into
-    k_horner(c, c->cpoly, 1, D, z, d_cz);
-    HIP_TRY(c, hipMemcpyAsync(cp, c->cpoly, D * 16, hipMemcpyDeviceToDevice, c->stream));
-    k_sub_at0(c, cp, d_cz);
-    k_syn_div(c, cp, D, z);
-    k_axpy(c, c->comp_poly, cp, k3, D);
+    if (dst_internal_combine_by_steps()) {
+        k_sub_dot_at0(c, t1, d_tz1, d_draws + 1, W);
+        k_sub_dot_at0(c, t2, d_tz2, d_draws + 257, W);
+        k_syn_div(c, t1, n, z);
+        k_syn_div(c, t2, n, next_z);
+        k_add(c, t1, t2, n);
+        HIP_TRY(c, hipMemsetAsync(c->comp_poly, 0, D * 16, c->stream));
+        k_axpy(c, c->comp_poly, t1, k1, n);
+        k_axpy(c, c->comp_poly + inc, t1, k2, n);
+        // constraint_poly.rs:39-52 merge_into
+        k_horner(c, c->cpoly, 1, D, z, d_cz);
+        HIP_TRY(c, hipMemcpyAsync(cp, c->cpoly, D * 16, hipMemcpyDeviceToDevice, c->stream));
+        k_sub_at0(c, cp, d_cz);
+        k_syn_div(c, cp, D, z);
+        k_axpy(c, c->comp_poly, cp, k3, D);
+    } else {
+        // The constant term of a dividend enters no coefficient of its quotient by (x - b), so the subtractions of T(z), T(z g) and C(z)
+        // (trace_table.rs:226-233, constraint_poly.rs:44) need not be made -- and C(z) need not be evaluated.  The division of the
+        // constraint polynomial writes the composition polynomial directly: k3 * quotient + (k1 + k2 x^inc) * t1.
+        k_syn_div(c, t1, n, z);
+        k_syn_div(c, t2, n, next_z);
+        k_add(c, t1, t2, n);
+        k_syn_div_compose(c, c->cpoly, c->comp_poly, D, z, t1, n, inc, k1, k2, k3);
+    }
     // evaluate over the LDE domain (prover.rs:98-101)
     k_lde_fold8(c, c->comp_poly, c->comp);
-    c->deep_z1.resize(W * 16); c->deep_z2.resize(W * 16);
-    HIP_TRY(c, hipMemcpyAsync(c->deep_z1.data(), d_tz1, W * 16, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->deep_z2.data(), d_tz2, W * 16, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipGetLastError());
-    memcpy(trace_at_z1, c->deep_z1.data(), W * 16);
-    memcpy(trace_at_z2, c->deep_z2.data(), W * 16);
-    c->phase_ms[5] = wall_ms() - t0;
+    HIP_TRY(c, hipEventRecord(c->ph_ev[1], c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_stage + 32768, d_tz1, W * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_stage + 32768 + 2048, d_tz2, W * 16, hipMemcpyDeviceToHost, c->stream));
+    c->deep_pending = true;
+    if (wait) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipGetLastError());
+        finish_deep_values(c);
+        memcpy(trace_at_z1, c->deep_z1.data(), W * 16);
+        memcpy(trace_at_z2, c->deep_z2.data(), W * 16);
+    }
+    c->phase_ms[5] = wall_ms() - t0;        // without the wait: the host's share only; the first FRI layer's wait absorbs the rest (dst_prove adds it back)
     c->composed = true; c->fri_committed = 0; c->fri_folded = 0; c->fri_roots.clear(); c->fri_tail_pending = false;
     return DST_OK;
 }
@@ -633,6 +725,7 @@ int dst_build_proof(dst_ctx* c, const uint64_t* positions_in, uint32_t num_posit
     if (c->prm.world != 1) { c->err = "dst_build_proof: single-GPU contexts only"; return DST_ERR_ARG; }
     HIP_TRY(c, hipSetDevice(c->device));
     double t0 = wall_ms();
+    finish_deep_values(c);                                      // every FRI layer since has synchronised the stream
     // one plan, one batched device gather, one fill (shard.hip; the single-GPU case is the plan with every item local)
     std::vector<uint8_t> proof;
     int rc = dst_internal_build_proof(c, positions_in, num_positions, pow_nonce, proof);
@@ -659,14 +752,25 @@ int dst_prove(dst_ctx* c, const dst_public* pub, uint8_t* proof_out, size_t cap,
     if ((rc = dst_eval_constraints(c, pub, (const uint8_t*)coef.data(), constraint_root, &bad))) return rc;
     std::vector<fe> draws(516);
     prng_vector(constraint_root, 516, draws.data());             // z = draw 0; CompositionCoefficients (coefficients.rs:82)
+    // the DEEP values are not needed before the openings: the host queues the composition and goes on to the first FRI layer
     std::vector<uint8_t> z1(c->W * 16), z2(c->W * 16);
-    if ((rc = dst_compose(c, (const uint8_t*)draws.data(), z1.data(), z2.data()))) return rc;
+    const double t_compose = wall_ms();
+    if ((rc = compose_impl(c, (const uint8_t*)draws.data(), z1.data(), z2.data(), false))) return rc;
+    bool first_layer = true;
     std::vector<uint8_t> roots;
     for (;;) {                                                   // fri::reduce (fri/prover.rs:11-53)
         // the small layers (at most 2^13 evaluations, natural order) in one launch, Fiat-Shamir draws on the device
         if (int rt = dst_internal_fri_tail(c, roots)) { if (rt < 0) return rt; break; }
         uint8_t root[32]; int more = 0;
         if ((rc = dst_fri_commit_layer(c, root, &more))) return rc;
+        if (first_layer) {
+            // layer 0's wait covered the composition too: split at the device's own boundary (leaves of layer 0 start when the composition ends)
+            first_layer = false;
+            const double both = wall_ms() - t_compose, fri0 = c->phase_ms[6] < both ? c->phase_ms[6] : both;
+            float dev = 0;
+            if (hipEventElapsedTime(&dev, c->ph_ev[0], c->ph_ev[1]) == hipSuccess && dev > 0 && dev < both) { c->phase_ms[5] = dev; c->phase_ms[6] = both - dev; }   // events of compose_impl
+            else { c->phase_ms[5] = both - fri0; c->phase_ms[6] = fri0; }
+        }
         roots.insert(roots.end(), root, root + 32);
         if (!more) break;
         fe sx = prng(root);

@@ -137,6 +137,9 @@ struct dst_ctx {
     // instead of being rebuilt from an all-gather on every rank (the host-orchestrated dst_shard_import).  Index 0 trace, 1 constraint, 2 + d FRI layer d.
     bool tree_krange[2 + DST_MAX_FRI_LAYERS] = {false};
     uint64_t *d_u64 = nullptr;                        // small device scalars (pow result, AIR failure flag)
+    uint8_t *h_stage = nullptr;                       // page-locked host staging (64 KiB): small uploads / read-backs that must not make the host wait
+    unsigned long long air_flag_host = ~0ull;         // read-back of the AIR failure flag (deferred check)
+    hipEvent_t ph_ev[6] = {nullptr};                  // phase boundaries on the stream (phase times without host waits)
     uint8_t *d_stage = nullptr;                       // staging buffer for gathers
     size_t stage_bytes = 0;
 
@@ -144,6 +147,7 @@ struct dst_ctx {
     dst_public pub{};
     uint8_t trace_root[32] = {0}, constraint_root[32] = {0};
     std::vector<uint8_t> deep_z1, deep_z2;
+    bool deep_pending = false;          // the DEEP values of the last composition are still in the page-locked staging area
     std::vector<std::vector<uint8_t>> fri_roots;
     uint64_t op_count = 0;
     fe program_hash[2] = {};
@@ -204,7 +208,9 @@ struct KScope {
 // ---- kernel launchers (kernels_*.hip) ------------------------------------------------------------------------------------
 // NTT / LDE
 extern "C" bool dst_internal_boundary_by_evaluation();                                  // api.hip: DISTAFF_BOUNDARY=eval
-extern "C" int dst_internal_boundary_polys(dst_ctx* c, const fe* draws344, fe* ip, fe* fp);   // api.hip: boundary combinations in coefficient form
+extern "C" int dst_internal_boundary_polys(dst_ctx* c, const fe* draws344, fe* ip, fe* fp, fe* o0 = nullptr, fe* o1 = nullptr, fe* o2 = nullptr, fe* o3 = nullptr);   // api.hip: boundary combinations in coefficient form (ip / fp: 8n coefficients each; or the four n-coefficient pieces)
+extern "C" bool dst_internal_combine_by_steps();                                        // api.hip: DISTAFF_COMBINE=steps (the reference's sequence of whole-array steps)
+extern "C" int dst_internal_boundary_quotients(dst_ctx* c, const fe* draws344, fe* q4, size_t stride);   // api.hip: the n-coefficient quotients the fused combination reads
 int k_build_twiddle_tables(dst_ctx* c);                                                 // fills tw4_lde / tw4_fwd / tw4_inv (context creation)
 void k_intt_columns(dst_ctx* c, const fe* src, size_t src_stride, fe* dst, size_t ncols); // size-n inverse NTT of ncols columns src_stride apart -> contiguous columns
 void k_lde_columns(dst_ctx* c, const fe* polys, fe* lde, size_t ncols);                 // n coefficients -> coset-major [Bc][n] per column
@@ -221,9 +227,12 @@ void k_constraint_tree(dst_ctx* c);
 void k_fri_leaves_layer0(dst_ctx* c);
 void k_fri_leaves(dst_ctx* c, int layer);
 // AIR
-int k_eval_constraints(dst_ctx* c, const fe* coeffs_dev, const fe* tc_dev, int64_t* bad_step);
+int k_eval_constraints(dst_ctx* c, const fe* coeffs_dev, const fe* tc_dev, int64_t* bad_step, bool defer_check = false);   // defer_check: no host wait; k_constraint_check reads the flag later
+int k_constraint_check(dst_ctx* c, int64_t* bad_step);                                  // after a stream synchronisation: the failing step recorded by the last evaluation, if any
 // polynomial helpers
 void k_syn_div(dst_ctx* c, fe* a, size_t len, fe b);                                    // polynom.rs:190 semantics, in place
+void k_syn_div_compose(dst_ctx* c, const fe* a, fe* out, size_t len, fe b, const fe* t, size_t tn, size_t inc, fe k1, fe k2, fe k3);   // out = k3 * a / (x - b) + (k1 + k2 x^inc) * t
+void k_combine_fused(dst_ctx* c, const fe* work, const fe* q4, size_t q_stride, fe* cpoly);   // kernels_ntt.hip: 8-point step + division + boundary quotients -> constraint polynomial
 void k_syn_div_expanded(dst_ctx* c, const fe* a, fe* out, size_t len, size_t degree, fe exception);
 void k_horner(dst_ctx* c, const fe* polys, size_t ncols, size_t len, fe x, fe* out_dev);
 void k_lincomb(dst_ctx* c, const fe* cols, size_t ncols, size_t len, const fe* coeffs_dev, fe* out);

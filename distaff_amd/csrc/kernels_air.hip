@@ -15,7 +15,13 @@ void air_launch_generic(dst_ctx* c, const AirArgs& a, uint32_t Q) {
 }
 
 
-int k_eval_constraints(dst_ctx* c, const fe* coeffs_dev, const fe* tc_dev, int64_t* bad_step) {
+int k_constraint_check(dst_ctx* c, int64_t* bad_step) {
+    const unsigned long long res = c->air_flag_host;
+    if (res != ~0ull) { if (bad_step) *bad_step = (int64_t)res; return DST_ERR_AIR; }
+    if (bad_step) *bad_step = -1;
+    return DST_OK;
+}
+int k_eval_constraints(dst_ctx* c, const fe* coeffs_dev, const fe* tc_dev, int64_t* bad_step, bool defer_check) {
     if (!c->air_consts) {
         AirConsts h;
         memcpy(h.sponge_mds, SPONGE_MDS, sizeof(h.sponge_mds)); memcpy(h.sponge_inv_mds, SPONGE_INV_MDS, sizeof(h.sponge_inv_mds));
@@ -57,10 +63,12 @@ int k_eval_constraints(dst_ctx* c, const fe* coeffs_dev, const fe* tc_dev, int64
     else if (a.cl <= 2 && a.ll <= 1 && sd <= 8 && !general) air_launch_small(c, a, Q);
     else if (!want_generic) air_launch_deep(c, a, Q);
     else air_launch_generic(c, a, Q);
-    unsigned long long res = 0;
-    HIP_TRY(c, hipMemcpyAsync(&res, c->d_u64, 8, hipMemcpyDeviceToHost, c->stream));
+    // the failing step, if any (evaluator.rs:152-158 panics there): read back into page-locked memory; with defer_check the host does not
+    // wait here -- the caller looks at it (k_constraint_check) at its next synchronisation, after work that does not depend on it
+    unsigned long long* flag = c->h_stage ? reinterpret_cast<unsigned long long*>(c->h_stage + 65536 - 64) : &c->air_flag_host;
+    HIP_TRY(c, hipMemcpyAsync(flag, c->d_u64, 8, hipMemcpyDeviceToHost, c->stream));
+    if (defer_check && c->h_stage) return DST_OK;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (res != ~0ull) { if (bad_step) *bad_step = (int64_t)res; return DST_ERR_AIR; }
-    if (bad_step) *bad_step = -1;
-    return DST_OK;
+    c->air_flag_host = *flag;
+    return k_constraint_check(c, bad_step);
 }

@@ -837,12 +837,10 @@ void k_lde_fold8(dst_ctx* c, const fe* poly8n, fe* out) {
 
 // ---- inverse transform of size 8n from coset-major input ------------------------------------------------------------------
 // v[q][k] = V(w_8n^(8k+q)); c[m0 + n*m1] = (1/8n) sum_q w_8^(-q*m1) * w_8n^(-q*m0) * (sum_k v[q][k] w_n^(-k*m0)).
-__global__ void cross8_kernel(const fe* __restrict__ work, fe* __restrict__ out, const fe* itw_lo, const fe* itw_hi, uint32_t lo_bits,
-                              uint32_t log_n, uint32_t log_N, uint32_t log_b, fe eight_inv) {
-    const size_t n = (size_t)1 << log_n;
+// X[m1] = (1/8) sum_q w_8^(-q*m1) * w_8n^(-q*m0) * work[q][m0], m1 < 8: the 8n coefficients out[m0 + n*m1] of residue class m0
+__device__ __forceinline__ void cross8_point(const fe* __restrict__ work, size_t m0, size_t n, const fe* itw_lo, const fe* itw_hi, uint32_t lo_bits,
+                                             uint32_t log_N, uint32_t log_b, const fe& eight_inv, fe (&X)[8]) {
     const uint64_t nmask = ((uint64_t)1 << log_N) - 1;
-    size_t m0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (m0 >= n) return;
     fe x[8];
 #pragma unroll
     for (uint32_t q = 0; q < 8; q++) {
@@ -862,14 +860,93 @@ __global__ void cross8_kernel(const fe* __restrict__ work, fe* __restrict__ out,
     fe b1 = fe_add(a1, a3), b3 = fe_mul(fe_sub(a1, a3), r2);
     fe b4 = fe_add(a4, a6), b6 = fe_sub(a4, a6);
     fe b5 = fe_add(a5, a7), b7 = fe_mul(fe_sub(a5, a7), r2);
-    fe X0 = fe_add(b0, b1), X4 = fe_sub(b0, b1);
-    fe X2 = fe_add(b2, b3), X6 = fe_sub(b2, b3);
-    fe X1 = fe_add(b4, b5), X5 = fe_sub(b4, b5);
-    fe X3 = fe_add(b6, b7), X7 = fe_sub(b6, b7);
-    out[m0] = fe_mul(X0, eight_inv);         out[m0 + n] = fe_mul(X1, eight_inv);
-    out[m0 + 2 * n] = fe_mul(X2, eight_inv); out[m0 + 3 * n] = fe_mul(X3, eight_inv);
-    out[m0 + 4 * n] = fe_mul(X4, eight_inv); out[m0 + 5 * n] = fe_mul(X5, eight_inv);
-    out[m0 + 6 * n] = fe_mul(X6, eight_inv); out[m0 + 7 * n] = fe_mul(X7, eight_inv);
+    X[0] = fe_mul(fe_add(b0, b1), eight_inv); X[4] = fe_mul(fe_sub(b0, b1), eight_inv);
+    X[2] = fe_mul(fe_add(b2, b3), eight_inv); X[6] = fe_mul(fe_sub(b2, b3), eight_inv);
+    X[1] = fe_mul(fe_add(b4, b5), eight_inv); X[5] = fe_mul(fe_sub(b4, b5), eight_inv);
+    X[3] = fe_mul(fe_add(b6, b7), eight_inv); X[7] = fe_mul(fe_sub(b6, b7), eight_inv);
+}
+__global__ void cross8_kernel(const fe* __restrict__ work, fe* __restrict__ out, const fe* itw_lo, const fe* itw_hi, uint32_t lo_bits,
+                              uint32_t log_n, uint32_t log_N, uint32_t log_b, fe eight_inv) {
+    const size_t n = (size_t)1 << log_n;
+    size_t m0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (m0 >= n) return;
+    fe X[8];
+    cross8_point(work, m0, n, itw_lo, itw_hi, lo_bits, log_N, log_b, eight_inv, X);
+#pragma unroll
+    for (int m1 = 0; m1 < 8; m1++) out[m0 + (size_t)m1 * n] = X[m1];
+}
+
+// ---- combine_polys in one pass (constraint_table.rs:54-88) -----------------------------------------------------------------------------
+// The constraint polynomial is  I(x) / (x - 1)  +  F(x) / (x - x_last)  +  T(x) * (x - x_last) / (x^n - 1)  (8n coefficients).
+//  * T comes from the inverse-transformed evaluation cosets `work[8][n]`: the 8-point step across cosets gives, per residue class m0,
+//    the eight coefficients t[m0 + n m1]; the division by (x^n - 1) / (x - x_last) (polynom.rs:202-236) needs the stride-n suffix sums
+//    S_r[k] = sum_{s >= k} t[r + n s] of the classes m0 and m0 - 1:  out[m0 + n m1] = S_{m0-1}[m1 + 1] - x_last * S_{m0}[m1 + 1]
+//    (class n - 1 one level down for m0 = 0; nothing above 7n) -- a lane's left neighbour hands its sums over through LDS.
+//  * I = A + x^p A', F = C + x^p C' with p = 6n + 2 and A, A', C, C' of n coefficients each (linear combinations of the trace polynomials,
+//    dst_internal_boundary_quotients): the quotients of the sparse 8n-coefficient polynomials follow from the n-coefficient quotients.
+//    With sA[1 + i] = sum_{t > i} A_t, sA'[0] = sum A' (exclusive suffix sums of the arrays extended by a leading zero) and
+//    eC[1 + i] = sum_{t > i} C_t b^(t - i - 1), eC'[0] = C'(b) for b = x_last:
+//        i < n:            sA[1 + i] + sA'[0]  +  eC[1 + i] + b^(p - 1 - i) eC'[0]
+//        n <= i < p:       sA'[0]              +  b^(p - 1 - i) eC'[0]
+//        p <= i < p + n:   sA'[1 + i - p]      +  eC'[1 + i - p]
+//    and b^(p - 1 - i) = w_n^(m0 - 1) for every i of class m0 (b has order n).
+// The reference's sequence -- two more 8n-point inverse transforms, three divisions and two additions over 8n coefficients each -- is
+// DISTAFF_COMBINE=steps (api.hip; the tests compare both).
+struct CombineArgs {
+    const fe* work; fe* cpoly;
+    const fe *sA, *sAp, *eC, *eCp;                 // n + 1 entries each, or all null: transition part only
+    const fe *itw_lo, *itw_hi, *tw_lo, *tw_hi;
+    uint32_t lo_bits, log_n, log_N, log_b;
+    fe eight_inv, x_last;
+};
+#define COMBINE_THREADS 256
+__global__ void __launch_bounds__(COMBINE_THREADS) combine_fused_kernel(CombineArgs a) {
+    __shared__ fe S[COMBINE_THREADS][8];
+    const size_t n = (size_t)1 << a.log_n;
+    const uint32_t t = threadIdx.x;
+    // lane t of block b: class m0 = 255 b + t - 1; lane 0 only serves lane 1 as its left neighbour (class n - 1 for the first block)
+    const size_t m_plus = (size_t)blockIdx.x * (COMBINE_THREADS - 1) + t;
+    const bool inside = m_plus <= n;                             // m0 = m_plus - 1 in [-1, n - 1]
+    const size_t m0 = inside ? (m_plus + n - 1) & (n - 1) : 0;
+    fe X[8], Sx[9];
+    cross8_point(a.work, m0, n, a.itw_lo, a.itw_hi, a.lo_bits, a.log_N, a.log_b, a.eight_inv, X);
+    Sx[8] = fe_zero();
+#pragma unroll
+    for (int k = 7; k >= 0; k--) Sx[k] = k == 7 ? X[7] : fe_add(X[k], Sx[k + 1]);
+#pragma unroll
+    for (int k = 0; k < 8; k++) S[t][k] = Sx[k];
+    __syncthreads();
+    if (t == 0 || m_plus > n) return;
+    const bool first = m0 == 0;
+    fe term = fe_zero();                                         // what every i < p of this class receives from the boundary quotients
+    if (a.sA) {
+        const fe P = dom_pow(a.tw_lo, a.tw_hi, a.lo_bits, (uint64_t)((m0 + n - 1) & (n - 1)) << a.log_b);      // w_n^(m0 - 1)
+        term = fe_add(a.sAp[0], fe_mul(P, a.eCp[0]));
+    }
+#pragma unroll
+    for (int m1 = 0; m1 < 8; m1++) {
+        fe v;
+        if (m1 < 7) v = fe_sub(first ? S[t - 1][m1] : S[t - 1][m1 + 1], fe_mul(a.x_last, Sx[m1 + 1]));
+        else v = first ? S[t - 1][7] : fe_zero();                // i = 7n is the last coefficient of the quotient
+        if (a.sA) {
+            if (m1 == 0) v = fe_add(v, fe_add(fe_add(a.sA[1 + m0], a.eC[1 + m0]), term));
+            else if (m1 < 6 || (m1 == 6 && m0 < 2)) v = fe_add(v, term);
+            else if (m1 == 6) v = fe_add(v, fe_add(a.sAp[m0 - 1], a.eCp[m0 - 1]));                  // i - p = m0 - 2
+            else if (m0 < 2) v = fe_add(v, fe_add(a.sAp[m0 + n - 1], a.eCp[m0 + n - 1]));          // i - p = m0 + n - 2
+        }
+        a.cpoly[m0 + (size_t)m1 * n] = v;
+    }
+}
+void k_combine_fused(dst_ctx* c, const fe* work, const fe* q4, size_t q_stride, fe* cpoly) {
+    CombineArgs a{};
+    a.work = work; a.cpoly = cpoly;
+    if (q4) { a.sA = q4; a.sAp = q4 + q_stride; a.eC = q4 + 2 * q_stride; a.eCp = q4 + 3 * q_stride; }
+    a.itw_lo = c->itw_lo; a.itw_hi = c->itw_hi; a.tw_lo = c->tw_lo; a.tw_hi = c->tw_hi;
+    a.lo_bits = c->tw_lo_bits; a.log_n = c->log_n; a.log_N = c->log_N; a.log_b = c->log_b;
+    a.eight_inv = c->eight_inv; a.x_last = c->x_last;
+    const size_t blocks = (c->n + 1 + (COMBINE_THREADS - 2)) / (COMBINE_THREADS - 1);
+    KScope ks_(c, "combine_fused_kernel", 16.0 * c->n * 16);
+    hipLaunchKernelGGL(combine_fused_kernel, dim3((unsigned)blocks), dim3(COMBINE_THREADS), 0, c->stream, a);
 }
 
 // the two halves of k_intt8_cosets for the sharded prover: a rank inverts the size-n transforms of the evaluation cosets it owns BEFORE the

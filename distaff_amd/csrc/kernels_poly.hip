@@ -169,6 +169,39 @@ __global__ void __launch_bounds__(PT) syn_div_chunk_kernel(fe* a, size_t len, Sy
 #pragma unroll
     for (int r = 0; r < 8; r++) { const uint32_t i = r * PT + threadIdx.x; if (base + i < len) a[base + i] = tile[sd_slot(i)]; }
 }
+// The same division written to ANOTHER array with the DEEP composition's epilogue (constraint_poly.rs:39-52 merge_into after
+// trace_table.rs:248-260): out[i] = k3 * q_i + [i < tn] k1 * t[i] + [inc <= i < inc + tn] k2 * t[i - inc], q = a / (x - b).
+// Replaces: copy of the constraint polynomial, subtraction of C(z) (the constant term enters no quotient coefficient), in-place division,
+// zero fill of the composition polynomial and three multiply-adds over 8n coefficients each.
+struct SynDivEpilogue { fe_tw k1, k2, k3; const fe* t; size_t tn, inc; };
+__global__ void __launch_bounds__(PT) syn_div_chunk_out_kernel(const fe* __restrict__ a, fe* __restrict__ out, size_t len, SynDivArgs p, const fe* __restrict__ right, SynDivEpilogue ep) {
+    __shared__ fe tile[SD_TILE];
+    __shared__ fe sh[PT + 1];
+    fe v[8], q[8], e = fe_zero();
+    sd_load_chunk(tile, a, len, v);
+#pragma unroll
+    for (int j = 7; j >= 0; j--) { q[j] = e; e = fe_add(fe_mul_tw(e, p.b), v[j]); }
+    (void)sd_lane_scan(sh, p, e, right ? right[blockIdx.x] : fe_zero());
+    fe x = sh[threadIdx.x + 1];
+#pragma unroll
+    for (int j = 7; j >= 0; j--) {
+        tile[sd_slot(threadIdx.x * 8 + j)] = fe_add(q[j], x);
+        x = fe_mul_tw(x, p.b);
+    }
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * SD_CHUNK;
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint32_t i = r * PT + threadIdx.x;
+        const size_t gi = base + i;
+        if (gi < len) {
+            fe w = fe_mul_tw(tile[sd_slot(i)], ep.k3);
+            if (gi < ep.tn) w = fe_add(w, fe_mul_tw(ep.t[gi], ep.k1));
+            if (gi >= ep.inc && gi - ep.inc < ep.tn) w = fe_add(w, fe_mul_tw(ep.t[gi - ep.inc], ep.k2));
+            out[gi] = w;
+        }
+    }
+}
 static SynDivArgs syn_div_args(fe b) {
     SynDivArgs p;
     p.b = fe_tw_make(b);
@@ -187,6 +220,20 @@ static void syn_div_blocked(dst_ctx* c, fe* a, size_t len, fe b, fe* scratch) {
         syn_div_blocked(c, scratch, chunks, bc, scratch + chunks);
     }
     { KScope ks_(c, "syn_div_chunk_kernel", 32.0 * len); hipLaunchKernelGGL(syn_div_chunk_kernel, dim3((unsigned)chunks), dim3(PT), 0, c->stream, a, len, p, chunks > 1 ? (const fe*)scratch : (const fe*)nullptr); }
+}
+// out = k3 * (a / (x - b)) + k1 * t + k2 * x^inc * t  (t of tn coefficients); `a` is left untouched
+void k_syn_div_compose(dst_ctx* c, const fe* a, fe* out, size_t len, fe b, const fe* t, size_t tn, size_t inc, fe k1, fe k2, fe k3) {
+    fe* scr = c->scratch;
+    const size_t chunks = (len + SD_CHUNK - 1) / SD_CHUNK;
+    const SynDivArgs p = syn_div_args(b);
+    if (chunks > 1) {
+        { KScope ks_(c, "syn_div_chunk_sums_kernel", 16.0 * len); hipLaunchKernelGGL(syn_div_chunk_sums_kernel, dim3((unsigned)chunks), dim3(PT), 0, c->stream, a, len, p, scr); }
+        fe bc = b;
+        for (int i = 0; i < 11; i++) bc = fe_mul(bc, bc);                   // b^2048
+        syn_div_blocked(c, scr, chunks, bc, scr + chunks);
+    }
+    SynDivEpilogue ep{fe_tw_make(k1), fe_tw_make(k2), fe_tw_make(k3), t, tn, inc};
+    { KScope ks_(c, "syn_div_chunk_out_kernel", 32.0 * len); hipLaunchKernelGGL(syn_div_chunk_out_kernel, dim3((unsigned)chunks), dim3(PT), 0, c->stream, a, out, len, p, chunks > 1 ? (const fe*)scr : (const fe*)nullptr, ep); }
 }
 void k_syn_div(dst_ctx* c, fe* a, size_t len, fe b) {
     unsigned g = (unsigned)((len + PT - 1) / PT);

@@ -135,23 +135,37 @@ int dst_shard_eval_constraints(dst_ctx* c, const dst_public* pub, const uint8_t*
 static int shard_combine_parts(dst_ctx* c, int parts) {
     const size_t n = c->n, D = 8 * n;
     fe* ip = c->cwork; fe* fp = c->cwork + D; fe* tp = c->cwork + 2 * D; fe* work = c->cwork + 3 * D;
+    const bool steps = dst_internal_combine_by_steps();         // the reference's sequence of whole-array steps (tests), else the fused pass of the single-GPU path
+    fe* q4 = c->cwork; const size_t qs = n + 16;
     if (parts & 1) {
-        if (dst_internal_boundary_by_evaluation()) {
-            k_intt8_cosets(c, c->ceval, ip, work);
-            k_intt8_cosets(c, c->ceval + D, fp, work);
-        } else {
-            int rb = dst_internal_boundary_polys(c, c->shard_draws.data(), ip, fp);
+        if (!steps) {
+            int rb = dst_internal_boundary_quotients(c, c->shard_draws.data(), q4, qs);
             if (rb) return rb;
+        } else {
+            if (dst_internal_boundary_by_evaluation()) {
+                k_intt8_cosets(c, c->ceval, ip, work);
+                k_intt8_cosets(c, c->ceval + D, fp, work);
+            } else {
+                int rb = dst_internal_boundary_polys(c, c->shard_draws.data(), ip, fp);
+                if (rb) return rb;
+            }
+            k_syn_div(c, ip, D, fe_one());
+            k_syn_div(c, fp, D, c->x_last);
         }
-        k_syn_div(c, ip, D, fe_one());
-        k_syn_div(c, fp, D, c->x_last);
     }
     if (parts & 2) {
-        if (c->ceval_inverted) { k_cross8(c, c->ceval + 2 * D, tp); c->ceval_inverted = false; }
-        else k_intt8_cosets(c, c->ceval + 2 * D, tp, work);
-        k_syn_div_expanded(c, tp, c->cpoly, D, n, c->x_last);
-        k_add(c, c->cpoly, ip, D);
-        k_add(c, c->cpoly, fp, D);
+        if (!steps) {
+            const fe* inv = c->ceval + 2 * D;                   // already inverse-transformed per coset by its owner (dst_prove_sharded) ...
+            if (!c->ceval_inverted) { k_intt_cosets_local(c, c->ceval + 2 * D, work, 8); inv = work; }      // ... or not (host-orchestrated path)
+            c->ceval_inverted = false;
+            k_combine_fused(c, inv, q4, qs, c->cpoly);
+        } else {
+            if (c->ceval_inverted) { k_cross8(c, c->ceval + 2 * D, tp); c->ceval_inverted = false; }
+            else k_intt8_cosets(c, c->ceval + 2 * D, tp, work);
+            k_syn_div_expanded(c, tp, c->cpoly, D, n, c->x_last);
+            k_add(c, c->cpoly, ip, D);
+            k_add(c, c->cpoly, fp, D);
+        }
         k_lde_fold8(c, c->cpoly, c->cevals);
         if (c->Bc >= 4) {                                   // with two cosets per rank the leaves themselves are the boundary (see dst_shard_export)
             k_constraint_level1(c);

@@ -21,6 +21,7 @@ SELECTION = [
     "test_fibonacci_all_phases[7]",
     "test_fibonacci_all_phases[10]",
     "test_boundary_constraints_by_evaluation[]",
+    "test_combination_and_composition_as_whole_array_steps",
     "test_other_program_shapes",
     "test_program_shapes_with_stack_depth_5_to_8",
     "test_blowup_16_and_64",

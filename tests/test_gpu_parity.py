@@ -118,6 +118,26 @@ def test_boundary_constraints_by_evaluation(oracle, monkeypatch, instance):
     _check_all_phases(oracle, D, oracle.Trace("begin dup.4 add mul swap.2 add drop drop block push.9 mul end end", [1, 2, 3, 4]), num_outputs=2)
 
 
+def test_combination_and_composition_as_whole_array_steps(oracle, monkeypatch):
+    """DISTAFF_COMBINE=steps: combine_polys and the DEEP composition as the reference's sequence of whole-array steps (8n-coefficient boundary
+    polynomials, three divisions, additions; copy / C(z) / division / multiply-adds) instead of the fused passes the library takes by
+    default -- every intermediate and the proof must be the same, on one context and through the sharded prover."""
+    import distaff_amd as D
+    monkeypatch.setenv("DISTAFF_COMBINE", "steps")
+    _check_all_phases(oracle, D, oracle.fibonacci_trace(1 << 9))
+    t = oracle.fibonacci_trace(1 << 8)
+    op = oracle.Prover.from_trace(t, 1, grinding=8)
+    expected = op.prove()
+    ctxs = []
+    for r in range(4):
+        ctx = D.Context(8, t.width, t.ctx_depth, t.loop_depth, rank=r, world=4, grinding=8)
+        ctx.upload_owned(t.columns)
+        ctxs.append(ctx)
+    assert D.prove_sharded_local(ctxs, t.public_inputs, op.outputs) == expected
+    for ctx in ctxs:
+        ctx.close()
+
+
 @pytest.mark.parametrize("shape", ["fibonacci", "w17", "w18"])
 def test_trace_from_pinned_host_memory(oracle, shape):
     """dst_trace_upload_async: the registers arrive group by group (the first group is short) and every group is interpolated and extended
