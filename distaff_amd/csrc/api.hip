@@ -79,7 +79,7 @@ static std::vector<fe> build_periodic_table() {
 }
 
 static void free_all(dst_ctx* c) {
-    void* ptrs[] = {c->tw_lo, c->tw_hi, c->itw_lo, c->itw_hi, c->w1f, c->w2f, c->w1i, c->w2i, c->prescale, c->dit_last, c->tw4_lde, c->tw4_fwd, c->tw4_inv, c->tw4_row_fwd, c->tw4_row_inv, c->w3f, c->w3i, c->tmp2, c->periodic, c->trace == c->lde ? nullptr : c->trace, c->polys, c->lde, c->tmp,
+    void* ptrs[] = {c->tw_lo, c->tw_hi, c->itw_lo, c->itw_hi, c->w1f, c->w2f, c->w1i, c->w2i, c->w1pf, c->w1pi, c->w2pf, c->w2pi, c->prescale, c->dit_last, c->tw4_lde, c->tw4_fwd, c->tw4_inv, c->tw4_row_fwd, c->tw4_row_inv, c->w3f, c->w3i, c->tmp2, c->periodic, c->trace == c->lde ? nullptr : c->trace, c->polys, c->lde, c->tmp,
                     c->trace_leaves, c->trace_nodes, c->air_consts, c->ceval, c->cwork, c->cpoly, c->cevals, c->cnodes, c->comp_poly, c->comp, c->scratch, c->d_u64, c->d_stage};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& e : c->kpending) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
@@ -131,7 +131,11 @@ static int ctx_init(dst_ctx* c) {
     // 16-column tiles (256-byte HBM segments) instead of 4096-point tiles that hold one or two columns
     NttPlan& pl = c->plan;
     const char* force = getenv("DISTAFF_NTT");
-    const bool three = (c->log_n >= 21 && !(force && (!strcmp(force, "reg") || !strcmp(force, "lds")))) || (force && !strcmp(force, "3pass") && c->log_n >= 12);
+    // n = 2^21, 2^22: still two passes -- their 2048-point factors run as a register pre-stage + 1024-point LDS tiles (NttArgs::pre);
+    // DISTAFF_NTT=pre forces the pre-stages onto smaller transforms (tests), DISTAFF_NTT=3pass keeps the three-pass plan from 2^21 on
+    const bool force_3 = force && !strcmp(force, "3pass"), force_pre = force && !strcmp(force, "pre") && c->log_n >= 10 && c->log_n <= 22;
+    const bool pre_plan = force_pre || ((c->log_n == 21 || c->log_n == 22) && !force);
+    const bool three = !pre_plan && ((c->log_n >= 21 && !(force && (!strcmp(force, "reg") || !strcmp(force, "lds")))) || (force_3 && c->log_n >= 12));
     pl.log_n = c->log_n;
     if (three) {
         // shape n1 * nm * n3 with n1 >= nm >= n3 as balanced as possible, at most 2^8 each; DISTAFF_NTT_SHAPE=a,b overrides n1, nm (tests)
@@ -141,18 +145,19 @@ static int ctx_init(dst_ctx* c) {
         pl.log_n1 = a; pl.log_n2 = c->log_n - a; pl.log_n3 = c->log_n - a - b;
     }
     else { pl.log_n1 = (c->log_n + 1) / 2; pl.log_n2 = c->log_n / 2; pl.log_n3 = 0; }
+    if (pre_plan) { pl.pre_a = (force_pre || pl.log_n1 > 10) ? 1u : 0u; pl.pre_b = (force_pre || pl.log_n2 > 10) ? 1u : 0u; }
     auto tile_for = [](uint32_t log_len, uint32_t other_len_log, uint32_t cap) {
         uint32_t t = cap;
         while (t > 1 && (((size_t)1 << log_len) * t * sizeof(fe) > 65536 || t > (1u << other_len_log))) t >>= 1;
         return t;
     };
-    pl.tile_a = tile_for(pl.log_n1, pl.log_n2, three ? 16 : 4);
-    pl.tile_b = three ? tile_for(pl.log_n3, pl.log_n1, 16) : tile_for(pl.log_n2, pl.log_n1, 4);
+    pl.tile_a = tile_for(pl.log_n1 - pl.pre_a, pl.log_n2, three ? 16 : 4);
+    pl.tile_b = three ? tile_for(pl.log_n3, pl.log_n1, 16) : tile_for(pl.log_n2 - pl.pre_b, pl.log_n1, 4);
     pl.tile_m = three ? tile_for(pl.log_n2 - pl.log_n3, pl.log_n3, 16) : 1;
     // kernel choice per pass (measured): the LDS radix-2 kernels win while a tile holds >= 2 columns in 64 KiB of LDS; the
     // register-radix kernels take over for 4096-point tiles.  DISTAFF_NTT=reg|lds forces one two-pass family (tests run both).
     {
-        const bool reg_ok = !three && pl.log_n2 >= 6 && pl.log_n1 <= 12;
+        const bool reg_ok = !three && !pre_plan && pl.log_n2 >= 6 && pl.log_n1 <= 12;
         pl.reg_a = reg_ok && pl.log_n1 >= 12; pl.reg_b = reg_ok && pl.log_n2 >= 12;      // 4096-point tiles: the LDS family is down to one column (16-byte segments)
         if (force && !strcmp(force, "reg") && reg_ok) pl.reg_a = pl.reg_b = true;
         if (force && !strcmp(force, "lds")) { pl.reg_a = pl.reg_a && pl.log_n1 >= 12; pl.reg_b = pl.reg_b && pl.log_n2 >= 12; }   // a 4096-point coset DIT (64 KiB tile + 128 KiB of twiddle pairs) does not fit LDS
@@ -172,12 +177,23 @@ static int ctx_init(dst_ctx* c) {
     if ((r = dev_upload(c, &c->tw_hi, h_powers(h_pow(wN, (u128)1 << c->tw_lo_bits), (size_t)1 << hi_bits)))) return r;
     if ((r = dev_upload(c, &c->itw_lo, h_powers(wN_inv, (size_t)1 << c->tw_lo_bits)))) return r;
     if ((r = dev_upload(c, &c->itw_hi, h_powers(h_pow(wN_inv, (u128)1 << c->tw_lo_bits), (size_t)1 << hi_bits)))) return r;
-    const uint32_t log_second = pl.log_n3 ? pl.log_n2 - pl.log_n3 : pl.log_n2;        // three-pass: w2* serve the middle pass
-    fe w1 = h_root_of_unity(pl.log_n1), w2 = h_root_of_unity(log_second);
-    if ((r = dev_upload(c, &c->w1f, h_powers_tw(w1, (size_t)1 << (pl.log_n1 - 1))))) return r;
+    const uint32_t log_second = pl.log_n3 ? pl.log_n2 - pl.log_n3 : pl.log_n2 - pl.pre_b;        // three-pass: w2* serve the middle pass
+    const uint32_t log_first = pl.log_n1 - pl.pre_a;                                             // length of the first pass's LDS transform
+    fe w1 = h_root_of_unity(log_first), w2 = h_root_of_unity(log_second);
+    if ((r = dev_upload(c, &c->w1f, h_powers_tw(w1, (size_t)1 << (log_first - 1))))) return r;
     if ((r = dev_upload(c, &c->w2f, h_powers_tw(w2, (size_t)1 << (log_second - 1))))) return r;
-    if ((r = dev_upload(c, &c->w1i, h_powers_tw(h_inv(w1), (size_t)1 << (pl.log_n1 - 1))))) return r;
+    if ((r = dev_upload(c, &c->w1i, h_powers_tw(h_inv(w1), (size_t)1 << (log_first - 1))))) return r;
     if ((r = dev_upload(c, &c->w2i, h_powers_tw(h_inv(w2), (size_t)1 << (log_second - 1))))) return r;
+    if (pl.pre_a) {
+        fe wp = h_root_of_unity(pl.log_n1);
+        if ((r = dev_upload(c, &c->w1pf, h_powers_tw(wp, (size_t)1 << (pl.log_n1 - 1))))) return r;
+        if ((r = dev_upload(c, &c->w1pi, h_powers_tw(h_inv(wp), (size_t)1 << (pl.log_n1 - 1))))) return r;
+    }
+    if (pl.pre_b) {
+        fe wp = h_root_of_unity(pl.log_n2);
+        if ((r = dev_upload(c, &c->w2pf, h_powers_tw(wp, (size_t)1 << (pl.log_n2 - 1))))) return r;
+        if ((r = dev_upload(c, &c->w2pi, h_powers_tw(h_inv(wp), (size_t)1 << (pl.log_n2 - 1))))) return r;
+    }
     if (pl.log_n3) {
         fe w3 = h_root_of_unity(pl.log_n3);
         if ((r = dev_upload(c, &c->w3f, h_powers_tw(w3, (size_t)1 << (pl.log_n3 - 1))))) return r;
@@ -188,9 +204,10 @@ static int ctx_init(dst_ctx* c) {
     {
         const std::vector<fe_tw> pre = h_powers_tw(h_root_of_unity(c->log_b + pl.log_n1), (size_t)1 << (c->log_b + pl.log_n1));
         if ((r = dev_upload(c, &c->prescale, pre))) return r;
-        const size_t half = (size_t)1 << (pl.log_n1 - 1);
-        std::vector<fe_tw> last(c->B * half);
-        for (size_t j = 0; j < c->B; j++) for (size_t k = 0; k < half; k++) last[j * half + k] = pre[j + c->B * k];
+        // last-stage twiddles of the (half-length, with a pre-stage) coset DITs: [B][R][len / 2] entries pre[j + B * (h + R * k)]
+        const size_t R = (size_t)1 << pl.pre_a, half = (size_t)1 << (pl.log_n1 - pl.pre_a - 1);
+        std::vector<fe_tw> last(c->B * R * half);
+        for (size_t j = 0; j < c->B; j++) for (size_t h = 0; h < R; h++) for (size_t k = 0; k < half; k++) last[(j * R + h) * half + k] = pre[j + c->B * (h + R * k)];
         if ((r = dev_upload(c, &c->dit_last, last))) return r;
     }
     if ((r = dev_alloc(c, &c->tw4_lde, c->Bc * c->n))) return r;

@@ -64,6 +64,7 @@ struct NttPlan {
     uint32_t tile_a = 1, tile_b = 1;                 // columns per workgroup tile in pass A / pass B
     uint32_t tile_m = 1;                             // three-pass plans: columns per tile of the middle pass
     bool reg_a = false, reg_b = false;               // per pass: register-radix kernel (tile lengths 2^6 .. 2^12) instead of the LDS radix-2 one
+    uint32_t pre_a = 0, pre_b = 0;                   // two-pass plans: register pre-stage of the pass (its LDS tiles hold 2^(log_n1 - pre_a) / 2^(log_n2 - pre_b) points), see NttArgs
 };
 
 struct dst_ctx {
@@ -92,9 +93,10 @@ struct dst_ctx {
     fe *itw_lo = nullptr, *itw_hi = nullptr;     // w_N^-t
     uint32_t tw_lo_bits = 0;
     // every twiddle of the LDS-family transforms is a table pair (w, w * 2^64 mod p), see fe_mul_tw (fe.h)
-    fe_tw *w1f = nullptr, *w2f = nullptr, *w1i = nullptr, *w2i = nullptr;   // stage twiddles w_{n1}^t, w_{n2}^t and inverses
+    fe_tw *w1f = nullptr, *w2f = nullptr, *w1i = nullptr, *w2i = nullptr;   // stage twiddles w_{n1}^t, w_{n2}^t and inverses (of the LDS transform lengths)
+    fe_tw *w1pf = nullptr, *w1pi = nullptr, *w2pf = nullptr, *w2pi = nullptr;   // register pre-stages: w_{n1}^m, m < n1 / 2 (and inverse), the same for n2
     fe_tw *prescale = nullptr;                   // w_{B*n1}^t, t < B*n1
-    fe_tw *dit_last = nullptr;                   // [B][n1/2]: last-stage twiddles of every coset's DIT, w_{B*n1}^(j + B*k) (the pre-scale table regrouped per coset)
+    fe_tw *dit_last = nullptr;                   // [B][R][len/2], len = n1 / R, R = 2^pre_a: last-stage twiddles of every coset's (half-length) DIT, w_{B*n1}^(j + B*(h + R*k)) (the pre-scale table regrouped)
     // four-step twiddles of pass A as full tables in output order [k1][m2] (one multiplication per element instead of a two-level
     // lookup + two; the extra 16 B/element read is free: the pass runs at a tenth of the HBM bandwidth)
     tw4_t *tw4_lde = nullptr;                    // [Bc][n]: w_N^(m2 * (B*k1 + j)), local cosets j

@@ -51,6 +51,15 @@ struct NttArgs {
     uint32_t dit;              // pass A of an extension: coset DIT (pre-scale folded into the stage twiddles, taken from `prescale`)
     uint32_t groups, cosets, cols;   // extent of the linear block index: tile groups x cosets x columns (registers)
     uint32_t coset_fast;       // block order of first passes over several cosets, see ntt_block
+    // Register pre-stage (instances with PRE = 1): the pass's transform has TWICE the length of its LDS tile.  A workgroup owns one half h
+    // of the frequencies (k = 2 k' + h; h = upper half of the tile-group index): it loads the elements m and m + len of a column,
+    // forms u_h[m] in registers and runs the len-point LDS transform on it --
+    //   coset DIT (extension):  u_h = x[m] + (-1)^h c x[m + len], c = g^len, followed by the coset transform with shift g * w^h
+    //                           (virtual coset j + B h of the same pre-scale table);
+    //   DIF (everything else):  u_0 = x[m] + x[m + len],  u_1 = (x[m] - x[m + len]) * w_{2 len}^m  (pre_tw).
+    // n = 2^21 and 2^22 then stay on the two-pass plan with 1024 x 4 tiles (a third HBM pass costs more than the extra stage).
+    uint32_t pre;              // 0 / 1 (read by the PRE instances only)
+    const fe_tw* pre_tw;       // w_{2 len}^m, m < len (forward or inverse), DIF pre-stage
     fe_tw scale;
 };
 
@@ -90,10 +99,11 @@ __device__ __forceinline__ void ntt_block(const NttArgs& a, uint32_t& group, uin
 struct OutB {                                          // natural-order store X[k1 + n1 * k2] from the last round, 1/n of inverse transforms on the way
     static constexpr bool active = true;
     fe* __restrict__ dst /* at the tile's first k1 */; uint32_t k_stride, log_n2; bool scale; fe_tw s;
+    uint32_t pre_shift, h;                             // register pre-stage: the tile holds the frequencies k2 = (k' << pre_shift) + h
     struct Tok {};
     __device__ __forceinline__ Tok pre(uint32_t, uint32_t) const { return Tok{}; }
     __device__ __forceinline__ void put(uint32_t row, uint32_t t, const fe& v, const Tok&) const {
-        const uint32_t k2 = log_n2 ? (__brev(row) >> (32 - log_n2)) : 0u;
+        const uint32_t k2 = ((log_n2 ? (__brev(row) >> (32 - log_n2)) : 0u) << pre_shift) + h;
         dst[k2 * k_stride + t] = scale ? fe_mul_tw(v, s) : v;            // uniform base + 32-bit lane offset (at most 2^24 points)
     }
 };
@@ -110,25 +120,28 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
 // twiddles: that instance runs as ONE workgroup of 1024 lanes per CU; everything that fits 80 KiB runs as two workgroups per CU.
 // LOG_LEN / LOG_T != 0: the instance of ONE tile shape (2^LOG_LEN points x 2^LOG_T columns) -- its rounds are separate code with literal
 // strides (ntt_lds.h) and the tile index arithmetic folds into immediates; 0: any shape, from the arguments.
-template <int THREADS, int WPE = 4, bool PREFETCH = true, int LOG_LEN = 0, int LOG_T = 0>
+template <int THREADS, int WPE = 4, bool PREFETCH = true, int LOG_LEN = 0, int LOG_T = 0, int PRE = 0>
 __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* __restrict__ src_base, fe* __restrict__ dst_base) {
     constexpr int EPT = NTT_TILE_ELEMS / THREADS;
     fe* L = reinterpret_cast<fe*>(ntt_smem);
-    const uint32_t log_n1 = LOG_LEN ? (uint32_t)LOG_LEN : a.log_n1;
+    const uint32_t log_n1 = LOG_LEN ? (uint32_t)LOG_LEN : a.log_n1;          // length of the LDS transform (half of the pass's with PRE)
     const uint32_t log_t = LOG_T ? (uint32_t)LOG_T : a.tile, T = 1u << log_t, n1 = 1u << log_n1;
     fe_tw* TW = reinterpret_cast<fe_tw*>(L + n1 * T);
     uint32_t group, jl, col;
     ntt_block(a, group, jl, col);
+    uint32_t hh = 0;                                       // PRE: which half of the frequencies this workgroup produces
+    if (PRE) { const uint32_t half = a.groups >> 1; hh = group >= half ? 1u : 0u; group -= hh * half; }
     const uint32_t jg = a.j0 + jl;
     const fe* __restrict__ src0 = src_base + (size_t)col * a.src_col_stride + (size_t)jl * a.src_coset_stride;
     fe* __restrict__ dst0 = dst_base + (size_t)col * a.dst_col_stride + (size_t)jl * a.dst_coset_stride;
-    const uint32_t pmask = (1u << (a.log_b + log_n1)) - 1u;
+    const uint32_t pmask = (1u << (a.log_b + log_n1 + PRE)) - 1u;
+    const uint32_t jv = jg + (hh << a.log_b);              // PRE: the half-length transform of frequencies 2k' + h is the coset transform with shift g * w^h
     if (a.dit) {
         // stage twiddles of this coset: g^(n1/B) * w_B^k = w_{B_lde*n1}^((j + B_lde*k) * n1/B) straight from the pre-scale table
         const uint32_t in_lds = a.dit_last ? n1 / 2 : n1;                                     // entries + 1
         for (uint32_t i = threadIdx.x; i + 1 < in_lds; i += THREADS) {
             const uint32_t lb = 31u - (uint32_t)__clz(i + 1), k = i + 1 - (1u << lb);         // entry i: block size B = 2^(lb+1), index k
-            TW[i] = a.prescale[((jg + (k << a.log_b)) << (log_n1 - lb - 1)) & pmask];
+            TW[i] = a.prescale[((jv + (k << (a.log_b + PRE))) << (log_n1 - lb - 1)) & pmask];
         }
     } else
     for (uint32_t i = threadIdx.x; i < n1 / 2; i += THREADS) TW[dif_tw_slot(i)] = a.stage_tw[i];
@@ -144,7 +157,15 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
     // segment of a row is read by the same four lanes as before, in another order).
     const bool rot_a = a.dit && log_t == 2 && !NTT_NO_ROTATE_DEFINED;
 #define NTT_COL_A(idx) (rot_a ? (((idx) + ((idx) >> log_t)) & (T - 1)) : ((idx) & (T - 1)))
-#define NTT_FETCH_A1(e, var) if constexpr ((e) < EPT) { uint32_t idx = lane + (e) * THREADS; idx = idx < count ? idx : 0u; var = src[((idx >> log_t) << a.log_n2) + NTT_COL_A(idx)]; }
+    // PRE: the element is formed from the rows m and m + n1 of the column as it arrives (see NttArgs)
+    const fe_tw pre_c = (PRE && a.dit) ? a.prescale[(jg << log_n1) & pmask] : fe_tw{};       // c = g^len
+    auto pre_stage_a = [&](const fe& x0, const fe& x1, uint32_t row) -> fe {
+        if (a.dit) { const fe t = fe_mul_tw(x1, pre_c); return hh ? fe_sub(x0, t) : fe_add(x0, t); }
+        return hh ? fe_mul_tw(fe_sub(x0, x1), a.pre_tw[row]) : fe_add(x0, x1);
+    };
+#define NTT_FETCH_A1(e, var) if constexpr ((e) < EPT) { uint32_t idx = lane + (e) * THREADS; idx = idx < count ? idx : 0u; \
+        if constexpr (PRE != 0) { const uint32_t row_ = idx >> log_t; const fe x0_ = src[(row_ << a.log_n2) + NTT_COL_A(idx)], x1_ = src[((row_ + n1) << a.log_n2) + NTT_COL_A(idx)]; var = pre_stage_a(x0_, x1_, row_); } \
+        else var = src[((idx >> log_t) << a.log_n2) + NTT_COL_A(idx)]; }
 #define NTT_FETCH_A(tile) { const fe* __restrict__ src = src0 + (tile) * T; NTT_EACH(NTT_FETCH_A1) }
     const tw4_t* __restrict__ tw4 = a.tw4 + (size_t)jl * a.tw4_coset_stride;
     const uint32_t tile0 = group * a.tiles_per_block;
@@ -162,10 +183,10 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
         __syncthreads();
         if (PREFETCH && it + 1 < a.tiles_per_block) NTT_FETCH_A(tile + 1)
         if constexpr (LOG_LEN != 0) {
-            if (a.dit) lds_ntt_dit_fixed<THREADS, LOG_LEN, LOG_T>(L, TW, a.dit_last ? a.dit_last + (size_t)jg * (n1 / 2) : nullptr);
+            if (a.dit) lds_ntt_dit_fixed<THREADS, LOG_LEN, LOG_T>(L, TW, a.dit_last ? a.dit_last + (size_t)((jg << PRE) + hh) * (n1 / 2) : nullptr);
             else lds_ntt_dif_fixed<THREADS, LOG_LEN, LOG_T>(L, TW);
         } else {
-            if (a.dit) lds_ntt_dit<THREADS>(L, TW, log_n1, log_t, 1u, log_n1 + 1u, a.dit_last ? a.dit_last + (size_t)jg * (n1 / 2) : nullptr);
+            if (a.dit) lds_ntt_dit<THREADS>(L, TW, log_n1, log_t, 1u, log_n1 + 1u, a.dit_last ? a.dit_last + (size_t)((jg << PRE) + hh) * (n1 / 2) : nullptr);
             else lds_ntt_dif<THREADS>(L, TW, log_n1, log_t, 1u, log_n1 + 1u);
         }
         // read-out in batches of RB elements per lane: the twiddle loads of a batch are in flight together (the 512-lane instance also
@@ -188,7 +209,7 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
                 ok[q] = idx < count;
                 idx = ok[q] ? idx : 0u;
                 const uint32_t t = idx & (T - 1), r = idx >> log_t;
-                const uint32_t k1 = a.dit ? r : __brev(r) >> (32 - log_n1);        // DIT leaves the tile in natural order
+                const uint32_t k1 = ((a.dit ? r : __brev(r) >> (32 - log_n1)) << PRE) + hh;        // DIT leaves the tile in natural order; PRE: frequencies 2 k' + h
                 off[q] = (k1 << a.log_n2) + t;
                 v[q] = L[idx];
                 w[q] = tw[off[q]];
@@ -206,15 +227,17 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
 }
 
 // WPE: waves per SIMD the instance is compiled for (its register budget); PREFETCH: the next tile travels in registers during the rounds
-template <int THREADS, int WPE = 4, bool PREFETCH = true, int LOG_LEN = 0, int LOG_T = 0>
+template <int THREADS, int WPE = 4, bool PREFETCH = true, int LOG_LEN = 0, int LOG_T = 0, int PRE = 0>
 __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_b(NttArgs a, const fe* __restrict__ src_base, fe* __restrict__ dst_base) {
     constexpr int EPT = NTT_TILE_ELEMS / THREADS;
     fe* L = reinterpret_cast<fe*>(ntt_smem);
-    const uint32_t log_n2 = LOG_LEN ? (uint32_t)LOG_LEN : a.log_n2;
+    const uint32_t log_n2 = LOG_LEN ? (uint32_t)LOG_LEN : a.log_n2;          // length of the LDS transform (half of the pass's with PRE)
     const uint32_t log_t = LOG_T ? (uint32_t)LOG_T : a.tile, T = 1u << log_t, n2 = 1u << log_n2;
     fe_tw* TW = reinterpret_cast<fe_tw*>(L + n2 * T);
     uint32_t g, jl, col;
     ntt_block(a, g, jl, col);
+    uint32_t hh = 0;                                       // PRE: which half of the frequencies this workgroup produces (two-pass plans: no batches)
+    if (PRE) { const uint32_t half = a.groups >> 1; hh = g >= half ? 1u : 0u; g -= hh * half; }
     const uint32_t batch = g & ((1u << a.batch_log) - 1u), group = g >> a.batch_log;
     const fe* __restrict__ src = src_base + (size_t)col * a.src_col_stride + (size_t)jl * a.src_coset_stride + (size_t)batch * a.src_batch_stride;
     fe* __restrict__ dst = dst_base + (size_t)col * a.dst_col_stride + (size_t)jl * a.dst_coset_stride + (size_t)batch * a.dst_batch_stride;
@@ -228,7 +251,11 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_b(NttArgs a, const fe* 
     const bool colfast_b = log_t == 2 && !NTT_NO_ROTATE_DEFINED;
 #define NTT_ROW_B(idx) (colfast_b ? ((idx) & (T - 1)) : ((idx) >> log_n2))
 #define NTT_M2_B(idx) (colfast_b ? ((idx) >> log_t) : ((idx) & (n2 - 1)))
-#define NTT_FETCH_B1(e, var) if constexpr ((e) < EPT) { uint32_t idx = lane + (e) * THREADS; idx = idx < count ? idx : 0u; var = srct[NTT_ROW_B(idx) * row_stride + NTT_M2_B(idx)]; }
+    // PRE (DIF pre-stage, see NttArgs): u_0 = y[m] + y[m + n2], u_1 = (y[m] - y[m + n2]) * w_{2 n2}^m
+#define NTT_FETCH_B1(e, var) if constexpr ((e) < EPT) { uint32_t idx = lane + (e) * THREADS; idx = idx < count ? idx : 0u; \
+        if constexpr (PRE != 0) { const uint32_t m_ = NTT_M2_B(idx); const fe* p_ = srct + NTT_ROW_B(idx) * row_stride + m_; const fe x0_ = p_[0], x1_ = p_[n2]; \
+                                  var = hh ? fe_mul_tw(fe_sub(x0_, x1_), a.pre_tw[m_]) : fe_add(x0_, x1_); } \
+        else var = srct[NTT_ROW_B(idx) * row_stride + NTT_M2_B(idx)]; }
 #define NTT_FETCH_B(tile) { const fe* __restrict__ srct = src + (size_t)((tile) * T) * a.src_row_stride; NTT_EACH(NTT_FETCH_B1) }
     const uint32_t row_stride = (uint32_t)a.src_row_stride;
     const uint32_t tile0 = group * a.tiles_per_block;
@@ -244,7 +271,7 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_b(NttArgs a, const fe* 
 #undef NTT_PUT_B
         __syncthreads();
         if (PREFETCH && it + 1 < a.tiles_per_block) NTT_FETCH_B(tile0 + it + 1)
-        const OutB out{dst + k1_0, (uint32_t)a.dst_k_stride, log_n2, a.has_scale != 0, a.scale};
+        const OutB out{dst + k1_0, (uint32_t)a.dst_k_stride, log_n2, a.has_scale != 0, a.scale, (uint32_t)PRE, hh};
 #if defined(NTT_TW_GLOBAL_B)
         const fe_tw* Wuse = a.stage_tw;          // experiment: stage twiddles through the vector cache instead of LDS
 #else
@@ -499,6 +526,10 @@ static void ntt_raise_lds_limit(dst_ctx* c) {                  // tile + stage t
     (void)hipFuncSetAttribute((const void*)ntt_pass_b<512, 4, true, 8, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ntt_pass_b<1024, 8, true, 10, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     (void)hipFuncSetAttribute((const void*)ntt_pass_b<1024, 8, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ntt_pass_a<1024, 8, false, 10, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ntt_pass_b<1024, 8, false, 10, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ntt_pass_a<512, 4, true, 0, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)ntt_pass_b<512, 4, true, 0, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 
     raised[c->device] = true;
 }
@@ -527,6 +558,7 @@ static void ntt_launch(dst_ctx* c, bool pass_b, NttArgs& a, size_t groups, size_
     const uint32_t stages = pass_b ? a.log_n2 : a.log_n1;
     double mults = (!pass_b && a.dit) ? 0.5 * stages : ((stages & 1u) ? 0.5 * (stages - 1) : (stages >= 2 ? 0.5 * stages - 0.75 : 0.0));
     if (!pass_b) mults += ((!a.dit && a.prescale != nullptr) ? 1.0 : 0.0) + (NTT_TW4_PAIRS ? 1.0 : 21.0 / 18.0); else if (a.has_scale) mults += 1.0;     // the four-step product: 18 or 21 mads
+    if (a.pre) mults += (!pass_b && a.dit) ? 1.0 : 0.5;        // register pre-stage: c * x[m + len] in both halves of a coset DIT, the twiddle of the odd half otherwise
     const double elements = (double)groups * a.tiles_per_block * ((size_t)1 << a.tile) * ((size_t)1 << stages) * cosets * cols;
     KScope ks_(c, name, bytes, true, 18.0 * mults * elements);
     const char* wv = getenv("DISTAFF_NTT_WAVES");
@@ -535,6 +567,14 @@ static void ntt_launch(dst_ctx* c, bool pass_b, NttArgs& a, size_t groups, size_
     const bool fixed = stages == 10 && a.tile == 2 && !any_shape;      // 1024 x 4 tiles (n = 2^20) have their own instances,
     const bool fixed84 = stages == 8 && a.tile == 4 && !any_shape;     // and so have 256 x 16 tiles (n = 2^16, the first two passes of three-pass plans)
     if (a.debug & 1u) ntt_report_occupancy(name, pass_b, eight || !two ? 1024 : 512, eight, lds);
+    if (a.pre) {
+        // register pre-stage instances (NttArgs::pre): the 1024 x 4 shape of n = 2^21 / 2^22 compiled for the shape, any other shape (tests) from the arguments
+        if (pass_b && fixed) hipLaunchKernelGGL((ntt_pass_b<1024, 8, false, 10, 2, 1>), grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
+        else if (!pass_b && fixed) hipLaunchKernelGGL((ntt_pass_a<1024, 8, false, 10, 2, 1>), grid, dim3(1024), lds, c->stream, a, a.src, a.dst);
+        else if (pass_b) hipLaunchKernelGGL((ntt_pass_b<512, 4, true, 0, 0, 1>), grid, dim3(512), lds, c->stream, a, a.src, a.dst);
+        else hipLaunchKernelGGL((ntt_pass_a<512, 4, true, 0, 0, 1>), grid, dim3(512), lds, c->stream, a, a.src, a.dst);
+        return;
+    }
     if (two) {
         // 1024-point tiles (five LDS rounds per tile): two workgroups of 1024 lanes = 8 waves per SIMD, 64 registers, no register prefetch -- the
         // other workgroup's rounds cover a workgroup's loads (measured 20.2 against 20.55 ms of extension per 2^20 proof, same box); shorter
@@ -589,22 +629,27 @@ static void launch_pass_lds(dst_ctx* c, bool pass_b, const fe* src, size_t src_c
     if (!pass_b) {
         a.tw4 = lde ? c->tw4_lde + (size_t)skip * c->n : (inverse ? c->tw4_inv : c->tw4_fwd); a.tw4_coset_stride = lde ? c->n : 0;
         a.stage_tw = inverse ? c->w1i : c->w1f; a.tile = (uint32_t)__builtin_ctz(p.tile_a);
-        const size_t n1 = (size_t)1 << p.log_n1;
-        const int mode = lde ? ntt_first_pass_mode(n1, p.tile_a) : 0;
+        a.pre = p.pre_a; a.pre_tw = inverse ? c->w1pi : c->w1pf;
+        a.log_n1 = p.log_n1 - p.pre_a;                                 // the kernel's LDS transform; with the pre-stage the pass covers twice that
+        const size_t n1 = (size_t)1 << a.log_n1;
+        int mode = lde ? ntt_first_pass_mode(n1, p.tile_a) : 0;
+        if (p.pre_a && lde && mode == 0) mode = 2;                     // the pre-stage is written for the coset DIT (tiles of at most 1024 x 4: always fits)
         a.dit = mode ? 1u : 0u; a.dit_last = mode == 2 ? c->dit_last : nullptr;
         const size_t lds_a = n1 * p.tile_a * sizeof(fe) + (mode == 1 ? n1 : n1 / 2) * sizeof(fe_tw);
         const uint32_t tiles = (1u << p.log_n2) / p.tile_a;
-        a.tiles_per_block = ntt_tiles_per_block(tiles, cosets * cols);
-        a.coset_fast = ntt_coset_fast(tiles / a.tiles_per_block, cosets);
-        ntt_launch(c, false, a, tiles / a.tiles_per_block, cosets, cols, lds_a, "ntt_pass_a", 16.0 * c->n * cols * (lde ? (1 + cosets) : 2 * cosets));
+        a.tiles_per_block = ntt_tiles_per_block(tiles, (cosets * cols) << p.pre_a);
+        a.coset_fast = ntt_coset_fast((size_t)(tiles / a.tiles_per_block) << p.pre_a, cosets);
+        ntt_launch(c, false, a, (size_t)(tiles / a.tiles_per_block) << p.pre_a, cosets, cols, lds_a, "ntt_pass_a", 16.0 * c->n * cols * (lde ? (1 + cosets) : 2 * cosets));
     } else {
         a.stage_tw = inverse ? c->w2i : c->w2f; a.tile = (uint32_t)__builtin_ctz(p.tile_b);
+        a.pre = p.pre_b; a.pre_tw = inverse ? c->w2pi : c->w2pf;
+        a.log_n2 = p.log_n2 - p.pre_b;
         a.src_row_stride = (size_t)1 << p.log_n2; a.dst_k_stride = (size_t)1 << p.log_n1; a.batch_log = 0; a.src_batch_stride = a.dst_batch_stride = 0;
-        const size_t n2 = (size_t)1 << p.log_n2;
+        const size_t n2 = (size_t)1 << a.log_n2;
         const size_t lds_b = n2 * p.tile_b * sizeof(fe) + (n2 / 2) * sizeof(fe_tw);
         const uint32_t tiles = (1u << p.log_n1) / p.tile_b;
-        a.tiles_per_block = ntt_tiles_per_block(tiles, cosets * cols);
-        ntt_launch(c, true, a, tiles / a.tiles_per_block, cosets, cols, lds_b, "ntt_pass_b", 32.0 * c->n * cols * cosets);
+        a.tiles_per_block = ntt_tiles_per_block(tiles, (cosets * cols) << p.pre_b);
+        ntt_launch(c, true, a, (size_t)(tiles / a.tiles_per_block) << p.pre_b, cosets, cols, lds_b, "ntt_pass_b", 32.0 * c->n * cols * cosets);
     }
 }
 

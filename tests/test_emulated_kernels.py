@@ -22,6 +22,9 @@ SELECTION = [
     "test_fibonacci_all_phases[10]",
     "test_boundary_constraints_by_evaluation[]",
     "test_combination_and_composition_as_whole_array_steps",
+    "test_all_phases_with_register_pre_stages",
+    "test_lde_every_tile_length[pre-13-5]",
+    "test_lde_every_tile_length[pre-16-5]",
     "test_other_program_shapes",
     "test_program_shapes_with_stack_depth_5_to_8",
     "test_blowup_16_and_64",

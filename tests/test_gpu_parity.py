@@ -118,6 +118,26 @@ def test_boundary_constraints_by_evaluation(oracle, monkeypatch, instance):
     _check_all_phases(oracle, D, oracle.Trace("begin dup.4 add mul swap.2 add drop drop block push.9 mul end end", [1, 2, 3, 4]), num_outputs=2)
 
 
+def test_all_phases_with_register_pre_stages(oracle, monkeypatch):
+    """DISTAFF_NTT=pre: every transform of a proof (interpolation, extension, inverse coset transforms of the combination, constraint and
+    composition extensions) through the pre-stage instances the library takes by itself at 2^21 / 2^22 steps -- all intermediates
+    against the oracle, on one context and sharded over four ranks."""
+    import distaff_amd as D
+    monkeypatch.setenv("DISTAFF_NTT", "pre")
+    _check_all_phases(oracle, D, oracle.fibonacci_trace(1 << 10))
+    t = oracle.fibonacci_trace(1 << 10)
+    op = oracle.Prover.from_trace(t, 1, grinding=8)
+    expected = op.prove()
+    ctxs = []
+    for r in range(4):
+        ctx = D.Context(10, t.width, t.ctx_depth, t.loop_depth, rank=r, world=4, grinding=8)
+        ctx.upload_owned(t.columns)
+        ctxs.append(ctx)
+    assert D.prove_sharded_local(ctxs, t.public_inputs, op.outputs) == expected
+    for ctx in ctxs:
+        ctx.close()
+
+
 def test_combination_and_composition_as_whole_array_steps(oracle, monkeypatch):
     """DISTAFF_COMBINE=steps: combine_polys and the DEEP composition as the reference's sequence of whole-array steps (8n-coefficient boundary
     polynomials, three divisions, additions; copy / C(z) / division / multiply-adds) instead of the fused passes the library takes by
@@ -468,12 +488,15 @@ def _random_columns(W, n, seed):
 @pytest.mark.parametrize("family,log_n,log_blowup", [("reg", 13, 5), ("reg", 14, 5), ("reg", 15, 4), ("reg", 16, 5), ("reg", 17, 4), ("reg", 18, 4),
                                                       ("reg", 19, 4), ("reg", 20, 4), ("reg", 21, 4), ("reg", 22, 4), ("reg", 23, 4), ("reg", 24, 4),
                                                       ("lds", 13, 5), ("lds", 16, 5), ("lds", 19, 4), ("lds", 22, 4), ("auto", 21, 4), ("auto", 22, 4), ("auto", 23, 4), ("auto", 24, 4), ("3pass", 20, 5), ("dif", 16, 5), ("dif", 21, 4), ("dit", 16, 5), ("dit", 20, 5), ("dit2", 13, 5), ("dit2", 20, 5),
-                                                      ("waves4", 20, 5), ("waves8", 13, 5), ("waves8", 16, 5), ("order0", 16, 5), ("order0", 20, 5), ("generic", 20, 5)])
+                                                      ("waves4", 20, 5), ("waves8", 13, 5), ("waves8", 16, 5), ("order0", 16, 5), ("order0", 20, 5), ("generic", 20, 5),
+                                                      ("pre", 13, 5), ("pre", 16, 5), ("pre", 20, 5), ("3pass", 21, 4), ("3pass", 22, 4)])
 def test_lde_every_tile_length(oracle, monkeypatch, family, log_n, log_blowup):
     """Both NTT kernel families (register-radix: every tile length 2^6 .. 2^12 in both passes; LDS radix-2) and the default per-pass
     choice at the largest size, through size-independent properties that pin the
     transforms point-wise: the interpolated polynomial evaluated by the oracle (Horner) at trace-domain points gives the trace, and at
-    LDE-domain points gives the device's extension -- including the largest trace length (BASELINE config 5: 2^24, blowup 16)."""
+    LDE-domain points gives the device's extension -- including the largest trace length (BASELINE config 5: 2^24, blowup 16).
+    "auto" at 2^21 / 2^22 is the two-pass plan with a register pre-stage (2048-point factors on 1024 x 4 tiles); "pre" forces pre-stages
+    onto smaller transforms, "3pass" the three-pass plan onto sizes that would not take it."""
     import distaff_amd as D
     O = oracle
     n, B, W = 1 << log_n, 1 << log_blowup, 16

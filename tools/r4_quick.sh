@@ -9,7 +9,7 @@ PY
 for round in 1 2; do
 for spec in "$@"; do
   name=${spec%%:*}; envs=${spec#*:}; [ "$envs" = "$spec" ] && envs=""
-  ( IFS=,; for kv in $envs; do export "$kv"; done
+  ( IFS=, read -ra kvs <<< "$envs"; for kv in "${kvs[@]}"; do [ -n "$kv" ] && export "$kv"; done
     python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-upload-leg --no-verify $EXTRA > $O/${name}_$round.json 2> $O/${name}_$round.err )
 done; done
 python - <<'PY'
