@@ -513,10 +513,9 @@ int dst_internal_boundary_quotients(dst_ctx* c, const fe* draws344, fe* q4, size
     // "+ p" lands on the next array
     int r = dst_internal_boundary_polys(c, draws344, nullptr, nullptr, q4 + 1, q4 + stride + 1, q4 + 2 * stride + 1, q4 + 3 * stride + 1);
     if (r) return r;
-    k_syn_div(c, q4, n + 1, fe_one());
-    k_syn_div(c, q4 + stride, n + 1, fe_one());
-    k_syn_div(c, q4 + 2 * stride, n + 1, c->x_last);
-    k_syn_div(c, q4 + 3 * stride, n + 1, c->x_last);
+    fe* arrays[4] = {q4, q4 + stride, q4 + 2 * stride, q4 + 3 * stride};
+    const fe divisors[4] = {fe_one(), fe_one(), c->x_last, c->x_last};
+    k_syn_div_batch(c, arrays, divisors, 4, n + 1);            // one set of launches for the four
     return DST_OK;
 }
 
@@ -620,12 +619,14 @@ static int compose_impl(dst_ctx* c, const uint8_t* draws_bytes, uint8_t* trace_a
     fe* d_tz1 = d_draws + 520; fe* d_tz2 = d_tz1 + 128; fe* d_cz = d_tz2 + 128;
     HIP_TRY(c, hipMemcpyAsync(d_draws, draws.data(), 516 * 16, hipMemcpyHostToDevice, c->stream));
     // trace_table.rs:206-261
+    const bool steps = dst_internal_combine_by_steps();
+    const fe zz[2] = {z, next_z};
     k_horner(c, c->polys, W, n, z, d_tz1);
     k_horner(c, c->polys, W, n, next_z, d_tz2);
     fe* t1 = c->cwork; fe* t2 = c->cwork + n; fe* cp = c->cwork + D;
     k_lincomb2(c, c->polys, W, n, d_draws + 1, 256, t1, t2);          // both combinations in one pass over the trace polynomials
     const size_t inc = 6 * n + 1;                                // get_incremental_trace_degree (utils/mod.rs:20)
-    if (dst_internal_combine_by_steps()) {
+    if (steps) {
         k_sub_dot_at0(c, t1, d_tz1, d_draws + 1, W);
         k_sub_dot_at0(c, t2, d_tz2, d_draws + 257, W);
         k_syn_div(c, t1, n, z);
@@ -644,8 +645,8 @@ static int compose_impl(dst_ctx* c, const uint8_t* draws_bytes, uint8_t* trace_a
         // The constant term of a dividend enters no coefficient of its quotient by (x - b), so the subtractions of T(z), T(z g) and C(z)
         // (trace_table.rs:226-233, constraint_poly.rs:44) need not be made -- and C(z) need not be evaluated.  The division of the
         // constraint polynomial writes the composition polynomial directly: k3 * quotient + (k1 + k2 x^inc) * t1.
-        k_syn_div(c, t1, n, z);
-        k_syn_div(c, t2, n, next_z);
+        fe* both[2] = {t1, t2};
+        k_syn_div_batch(c, both, zz, 2, n);
         k_add(c, t1, t2, n);
         k_syn_div_compose(c, c->cpoly, c->comp_poly, D, z, t1, n, inc, k1, k2, k3);
     }

@@ -233,6 +233,7 @@ int k_eval_constraints(dst_ctx* c, const fe* coeffs_dev, const fe* tc_dev, int64
 int k_constraint_check(dst_ctx* c, int64_t* bad_step);                                  // after a stream synchronisation: the failing step recorded by the last evaluation, if any
 // polynomial helpers
 void k_syn_div(dst_ctx* c, fe* a, size_t len, fe b);                                    // polynom.rs:190 semantics, in place
+void k_syn_div_batch(dst_ctx* c, fe* const* a, const fe* b, int count, size_t len);                 // a[k] <- a[k] / (x - b[k]) in place, count <= 4 arrays of `len` coefficients, one set of launches
 void k_syn_div_compose(dst_ctx* c, const fe* a, fe* out, size_t len, fe b, const fe* t, size_t tn, size_t inc, fe k1, fe k2, fe k3);   // out = k3 * a / (x - b) + (k1 + k2 x^inc) * t
 void k_combine_fused(dst_ctx* c, const fe* work, const fe* q4, size_t q_stride, fe* cpoly);   // kernels_ntt.hip: 8-point step + division + boundary quotients -> constraint polynomial
 void k_syn_div_expanded(dst_ctx* c, const fe* a, fe* out, size_t len, size_t degree, fe exception);

@@ -101,6 +101,40 @@ __global__ void __launch_bounds__(HASH_THREADS) merkle_level_kernel(const digest
     store_digest(out + i, h);
 }
 
+// two levels per launch for the wide levels: a lane turns four consecutive children into their two parents and the grandparent (three
+// compressions, every lane busy), so the level in between is written but not read back and a tree needs half as many wide launches
+__global__ void __launch_bounds__(HASH_THREADS) merkle_level2_kernel(const digest* __restrict__ children, digest* __restrict__ parents, digest* __restrict__ grand, size_t count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // grandparent index, count of them
+    if (i >= count) return;
+    uint32_t h0[8], h1[8], g[8];
+    {
+        const uint4* p = reinterpret_cast<const uint4*>(children + 4 * i);
+        uint4 a = p[0], b = p[1], c = p[2], d = p[3];
+        uint32_t m[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+        b3_hash64(m, h0);
+        a = p[4]; b = p[5]; c = p[6]; d = p[7];
+        uint32_t m2[16] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, d.x, d.y, d.z, d.w};
+        b3_hash64(m2, h1);
+    }
+    store_digest(parents + 2 * i, h0);
+    store_digest(parents + 2 * i + 1, h1);
+    uint32_t m[16];
+#pragma unroll
+    for (int w = 0; w < 8; w++) { m[w] = h0[w]; m[8 + w] = h1[w]; }
+    b3_hash64(m, g);
+    store_digest(grand + i, g);
+}
+#define MERKLE_LEVEL2_MIN ((size_t)1 << 19)        // grandparents per launch from which the fused form is used (below: the subtree kernel takes over)
+// children[0 .. 4 * count) -> nodes[2 * count .. 4 * count) and nodes[count .. 2 * count)   (heap positions of the two levels above)
+static bool merkle_two_levels(dst_ctx* c, const digest* children, digest* nodes, size_t count) {
+    size_t min_count = MERKLE_LEVEL2_MIN;
+    if (const char* e = getenv("DISTAFF_MERKLE_LEVEL2_LOG")) min_count = (size_t)1 << (atoi(e) < 0 ? 0 : atoi(e) > 40 ? 40 : atoi(e));      // tests: the fused form on small trees
+    if (count < min_count || count == 0 || getenv("DISTAFF_MERKLE_LEVELS")) return false;
+    KScope ks_(c, "merkle_level2_kernel", 96.0 * 3 * count);
+    hipLaunchKernelGGL(merkle_level2_kernel, dim3((unsigned)((count + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream, children, nodes + 2 * count, nodes + count, count);
+    return true;
+}
+
 // the top of the tree in one workgroup: nodes[count .. 2*count) are already valid, fills nodes[1 .. count)
 __global__ void __launch_bounds__(HASH_THREADS) merkle_top_kernel(digest* nodes, uint32_t count) {
     for (uint32_t cnt = count >> 1; cnt >= 1; cnt >>= 1) {
@@ -162,6 +196,7 @@ static void merkle_upper_levels(dst_ctx* c, digest* nodes, size_t count) {
             count /= 512;
             continue;
         }
+        if (merkle_two_levels(c, nodes + count, nodes, count >> 2)) { count >>= 2; continue; }
         size_t cnt = count >> 1;
         { KScope ks_(c, "merkle_level_kernel", 96.0 * cnt); hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((cnt + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream,
                            (const digest*)(nodes + count), nodes + cnt, cnt); }
@@ -171,6 +206,7 @@ static void merkle_upper_levels(dst_ctx* c, digest* nodes, size_t count) {
 }
 
 void k_merkle_levels(dst_ctx* c, const digest* leaves, digest* nodes, size_t num_leaves) {
+    if (merkle_two_levels(c, leaves, nodes, num_leaves >> 2)) { merkle_upper_levels(c, nodes, num_leaves >> 2); return; }
     size_t cnt = num_leaves >> 1;
     { KScope ks_(c, "merkle_level_kernel", 96.0 * cnt); hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((cnt + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream,
                        leaves, nodes + cnt, cnt); }
@@ -271,6 +307,7 @@ void k_fri_leaves(dst_ctx* c, int layer) { k_fri_leaves_at(c, c->fri_e[layer], c
 //      and finishes the replicated upper part of the tree. ---------------------------------------------------------------------
 void k_merkle_local_levels(dst_ctx* c, digest* nodes, size_t count, size_t stop_count) {      // nodes[count..2count) valid on entry
     while (count > stop_count) {
+        if ((count >> 2) >= stop_count && merkle_two_levels(c, nodes + count, nodes, count >> 2)) { count >>= 2; continue; }
         size_t cnt = count >> 1;
         { KScope ks_(c, "merkle_level_kernel", 96.0 * cnt); hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((cnt + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream,
                            (const digest*)(nodes + count), nodes + cnt, cnt); }
@@ -278,6 +315,7 @@ void k_merkle_local_levels(dst_ctx* c, digest* nodes, size_t count, size_t stop_
     }
 }
 void k_merkle_levels_to(dst_ctx* c, const digest* leaves, digest* nodes, size_t num_leaves, size_t stop_count) {
+    if ((num_leaves >> 2) >= stop_count && merkle_two_levels(c, leaves, nodes, num_leaves >> 2)) { k_merkle_local_levels(c, nodes, num_leaves >> 2, stop_count); return; }
     size_t cnt = num_leaves >> 1;
     { KScope ks_(c, "merkle_level_kernel", 96.0 * cnt); hipLaunchKernelGGL(merkle_level_kernel, dim3((unsigned)((cnt + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream,
                        leaves, nodes + cnt, cnt); }

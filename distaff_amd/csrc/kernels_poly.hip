@@ -235,6 +235,61 @@ void k_syn_div_compose(dst_ctx* c, const fe* a, fe* out, size_t len, fe b, const
     SynDivEpilogue ep{fe_tw_make(k1), fe_tw_make(k2), fe_tw_make(k3), t, tn, inc};
     { KScope ks_(c, "syn_div_chunk_out_kernel", 32.0 * len); hipLaunchKernelGGL(syn_div_chunk_out_kernel, dim3((unsigned)chunks), dim3(PT), 0, c->stream, a, out, len, p, chunks > 1 ? (const fe*)scr : (const fe*)nullptr, ep); }
 }
+// ---- several divisions / evaluations in one set of launches -------------------------------------------------------------------------
+// Up to four arrays of the same length, each with its own divisor (x - b_k), through the blocked division above: blockIdx.y selects the array.
+// (A division of 2^20 coefficients is three launches of a few hundred workgroups; the boundary quotients need four of them and the DEEP
+// composition two -- batched they are three launches of four times the width.)  b = 1 (plain suffix sums) goes the same way.
+struct SynDivBatch { fe* a[4]; fe* sums[4]; SynDivArgs p[4]; };
+__global__ void __launch_bounds__(PT) syn_div_sums_batch_kernel(SynDivBatch B, size_t len) {
+    __shared__ fe tile[SD_TILE];
+    __shared__ fe sh[PT + 1];
+    const SynDivArgs& p = B.p[blockIdx.y];
+    fe v[8], e = fe_zero();
+    sd_load_chunk(tile, B.a[blockIdx.y], len, v);
+#pragma unroll
+    for (int j = 7; j >= 0; j--) e = fe_add(fe_mul_tw(e, p.b), v[j]);
+    const fe y = sd_lane_scan(sh, p, e, fe_zero());
+    if (threadIdx.x == 0) B.sums[blockIdx.y][blockIdx.x] = y;
+}
+__global__ void __launch_bounds__(PT) syn_div_chunk_batch_kernel(SynDivBatch B, size_t len, int use_right) {
+    __shared__ fe tile[SD_TILE];
+    __shared__ fe sh[PT + 1];
+    const SynDivArgs& p = B.p[blockIdx.y];
+    fe* a = B.a[blockIdx.y];
+    fe v[8], q[8], e = fe_zero();
+    sd_load_chunk(tile, a, len, v);
+#pragma unroll
+    for (int j = 7; j >= 0; j--) { q[j] = e; e = fe_add(fe_mul_tw(e, p.b), v[j]); }
+    (void)sd_lane_scan(sh, p, e, use_right ? B.sums[blockIdx.y][blockIdx.x] : fe_zero());
+    fe x = sh[threadIdx.x + 1];
+#pragma unroll
+    for (int j = 7; j >= 0; j--) {
+        tile[sd_slot(threadIdx.x * 8 + j)] = fe_add(q[j], x);
+        x = fe_mul_tw(x, p.b);
+    }
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * SD_CHUNK;
+#pragma unroll
+    for (int r = 0; r < 8; r++) { const uint32_t i = r * PT + threadIdx.x; if (base + i < len) a[base + i] = tile[sd_slot(i)]; }
+}
+// a[k] <- a[k] / (x - b[k]) in place, k < count <= 4, all of `len` coefficients; scratch: count * (chunks + chunks' + ..) elements
+static void syn_div_batch_rec(dst_ctx* c, fe* const* a, const fe* b, int count, size_t len, fe* scratch) {
+    const size_t chunks = (len + SD_CHUNK - 1) / SD_CHUNK;
+    SynDivBatch B{};
+    for (int k = 0; k < count; k++) { B.a[k] = a[k]; B.sums[k] = scratch + (size_t)k * chunks; B.p[k] = syn_div_args(b[k]); }
+    if (chunks > 1) {
+        { KScope ks_(c, "syn_div_sums_batch_kernel", 16.0 * len * count); hipLaunchKernelGGL(syn_div_sums_batch_kernel, dim3((unsigned)chunks, (unsigned)count), dim3(PT), 0, c->stream, B, len); }
+        fe bc[4]; fe* sub[4];
+        for (int k = 0; k < count; k++) { bc[k] = b[k]; for (int i = 0; i < 11; i++) bc[k] = fe_mul(bc[k], bc[k]); sub[k] = B.sums[k]; }      // b^2048
+        syn_div_batch_rec(c, sub, bc, count, chunks, scratch + (size_t)count * chunks);
+    }
+    { KScope ks_(c, "syn_div_chunk_batch_kernel", 32.0 * len * count); hipLaunchKernelGGL(syn_div_chunk_batch_kernel, dim3((unsigned)chunks, (unsigned)count), dim3(PT), 0, c->stream, B, len, chunks > 1 ? 1 : 0); }
+}
+void k_syn_div_batch(dst_ctx* c, fe* const* a, const fe* b, int count, size_t len) {
+    for (int k = 0; k < count; k++) if (fe_is_zero(b[k]) || getenv("DISTAFF_SYN_DIV_TABLES")) { for (int q = 0; q < count; q++) k_syn_div(c, a[q], len, b[q]); return; }   // the special forms keep their own path
+    syn_div_batch_rec(c, a, b, count, len, c->scratch);
+}
+
 void k_syn_div(dst_ctx* c, fe* a, size_t len, fe b) {
     unsigned g = (unsigned)((len + PT - 1) / PT);
     fe* scr = c->scratch;

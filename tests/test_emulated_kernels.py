@@ -23,6 +23,7 @@ SELECTION = [
     "test_boundary_constraints_by_evaluation[]",
     "test_combination_and_composition_as_whole_array_steps",
     "test_all_phases_with_register_pre_stages",
+    "test_merkle_levels_two_per_launch_on_small_trees",
     "test_lde_every_tile_length[pre-13-5]",
     "test_lde_every_tile_length[pre-16-5]",
     "test_other_program_shapes",

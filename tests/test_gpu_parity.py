@@ -118,6 +118,27 @@ def test_boundary_constraints_by_evaluation(oracle, monkeypatch, instance):
     _check_all_phases(oracle, D, oracle.Trace("begin dup.4 add mul swap.2 add drop drop block push.9 mul end end", [1, 2, 3, 4]), num_outputs=2)
 
 
+def test_merkle_levels_two_per_launch_on_small_trees(oracle, monkeypatch):
+    """The wide levels of every tree are built two per launch (a lane hashes four children into two parents and the grandparent); trees
+    of the sizes the oracle can rebuild are below the width at which the library switches to that form, so it is forced here
+    (DISTAFF_MERKLE_LEVEL2_LOG): all node arrays of all trees against the oracle, single context and sharded (local levels)."""
+    import distaff_amd as D
+    monkeypatch.setenv("DISTAFF_MERKLE_LEVEL2_LOG", "3")
+    _check_all_phases(oracle, D, oracle.fibonacci_trace(1 << 10))
+    t = oracle.fibonacci_trace(1 << 9)
+    op = oracle.Prover.from_trace(t, 1, grinding=8)
+    expected = op.prove()
+    for world in (2, 8):
+        ctxs = []
+        for r in range(world):
+            ctx = D.Context(9, t.width, t.ctx_depth, t.loop_depth, rank=r, world=world, grinding=8)
+            ctx.upload(t.columns)
+            ctxs.append(ctx)
+        assert D.prove_sharded_local(ctxs, t.public_inputs, op.outputs) == expected
+        for ctx in ctxs:
+            ctx.close()
+
+
 def test_all_phases_with_register_pre_stages(oracle, monkeypatch):
     """DISTAFF_NTT=pre: every transform of a proof (interpolation, extension, inverse coset transforms of the combination, constraint and
     composition extensions) through the pre-stage instances the library takes by itself at 2^21 / 2^22 steps -- all intermediates
