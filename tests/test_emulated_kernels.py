@@ -25,7 +25,6 @@ SELECTION = [
     "test_all_phases_with_register_pre_stages",
     "test_merkle_levels_two_per_launch_on_small_trees",
     "test_lde_every_tile_length[pre-13-5]",
-    "test_lde_every_tile_length[pre-16-5]",
     "test_other_program_shapes",
     "test_program_shapes_with_stack_depth_5_to_8",
     "test_blowup_16_and_64",
@@ -36,7 +35,6 @@ SELECTION = [
     "test_tiny_traces_of_32_and_16_rows",
     "test_wide_rows_two_chunk_leaves",
     "test_sharded_prover_equals_single_gpu[2]",
-    "test_sharded_prover_equals_single_gpu[8]",
     "test_sharded_prover_reports_invalid_trace",
     "test_sharded_fri_protocol_state_errors",
     "test_prove_sharded_behind_the_c_abi[2-8-None-False]",
@@ -62,7 +60,6 @@ SELECTION = [
     "test_lde_every_tile_length[dit2-13-5]",
     "test_lde_every_tile_length[waves8-13-5]",
     "test_lde_every_tile_length[lds-16-5]",
-    "test_lde_every_tile_length[waves8-16-5]",
     "test_trace_from_pinned_host_memory[w17]",
     "test_synthetic_division_by_power_tables",
     "test_trace_in_its_own_buffer",
