@@ -1,6 +1,7 @@
 """Host side of libdistaff_hip.so that needs no GPU (runs under -m "not gpu"): the Fibonacci trace generator (host_vm.h), the
 Fiat-Shamir helpers (host_util.h: BLAKE3, StdRng/Uniform draws, query positions) against the oracle's restatements, which are
 themselves pinned by the reference's vectors (tests/test_oracle_*.py)."""
+import os
 import numpy as np
 import pytest
 
@@ -152,3 +153,18 @@ def test_kernel_gate_on_the_built_library():
             "other": {"code_bytes": 100, "vgpr_spill": 3, "scratch_bytes": 16}}
     bad = G._kernel_gate(fake)
     assert len(bad) == 2 and "bytes of code" in bad[1] and "spilled" in bad[0] and "scratch" in bad[0]
+
+
+def test_merged_stack_terms_equal_the_per_operation_sum(tmp_path):
+    """air_kernel.h's st_desc / st_merge tables (operations of a group sharing one product per slot, zero items above the compile-time
+    stack depth) against the plain sum of flag x st_term over all 32 low-degree operations, on random rows and random flag factors, for
+    every slot, both auxiliary constraints, stack depths 4..8 and the run-time-depth / deep instances -- including the operations no
+    tested program executes (their flags are zero in every proof, so proof-level parity cannot see their table entries).  Host build of
+    the kernel header against the stand-in HIP header of tests/emu."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    emu = os.path.join(root, "tests", "emu")
+    exe = tmp_path / "air_merge_test"
+    subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O1", "-pthread", "-I", emu, "-w", "-DFE_EMULATE_GFX950=1", os.path.join(emu, "air_merge_test.cpp"), "-o", str(exe)])
+    out = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
+    assert out.returncode == 0 and b" 0 mismatches" in out.stdout, out.stdout.decode()[-2000:]

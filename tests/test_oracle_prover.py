@@ -141,3 +141,25 @@ def test_oracle_reproduces_golden_proof_digests(oracle):
         proof = O.Prover.from_trace(t, 1, ext=c["extension_factor"], num_queries=c["num_queries"], grinding=c["grinding_factor"]).prove()
         assert len(proof) == c["proof_bytes"] and O.blake3(proof).hex() == c["proof_blake3"], c
         assert t.program_hash.hex() == c["program_hash"]
+
+
+def test_point_evaluator_equals_the_whole_domain_loop(oracle):
+    """orc_evaluate_at (the evaluator on ONE row pair, what the full-size GPU tests sample with) against the oracle prover's own loop over
+    the 8n-point domain (prover.rs:53-64) -- transition and both boundary combinations, incl. trace steps and the excepted last step."""
+    O = oracle
+    t = O.fibonacci_trace(128)
+    p = O.Prover.from_trace(t, 1, grinding=8)
+    for k in range(1, 4):
+        p.step(k)
+    n, B, W = 128, 32, t.width
+    regs = p.get("registers")
+    te, ie, fe = O.to_ints(p.get("t_evaluations")), O.to_ints(p.get("i_evaluations")), O.to_ints(p.get("f_evaluations"))
+    draws = p.get("constraint_draws")
+    last = O.to_ints(regs[:, (n - 1) * B, :])
+    g8 = O.root_of_unity(8 * n)
+    for step in list(range(0, 24)) + [8 * n - 8, 8 * n - 1, 517, 700]:
+        pos = step * (B // 8)
+        cur, nxt = O.to_ints(regs[:, pos, :]), O.to_ints(regs[:, (pos + B) % (n * B), :])
+        tv, iv, fv, ok = O.evaluate_at(n, t.ctx_depth, t.loop_depth, W - 15 - t.ctx_depth - t.loop_depth, draws, last[1:3], last[0], t.public_inputs, p.outputs,
+                                       step, O.exp(g8, step), cur, nxt)
+        assert ok and (tv, iv, fv) == (te[step], ie[step], fe[step]), step
