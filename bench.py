@@ -382,6 +382,8 @@ def run(args):
             if want == "rccl":
                 failure = None
                 try:
+                    if os.environ.get("BENCH_SIMULATE_RCCL_FAILURE") == str(rank):      # tests: the fallback below, as if this rank's communicator could not be created
+                        raise RuntimeError("simulated failure of dst_comm_init (BENCH_SIMULATE_RCCL_FAILURE)")
                     ids = [D.Comm.unique_id() if rank == 0 else None]
                     dist.broadcast_object_list(ids, src=0)
                     comm = D.Comm.rccl(ids[0], rank, world, device)
@@ -581,7 +583,7 @@ def run(args):
         "dtype": "u128 (prime field 2^128-45*2^40+1, 4x u32 limbs)", "data": "synthetic",
         "config": {"workload": workload,
                    "trace_steps": n, "registers": W_FIB, "blowup": blowup, "queries": args.queries, "grinding": 20,
-                   "parallelism": "1 GPU" if world == 1 else "one proof sharded over %d GPUs: interpolation by trace columns (coefficients all-gathered), everything on the LDE domain by cosets; "
+                   "parallelism": "1 GPU" if (world == 1 and not args.force_sharded) else "one proof sharded over %d GPUs: interpolation by trace columns (coefficients all-gathered), everything on the LDE domain by cosets; "
                                   "Merkle trees finished per k-range (all-to-all of boundary nodes, all-gather of subtree roots), all-gather of constraint evaluations and of the "
                                   "first small FRI layer; %s" % (world, transport)},
         "prover_ms": ms_per_step,

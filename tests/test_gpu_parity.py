@@ -1182,6 +1182,25 @@ def test_bench_with_n_processes_on_one_device(ranks):
     assert abs(d["value"] - d["config"]["trace_steps"] * 20 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
 
 
+def test_bench_falls_back_to_the_callback_transport_over_nccl():
+    """`bench.py --force-sharded` with the library's own RCCL communicator failing on a rank: the ranks agree on it and the collectives
+    of dst_prove_sharded go through the callback transport over the torch.distributed group instead -- here the nccl group, i.e. the
+    device-tensor form of Comm.over_torch (all_gather_into_tensor / all_to_all_single on staged device tensors), which the gloo
+    tests do not reach.  One rank is all a one-GPU box offers; the calls are the ones N ranks make."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BENCH_LOG_N="12", BENCH_SIMULATE_RCCL_FAILURE="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-sharded", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"], cwd=root, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert r.returncode == 0, r.stderr.decode()[-3000:]
+    d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][0])
+    assert "error" not in d and d["proof_verified"] and "simulated failure" in d["transport_note"]
+    assert "callback transport (torch.distributed nccl" in d["config"]["parallelism"] and d["shard_stage_ms_rank0"]["tree_exchanges"] >= 2
+
+
 def test_bench_prints_an_error_line_instead_of_hanging():
     """a run that cannot proceed (here: a size the library refuses) ends with ONE JSON line carrying `error` and the stage, and a
     non-zero exit code; a stalled run is ended the same way by the watchdog (BENCH_TIMEOUT_S)"""
