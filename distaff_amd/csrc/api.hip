@@ -80,7 +80,7 @@ static std::vector<fe> build_periodic_table() {
 
 static void free_all(dst_ctx* c) {
     void* ptrs[] = {c->tw_lo, c->tw_hi, c->itw_lo, c->itw_hi, c->w1f, c->w2f, c->w1i, c->w2i, c->w1pf, c->w1pi, c->w2pf, c->w2pi, c->prescale, c->dit_last, c->tw4_lde, c->tw4_fwd, c->tw4_inv, c->tw4_row_fwd, c->tw4_row_inv, c->w3f, c->w3i, c->tmp2, c->periodic, c->trace == c->lde ? nullptr : c->trace, c->polys, c->lde, c->tmp,
-                    c->trace_leaves, c->trace_nodes, c->air_consts, c->ceval, c->cwork, c->cpoly, c->cevals, c->cnodes, c->comp_poly, c->comp, c->scratch, c->d_u64, c->d_stage};
+                    c->trace_leaves, c->trace_nodes, c->air_consts, c->ceval, c->cwork, c->cpoly, c->cevals, c->cnodes, c->comp_poly, c->comp, c->scratch, c->d_u64, c->d_stage, c->d_fri_chain};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& e : c->kpending) { hipEventDestroy(e.e0); hipEventDestroy(e.e1); }
     for (hipEvent_t e : c->event_pool) hipEventDestroy(e);
@@ -254,6 +254,7 @@ static int ctx_init(dst_ctx* c) {
     c->scratch_elems = (size_t)1 << 21;
     if ((r = dev_alloc(c, &c->scratch, c->scratch_elems))) return r;
     if ((r = dev_alloc(c, &c->d_u64, 64))) return r;
+    if ((r = dev_alloc(c, &c->d_fri_chain, DST_MAX_FRI_LAYERS * 48))) return r;
     c->stage_bytes = (size_t)8 << 20;
     if ((r = dev_alloc(c, &c->d_stage, c->stage_bytes))) return r;
     // FRI layers: sizes N, N/4, ... while > 256; the last one (<= 256) is the remainder (fri/prover.rs:21, fri/mod.rs:13)
@@ -758,6 +759,60 @@ int dst_build_proof(dst_ctx* c, const uint64_t* positions_in, uint32_t num_posit
     return rc;
 }
 
+// fri::reduce (fri/prover.rs:11-53) for dst_prove.  chained = true: the layers above the single-launch tail are committed WITHOUT host
+// round trips -- x = prng(root) is drawn on the device from the root where it lies (fri_draw_kernel, the same ChaCha20 / Uniform statement
+// the tail kernel uses) and the fold reads it from device memory; all roots are read back once, with the tail's.  chained = false
+// (DISTAFF_FRI_CHAIN=0, tests): one root read-back and one host draw per layer through the public phase calls.
+static int fri_commit_all(dst_ctx* c, std::vector<uint8_t>& roots, bool chained) {
+    int rc;
+    if (!chained) {
+        for (;;) {
+            if (int rt = dst_internal_fri_tail(c, roots)) { if (rt < 0) return rt; break; }
+            uint8_t root[32]; int more = 0;
+            if ((rc = dst_fri_commit_layer(c, root, &more))) return rc;
+            roots.insert(roots.end(), root, root + 32);
+            if (!more) break;
+            fe sx = prng(root);
+            if ((rc = dst_fri_fold(c, (const uint8_t*)&sx))) return rc;
+        }
+        return DST_OK;
+    }
+    if (!c->composed || c->fri_committed != 0 || c->fri_folded != 0) { c->err = "dst_prove: FRI state"; return DST_ERR_STATE; }
+    const int L = c->num_fri_layers;
+    digest* d_roots = reinterpret_cast<digest*>(c->d_fri_chain);
+    fe* d_alpha = reinterpret_cast<fe*>(c->d_fri_chain + DST_MAX_FRI_LAYERS * 32);
+    const char* te = getenv("DISTAFF_FRI_TAIL");
+    const bool tail_on = !(te && te[0] == '0');
+    int d = 0;
+    for (; d < L; d++) {
+        if (tail_on && d >= 1 && c->fri_size[d] <= DST_FRI_TAIL_MAX_SIZE) break;          // the rest in one launch
+        if (d == 0) k_fri_leaves_layer0(c); else k_fri_leaves(c, d);
+        k_merkle_levels(c, c->fri_leaves[d], c->fri_nodes[d], c->fri_size[d] / 4);
+        k_fri_draw(c, d, d_alpha + d, d_roots + d);
+        if (d + 1 < L) k_fri_fold_dev(c, d, d_alpha + d);
+    }
+    const int big = d;                                                // layers committed by the per-layer kernels
+    uint8_t* h_roots = c->h_stage + 40960;                            // page-locked: queued, picked up after the wait below
+    if (big) HIP_TRY(c, hipMemcpyAsync(h_roots, d_roots, (size_t)big * 32, hipMemcpyDeviceToHost, c->stream));
+    c->fri_committed = big; c->fri_folded = big < L ? big : L - 1;
+    std::vector<uint8_t> tail_roots;
+    if (big < L) {
+        if (int rt = dst_internal_fri_tail(c, tail_roots)) { if (rt < 0) return rt; }     // synchronises the stream; appends its roots to c->fri_roots
+        else { c->err = "dst_prove: the FRI tail did not run"; return DST_ERR_STATE; }
+    } else {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        HIP_TRY(c, hipGetLastError());
+    }
+    // c->fri_roots in layer order: the tail pushed its own behind what was there (nothing yet): put the big layers' in front
+    std::vector<std::vector<uint8_t>> all;
+    for (int i = 0; i < big; i++) all.emplace_back(h_roots + 32 * i, h_roots + 32 * (i + 1));
+    for (auto& r : c->fri_roots) all.push_back(r);
+    c->fri_roots.swap(all);
+    for (auto& r : c->fri_roots) roots.insert(roots.end(), r.begin(), r.end());
+    c->fri_committed = L; c->fri_folded = L - 1;
+    return DST_OK;
+}
+
 // ---- the whole prover -----------------------------------------------------------------------------------------------------------
 int dst_prove(dst_ctx* c, const dst_public* pub, uint8_t* proof_out, size_t cap, size_t* proof_len) {
     if (!c || !pub || !proof_len) return DST_ERR_ARG;
@@ -774,25 +829,15 @@ int dst_prove(dst_ctx* c, const dst_public* pub, uint8_t* proof_out, size_t cap,
     std::vector<uint8_t> z1(c->W * 16), z2(c->W * 16);
     const double t_compose = wall_ms();
     if ((rc = compose_impl(c, (const uint8_t*)draws.data(), z1.data(), z2.data(), false))) return rc;
-    bool first_layer = true;
     std::vector<uint8_t> roots;
-    for (;;) {                                                   // fri::reduce (fri/prover.rs:11-53)
-        // the small layers (at most 2^13 evaluations, natural order) in one launch, Fiat-Shamir draws on the device
-        if (int rt = dst_internal_fri_tail(c, roots)) { if (rt < 0) return rt; break; }
-        uint8_t root[32]; int more = 0;
-        if ((rc = dst_fri_commit_layer(c, root, &more))) return rc;
-        if (first_layer) {
-            // layer 0's wait covered the composition too: split at the device's own boundary (leaves of layer 0 start when the composition ends)
-            first_layer = false;
-            const double both = wall_ms() - t_compose, fri0 = c->phase_ms[6] < both ? c->phase_ms[6] : both;
-            float dev = 0;
-            if (hipEventElapsedTime(&dev, c->ph_ev[0], c->ph_ev[1]) == hipSuccess && dev > 0 && dev < both) { c->phase_ms[5] = dev; c->phase_ms[6] = both - dev; }   // events of compose_impl
-            else { c->phase_ms[5] = both - fri0; c->phase_ms[6] = fri0; }
-        }
-        roots.insert(roots.end(), root, root + 32);
-        if (!more) break;
-        fe sx = prng(root);
-        if ((rc = dst_fri_fold(c, (const uint8_t*)&sx))) return rc;
+    {
+        const char* ce = getenv("DISTAFF_FRI_CHAIN");
+        if ((rc = fri_commit_all(c, roots, !(ce && ce[0] == '0')))) return rc;
+        // the commit phase's first wait covered the composition too: split at the device's own boundary (events of compose_impl)
+        const double both = wall_ms() - t_compose;
+        float dev = 0;
+        if (hipEventElapsedTime(&dev, c->ph_ev[0], c->ph_ev[1]) == hipSuccess && dev > 0 && dev < both) { c->phase_ms[5] = dev; c->phase_ms[6] = both - dev; }
+        else { c->phase_ms[6] = both > c->phase_ms[5] ? both - c->phase_ms[5] : 0.0; }
     }
     double t0 = wall_ms();
     uint8_t seed0[32], seed1[32];

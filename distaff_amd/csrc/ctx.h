@@ -139,6 +139,7 @@ struct dst_ctx {
     // instead of being rebuilt from an all-gather on every rank (the host-orchestrated dst_shard_import).  Index 0 trace, 1 constraint, 2 + d FRI layer d.
     bool tree_krange[2 + DST_MAX_FRI_LAYERS] = {false};
     uint64_t *d_u64 = nullptr;                        // small device scalars (pow result, AIR failure flag)
+    uint8_t *d_fri_chain = nullptr;                   // dst_prove's FRI commit phase without host round trips: [24] roots (32 B) then [24] draws (16 B)
     uint8_t *h_stage = nullptr;                       // page-locked host staging (64 KiB): small uploads / read-backs that must not make the host wait
     unsigned long long air_flag_host = ~0ull;         // read-back of the AIR failure flag (deferred check)
     hipEvent_t ph_ev[6] = {nullptr};                  // phase boundaries on the stream (phase times without host waits)
@@ -247,6 +248,8 @@ void k_sub_dot_at0(dst_ctx* c, fe* y, const fe* values_dev, const fe* coeffs_dev
 void k_sub_at0(dst_ctx* c, fe* y, const fe* v_dev);                                                   // y[0] -= v[0]
 // FRI
 void k_fri_fold(dst_ctx* c, int layer, fe special_x);
+void k_fri_fold_dev(dst_ctx* c, int layer, const fe* alpha_dev);                        // the same with x read from device memory
+void k_fri_draw(dst_ctx* c, int layer, fe* alpha_out, digest* root_out);                // x = prng(root of `layer`) on the device; files the root
 void k_intt_cosets_local(dst_ctx* c, fe* vals, fe* out, size_t cosets);
 void k_cross8(dst_ctx* c, const fe* work, fe* out8n);
 int k_fri_tail(dst_ctx* c, int first, uint8_t* roots_out);       // natural-order layers first .. last in one launch (kernels_poly.hip)

@@ -429,7 +429,8 @@ void k_sub_at0(dst_ctx* c, fe* y, const fe* v_dev) { { KScope ks_(c, "sub_at0_ke
 // ---- FRI fold -----------------------------------------------------------------------------------------------------------------------
 // row r of a layer of size M (R = M/4 rows) sits on xs = x * {1, i, -1, -i} with x = w_N^(r * stride) and i = w_N^(N/4);
 // the degree-3 interpolant evaluated at alpha is (1/4) * sum_j (alpha / x)^j * sum_k y_k i^(-jk).
-struct FoldArgs { const fe* itw_lo; const fe* itw_hi; uint32_t lo_bits; uint32_t log_N; fe alpha, iota, quarter; };
+struct FoldArgs { const fe* itw_lo; const fe* itw_hi; uint32_t lo_bits; uint32_t log_N; fe alpha, iota, quarter;
+                  const fe* alpha_dev; };      // not null: alpha is read from device memory (drawn there from the layer's root, fri_draw_kernel)
 __device__ __forceinline__ fe fold_row(const FoldArgs& a, const fe& y0, const fe& y1, const fe& y2, const fe& y3, uint64_t exp_x) {
     uint64_t e = exp_x & (((uint64_t)1 << a.log_N) - 1);
     uint32_t l = (uint32_t)e & ((1u << a.lo_bits) - 1u), h = (uint32_t)(e >> a.lo_bits);
@@ -447,6 +448,7 @@ __device__ __forceinline__ fe fold_row(const FoldArgs& a, const fe& y0, const fe
 __global__ void __launch_bounds__(PT) fri_fold0_kernel(const fe* __restrict__ comp, fe* __restrict__ out, size_t n, uint32_t Bc, uint32_t log_b,
                                                       uint32_t log_jt, uint32_t j0, FoldArgs a) {
     __shared__ fe tile[PT];
+    if (a.alpha_dev) a.alpha = *a.alpha_dev;
     const uint32_t JT = 1u << log_jt, KT = blockDim.x >> log_jt;          // the launcher shrinks the block for tiny traces
     const uint32_t kk = threadIdx.x % KT, jj = threadIdx.x / KT;
     const size_t k = (size_t)blockIdx.x * KT + kk;
@@ -462,12 +464,16 @@ __global__ void __launch_bounds__(PT) fri_fold0_kernel(const fe* __restrict__ co
 __global__ void __launch_bounds__(PT) fri_fold_kernel(const fe* __restrict__ e, fe* __restrict__ out, size_t R, uint32_t log_stride, FoldArgs a) {
     size_t r = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= R) return;
+    if (a.alpha_dev) a.alpha = *a.alpha_dev;
     out[r] = fold_row(a, e[r], e[r + R], e[r + 2 * R], e[r + 3 * R], (uint64_t)r << log_stride);
 }
-void k_fri_fold(dst_ctx* c, int layer, fe special_x) {
-    FoldArgs a;
+static void fri_fold_launch(dst_ctx* c, int layer, fe special_x, const fe* alpha_dev);
+void k_fri_fold(dst_ctx* c, int layer, fe special_x) { fri_fold_launch(c, layer, special_x, nullptr); }
+void k_fri_fold_dev(dst_ctx* c, int layer, const fe* alpha_dev) { fri_fold_launch(c, layer, fe_zero(), alpha_dev); }
+static void fri_fold_launch(dst_ctx* c, int layer, fe special_x, const fe* alpha_dev) {
+    FoldArgs a{};
     a.itw_lo = c->itw_lo; a.itw_hi = c->itw_hi; a.lo_bits = c->tw_lo_bits; a.log_N = c->log_N;
-    a.alpha = special_x; a.iota = c->iota; a.quarter = c->four_inv;
+    a.alpha = special_x; a.iota = c->iota; a.quarter = c->four_inv; a.alpha_dev = alpha_dev;
     size_t R = c->fri_size[layer] / 4;
     if (layer == 0) {
         uint32_t jt = c->Bc < 32 ? (uint32_t)c->Bc : 32u, log_jt = 0;
@@ -573,6 +579,19 @@ __global__ void __launch_bounds__(FRI_TAIL_THREADS) fri_tail_kernel(FriTailArgs 
         __threadfence_block(); __syncthreads();
     }
 }
+// x = field::prng(root) of a layer committed by the per-layer kernels, drawn where the root is: the host need not see the root before the
+// fold is queued (fri/prover.rs:40).  One lane; also files the root for the read-back at the end of the commit phase.
+__global__ void fri_draw_kernel(const digest* __restrict__ nodes, fe* __restrict__ alpha_out, digest* __restrict__ root_out) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    uint32_t root[8];
+    for (int i = 0; i < 8; i++) root[i] = nodes[1].w[i];
+    *alpha_out = fri_prng(root);
+    for (int i = 0; i < 8; i++) root_out->w[i] = root[i];
+}
+void k_fri_draw(dst_ctx* c, int layer, fe* alpha_out, digest* root_out) {
+    KScope ks_(c, "fri_draw_kernel", 0.0);
+    hipLaunchKernelGGL(fri_draw_kernel, dim3(1), dim3(64), 0, c->stream, (const digest*)c->fri_nodes[layer], alpha_out, root_out);
+}
 // commits (and folds) the natural-order layers first .. num_fri_layers - 1 in one launch; roots_out: (num_fri_layers - first) x 32 bytes
 int k_fri_tail(dst_ctx* c, int first, uint8_t* roots_out) {
     const int L = c->num_fri_layers, count = L - first;
@@ -597,6 +616,9 @@ int k_fri_tail(dst_ctx* c, int first, uint8_t* roots_out) {
 // ---- proof of work ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(PT) pow_kernel(const uint32_t* __restrict__ seed8, uint64_t base, uint32_t grinding, unsigned long long* best) {
     uint64_t nonce = base + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // a smaller nonce has been found by a workgroup that started earlier: nothing this one could contribute (the launch covers 2^22
+    // nonces, four times the expected search length at grinding 20; the result is the minimum either way)
+    if (__atomic_load_n(best, __ATOMIC_RELAXED) < base + (uint64_t)blockIdx.x * blockDim.x) return;
     uint32_t m[16], h[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) m[i] = seed8[i];
@@ -776,13 +798,13 @@ __global__ void __launch_bounds__(PT) fri_fold_cm_kernel(const fe* __restrict__ 
     out[jl * q + k] = fold_row(a, base[0], base[q], base[2 * q], base[3 * q], r << log_stride);
 }
 void k_fri_fold_at(dst_ctx* c, const fe* e, fe* out, size_t R, int layer, fe special_x) {      // natural-order layer `layer` of 4R evaluations -> R
-    FoldArgs a;
+    FoldArgs a{};
     a.itw_lo = c->itw_lo; a.itw_hi = c->itw_hi; a.lo_bits = c->tw_lo_bits; a.log_N = c->log_N;
     a.alpha = special_x; a.iota = c->iota; a.quarter = c->four_inv;
     { KScope ks_(c, "fri_fold_kernel", 80.0 * R); hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((R + PT - 1) / PT)), dim3(PT), 0, c->stream, e, out, R, (uint32_t)(2 * layer), a); }
 }
 void k_fri_fold_cm(dst_ctx* c, const fe* e, fe* out, size_t nd, int layer, fe special_x) {
-    FoldArgs a;
+    FoldArgs a{};
     a.itw_lo = c->itw_lo; a.itw_hi = c->itw_hi; a.lo_bits = c->tw_lo_bits; a.log_N = c->log_N;
     a.alpha = special_x; a.iota = c->iota; a.quarter = c->four_inv;
     size_t total = nd / 4 * c->Bc;

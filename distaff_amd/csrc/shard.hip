@@ -566,41 +566,38 @@ const void* read_source(dst_ctx* c, uint32_t buffer, uint32_t arg) {
 }
 }  // namespace
 
-// gathers the requests selected by `mine` (one staging upload, one gather launch per source buffer, one copy back) into `blob`,
-// concatenated in request order
+// gathers the requests selected by `me` / `everything` (one staging upload, one gather launch, one copy back) into `blob`, concatenated in
+// request order
 static int gather_requests(dst_ctx* c, const OpenPlan& p, int me, bool everything, std::vector<uint8_t>& blob) {
-    // two launches: the trace rows (W elements each, one per register array) and every other item as 16-byte pieces by address
-    std::vector<uint64_t> rows, addr;               // row positions; device address of every piece
-    std::vector<size_t> row_dst, piece_dst;         // where each row / piece goes in the blob
+    std::vector<uint64_t> addr;                     // device address of every 16-byte piece
+    addr.reserve(16384);
+    // every requested item as 16-byte pieces in blob order (an LDE row = W pieces, one per register: element (register, coset, k) of the
+    // coset-major extension): ONE batched gather writes the blob as it is, one copy brings it back
     size_t total = 0;
     for (auto& r : p.reqs) {
         if (!(everything || r.owner == me || (r.owner < 0 && me == 0))) continue;
-        if (r.buffer == RD_LDE_ROW) { rows.push_back(r.index); row_dst.push_back(total); }
-        else {
+        if (r.buffer == RD_LDE_ROW) {
+            const uint64_t j = r.index % c->B, k = r.index / c->B;
+            if (j < c->j0 || j >= c->j0 + c->Bc) { c->err = "openings: LDE row of a coset this rank does not own"; return DST_ERR_ARG; }
+            const fe* base = c->lde + (j - c->j0) * c->n + k;
+            for (size_t reg = 0; reg < c->W; reg++) addr.push_back((uint64_t)(uintptr_t)(base + reg * c->Bc * c->n));
+        } else {
             const uint8_t* src = (const uint8_t*)read_source(c, r.buffer, r.arg);
             if (!src) { c->err = "openings: buffer not allocated"; return DST_ERR_STATE; }
-            for (uint32_t o = 0; o < r.bytes; o += 16) { addr.push_back((uint64_t)(uintptr_t)(src + r.index * r.bytes + o)); piece_dst.push_back(total + o); }
+            for (uint32_t o = 0; o < r.bytes; o += 16) addr.push_back((uint64_t)(uintptr_t)(src + r.index * r.bytes + o));
         }
         total += r.bytes;
     }
     blob.resize(total);
-    const size_t row_bytes = c->W * 16;
-    const size_t idx_bytes = ((rows.size() + addr.size()) * 8 + 15) / 16 * 16, out_bytes = rows.size() * row_bytes + addr.size() * 16;
-    if (idx_bytes + out_bytes > c->stage_bytes) { c->err = "openings: staging buffer too small"; return DST_ERR_ARG; }
-    std::vector<uint64_t> hidx(rows);
-    hidx.insert(hidx.end(), addr.begin(), addr.end());
-    std::vector<uint8_t> hout(out_bytes);
-    if (!hidx.empty()) HIP_TRY(c, hipMemcpyAsync(c->d_stage, hidx.data(), hidx.size() * 8, hipMemcpyHostToDevice, c->stream));
-    const uint64_t* d_idx = (const uint64_t*)c->d_stage;
+    if (addr.size() * 16 != total) { c->err = "openings: an item is not a multiple of 16 bytes"; return DST_ERR_STATE; }
+    const size_t idx_bytes = (addr.size() * 8 + 15) / 16 * 16;
+    if (idx_bytes + total > c->stage_bytes) { c->err = "openings: staging buffer too small"; return DST_ERR_ARG; }
+    if (!addr.empty()) HIP_TRY(c, hipMemcpyAsync(c->d_stage, addr.data(), addr.size() * 8, hipMemcpyHostToDevice, c->stream));
     uint8_t* d_out = c->d_stage + idx_bytes;
-    if (!rows.empty()) k_gather_rows(c, d_idx, rows.size(), (fe*)d_out);
-    k_gather_pieces(c, d_idx + rows.size(), addr.size(), d_out + rows.size() * row_bytes);
-    if (out_bytes) HIP_TRY(c, hipMemcpyAsync(hout.data(), d_out, out_bytes, hipMemcpyDeviceToHost, c->stream));
+    k_gather_pieces(c, (const uint64_t*)c->d_stage, addr.size(), d_out);
+    if (total) HIP_TRY(c, hipMemcpyAsync(blob.data(), d_out, total, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
-    for (size_t i = 0; i < rows.size(); i++) memcpy(blob.data() + row_dst[i], hout.data() + i * row_bytes, row_bytes);
-    const uint8_t* pieces = hout.data() + rows.size() * row_bytes;
-    for (size_t i = 0; i < addr.size(); i++) memcpy(blob.data() + piece_dst[i], pieces + i * 16, 16);
     return DST_OK;
 }
 
@@ -611,8 +608,14 @@ int dst_internal_build_proof(dst_ctx* c, const uint64_t* positions, uint32_t num
     if (rc) return rc;
     std::vector<uint8_t> blob;
     if ((rc = gather_requests(c, p, 0, true, blob))) return rc;
+    // the slots follow each other in request order; consecutive items with no template bytes between them are copied as one run
     size_t cur = 0;
-    for (size_t i = 0; i < p.reqs.size(); i++) { memcpy(p.w.b.data() + p.slot[i], blob.data() + cur, p.reqs[i].bytes); cur += p.reqs[i].bytes; }
+    for (size_t i = 0; i < p.reqs.size();) {
+        size_t run = p.reqs[i].bytes, e = i + 1;
+        while (e < p.reqs.size() && p.slot[e] == p.slot[i] + run) { run += p.reqs[e].bytes; e++; }
+        memcpy(p.w.b.data() + p.slot[i], blob.data() + cur, run);
+        cur += run; i = e;
+    }
     proof.swap(p.w.b);
     return DST_OK;
 }

@@ -841,7 +841,17 @@ def test_small_fri_layers_in_one_launch_equal_the_per_layer_path(oracle, monkeyp
         assert ctx.kernel_stats(reset=True).get("fri_tail_kernel", {}).get("launches") == 1
         monkeypatch.setenv("DISTAFF_FRI_TAIL", "0")
         assert ctx.prove(t.public_inputs, op.outputs) == expected
-        assert "fri_tail_kernel" not in ctx.kernel_stats(reset=True)
+        stats = ctx.kernel_stats(reset=True)
+        assert "fri_tail_kernel" not in stats and stats.get("fri_draw_kernel", {}).get("launches", 0) >= 2      # every layer's x drawn on the device
+        # dst_prove commits the layers above the tail without host round trips (x = prng(root) drawn by fri_draw_kernel, the fold reads it
+        # from device memory); DISTAFF_FRI_CHAIN=0 keeps one root read-back and one host draw per layer: the same proof either way
+        for tail in ("0", None):
+            if tail is None:
+                monkeypatch.delenv("DISTAFF_FRI_TAIL", raising=False)
+            monkeypatch.setenv("DISTAFF_FRI_CHAIN", "0")
+            assert ctx.prove(t.public_inputs, op.outputs) == expected
+            assert "fri_draw_kernel" not in ctx.kernel_stats(reset=True)
+            monkeypatch.delenv("DISTAFF_FRI_CHAIN", raising=False)
         ctx.close()
 
 
