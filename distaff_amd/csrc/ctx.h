@@ -222,7 +222,7 @@ void k_intt8_cosets(dst_ctx* c, fe* vals /* [8][n] coset-major, in place scratch
 void k_coset_to_natural(dst_ctx* c, const fe* src, size_t cosets, fe* dst);             // [cosets][n] -> natural [n*cosets]
 void k_coset_to_natural_len(dst_ctx* c, const fe* src, size_t cosets, size_t len, fe* dst);
 void k_fri_leaves_at(dst_ctx* c, const fe* e, digest* leaves, size_t R);
-void k_fri_fold_at(dst_ctx* c, const fe* e, fe* out, size_t R, int layer, fe special_x);
+void k_fri_fold_at(dst_ctx* c, const fe* e, fe* out, size_t R, int layer, fe special_x, const fe* alpha_dev = nullptr);   // alpha_dev: x read from device memory instead
 // hashing
 void k_trace_leaves(dst_ctx* c);
 void k_merkle_levels(dst_ctx* c, const digest* leaves, digest* nodes, size_t num_leaves);

@@ -797,10 +797,10 @@ __global__ void __launch_bounds__(PT) fri_fold_cm_kernel(const fe* __restrict__ 
     uint64_t r = ((uint64_t)k << log_b) + j0 + jl;
     out[jl * q + k] = fold_row(a, base[0], base[q], base[2 * q], base[3 * q], r << log_stride);
 }
-void k_fri_fold_at(dst_ctx* c, const fe* e, fe* out, size_t R, int layer, fe special_x) {      // natural-order layer `layer` of 4R evaluations -> R
+void k_fri_fold_at(dst_ctx* c, const fe* e, fe* out, size_t R, int layer, fe special_x, const fe* alpha_dev) {      // natural-order layer `layer` of 4R evaluations -> R
     FoldArgs a{};
     a.itw_lo = c->itw_lo; a.itw_hi = c->itw_hi; a.lo_bits = c->tw_lo_bits; a.log_N = c->log_N;
-    a.alpha = special_x; a.iota = c->iota; a.quarter = c->four_inv;
+    a.alpha = special_x; a.iota = c->iota; a.quarter = c->four_inv; a.alpha_dev = alpha_dev;
     { KScope ks_(c, "fri_fold_kernel", 80.0 * R); hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((R + PT - 1) / PT)), dim3(PT), 0, c->stream, e, out, R, (uint32_t)(2 * layer), a); }
 }
 void k_fri_fold_cm(dst_ctx* c, const fe* e, fe* out, size_t nd, int layer, fe special_x) {

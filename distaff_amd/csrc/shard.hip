@@ -374,32 +374,34 @@ static int fri_replicated_tail(dst_ctx* c, const void* gathered, int src_is_devi
     k_coset_to_natural_len(c, (const fe*)c->gather_buf, c->B, fri_nd(c, d0), nat0);
     if (c->fri_roots.size() < (size_t)L) c->fri_roots.resize(L);
     const char* tail_env = getenv("DISTAFF_FRI_TAIL");
-    for (int d = d0; d < L; d++) {
-        if (d >= 1 && c->fri_size[d] <= ((size_t)1 << 13) && !(tail_env && tail_env[0] == '0')) {
-            // the small layers in one launch (k_fri_tail, as on a single GPU): the layer's evaluations are in fri_e[d] in natural order
-            std::vector<uint8_t> rs((size_t)(L - d) * 32);
-            int rt = k_fri_tail(c, d, rs.data());
-            if (rt) return rt;
-            for (int i = d; i < L; i++) c->fri_roots[i].assign(rs.begin() + 32 * (i - d), rs.begin() + 32 * (i - d + 1));
-            if (d == d0 && root_out) memcpy(root_out, rs.data(), 32);
-            break;
-        }
+    // layers above the single-launch tail: no host round trip per layer -- x = prng(root) is drawn on the device (fri_draw_kernel) and the
+    // fold reads it there; their roots come back with the tail's (as in dst_prove's commit phase, api.hip)
+    digest* d_roots = reinterpret_cast<digest*>(c->d_fri_chain);
+    fe* d_alpha = reinterpret_cast<fe*>(c->d_fri_chain + DST_MAX_FRI_LAYERS * 32);
+    uint8_t* h_roots = c->h_stage + 40960;
+    int d = d0;
+    for (; d < L; d++) {
+        if (d >= 1 && c->fri_size[d] <= ((size_t)1 << 13) && !(tail_env && tail_env[0] == '0')) break;
         const size_t R = c->fri_size[d] / 4;
         const fe* e = fri_layer_natural(c, d);
         k_fri_leaves_at(c, e, c->fri_leaves[d], R);
         k_merkle_levels(c, c->fri_leaves[d], c->fri_nodes[d], R);
-        uint8_t root[32];
-        HIP_TRY(c, hipMemcpyAsync(root, c->fri_nodes[d] + 1, 32, hipMemcpyDeviceToHost, c->stream));
+        k_fri_draw(c, d, d_alpha + d, d_roots + d);
+        if (d + 1 < L) k_fri_fold_at(c, e, c->fri_e[d + 1], R, d, fe_zero(), d_alpha + d);
+    }
+    if (d > d0) HIP_TRY(c, hipMemcpyAsync(h_roots, d_roots + d0, (size_t)(d - d0) * 32, hipMemcpyDeviceToHost, c->stream));
+    if (d < L) {
+        // the small layers in one launch (k_fri_tail, as on a single GPU): the layer's evaluations are in fri_e[d] in natural order
+        std::vector<uint8_t> rs((size_t)(L - d) * 32);
+        int rt = k_fri_tail(c, d, rs.data());                   // synchronises the stream
+        if (rt) return rt;
+        for (int i = d; i < L; i++) c->fri_roots[i].assign(rs.begin() + 32 * (i - d), rs.begin() + 32 * (i - d + 1));
+    } else {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         HIP_TRY(c, hipGetLastError());
-        c->fri_roots[d].assign(root, root + 32);
-        if (d == d0 && root_out) memcpy(root_out, root, 32);
-        if (d + 1 < L) {
-            fe x;
-            prng_vector(root, 1, &x);                          // fri/prover.rs:40 field::prng(root)
-            k_fri_fold_at(c, e, c->fri_e[d + 1], R, d, x);
-        }
     }
+    for (int i = d0; i < d; i++) c->fri_roots[i].assign(h_roots + 32 * (i - d0), h_roots + 32 * (i - d0 + 1));
+    if (root_out) memcpy(root_out, c->fri_roots[d0].data(), 32);
     c->fri_committed = L; c->fri_folded = L - 1;
     c->fri_tail_pending = false;
     return DST_OK;
