@@ -267,6 +267,7 @@ void k_merkle_local_levels(dst_ctx* c, digest* nodes, size_t count, size_t stop_
 void k_merkle_levels_to(dst_ctx* c, const digest* leaves, digest* nodes, size_t num_leaves, size_t stop_count);
 void k_upper_tree(dst_ctx* c, const digest* gathered, digest* upper, size_t nb, uint32_t G);
 void k_merkle_upper(dst_ctx* c, digest* nodes, size_t count);       // nodes[1 .. count) from the filled level nodes[count .. 2*count)
+void k_digests_from_records(dst_ctx* c, const void* recs, size_t stride, digest* dst, size_t count);   // dst[i] = first 32 bytes of record i (count <= 8)
 void k_constraint_level1(dst_ctx* c);
 void k_fri_leaves_cm(dst_ctx* c, const fe* e, digest* leaves, size_t nd);
 void k_fri_fold_cm(dst_ctx* c, const fe* e, fe* out, size_t nd, int layer, fe special_x);

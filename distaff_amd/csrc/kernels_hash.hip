@@ -333,6 +333,15 @@ void k_upper_tree(dst_ctx* c, const digest* gathered, digest* upper, size_t nb, 
     merkle_upper_levels(c, upper, count);
 }
 void k_merkle_upper(dst_ctx* c, digest* nodes, size_t count) { merkle_upper_levels(c, nodes, count); }
+// dst[i] = the digest at the head of record i (records `stride` bytes apart): the ranks' subtree roots out of the exchanged root + status records
+__global__ void digests_from_records_kernel(const uint8_t* __restrict__ recs, size_t stride, digest* __restrict__ dst, uint32_t count) {
+    const uint32_t i = threadIdx.x >> 3, w = threadIdx.x & 7;
+    if (i < count) dst[i].w[w] = reinterpret_cast<const uint32_t*>(recs + (size_t)i * stride)[w];
+}
+void k_digests_from_records(dst_ctx* c, const void* recs, size_t stride, digest* dst, size_t count) {      // count <= 8
+    KScope ks_(c, "digests_from_records_kernel", 0.0);
+    hipLaunchKernelGGL(digests_from_records_kernel, dim3(1), dim3(64), 0, c->stream, (const uint8_t*)recs, stride, dst, (uint32_t)count);
+}
 // first node level of the constraint tree only (local), see k_constraint_tree
 void k_constraint_level1(dst_ctx* c) {
     uint32_t qn = (uint32_t)(c->Bc / 4);

@@ -42,7 +42,7 @@ static bool fri_layer_replicated(const dst_ctx* c, int d) { return c->sharded_la
 
 static int ensure_shard_buffers(dst_ctx* c) {
     if (c->gather_buf && c->d_status) return DST_OK;
-    if (c->gather_buf) { HIP_TRY(c, hipMalloc((void**)&c->d_status, 64 * 8 + 64)); return DST_OK; }
+    if (c->gather_buf) { HIP_TRY(c, hipMalloc((void**)&c->d_status, 1024)); return DST_OK; }
     const size_t n = c->n, G = c->prm.world;
     c->fri_rep_from = fri_replicated_from(c);
     size_t need = 32 * n * G;
@@ -57,7 +57,7 @@ static int ensure_shard_buffers(dst_ctx* c) {
         size_t nb = c->fri_size[d] / c->B / 4;             // boundary nodes per rank = rows per coset
         HIP_TRY(c, hipMalloc((void**)&c->fri_upper[d], (2 * nb * G > 2 ? 2 * nb * G : 2) * sizeof(digest)));
     }
-    HIP_TRY(c, hipMalloc((void**)&c->d_status, 64 * 8 + 64));     // status records of dst_prove_sharded (one per rank)
+    HIP_TRY(c, hipMalloc((void**)&c->d_status, 1024));     // status records of dst_prove_sharded (one per rank)
     return DST_OK;
 }
 // Every buffer a collective of the sharded protocol touches exists from context creation on (api.hip, world > 1): a rank that fails
@@ -110,7 +110,10 @@ int dst_shard_commit_trace(dst_ctx* c) {
 }
 
 // step 3, local part: AIR evaluation on the owned evaluation cosets.  *bad_step = first failing trace step seen by this rank (-1: none)
-int dst_shard_eval_constraints(dst_ctx* c, const dst_public* pub, const uint8_t* coeffs, int64_t* bad_step) {
+static int shard_eval_constraints(dst_ctx* c, const dst_public* pub, const uint8_t* coeffs, int64_t* bad_step, bool defer_check);
+int dst_shard_eval_constraints(dst_ctx* c, const dst_public* pub, const uint8_t* coeffs, int64_t* bad_step) { return shard_eval_constraints(c, pub, coeffs, bad_step, false); }
+// defer_check: the host does not wait for the verdict; the failing step (device word c->d_u64, ~0 = none) is picked up later
+static int shard_eval_constraints(dst_ctx* c, const dst_public* pub, const uint8_t* coeffs, int64_t* bad_step, bool defer_check) {
     if (!c || !pub || !coeffs) return DST_ERR_ARG;
     if (!c->committed) { c->err = "dst_shard_eval_constraints: trace not committed"; return DST_ERR_STATE; }
     HIP_TRY(c, hipSetDevice(c->device));
@@ -123,7 +126,7 @@ int dst_shard_eval_constraints(dst_ctx* c, const dst_public* pub, const uint8_t*
     fe* d_tc = d_coef + 344;
     HIP_TRY(c, hipMemcpyAsync(d_coef, draws.data(), 344 * 16, hipMemcpyHostToDevice, c->stream));
     HIP_TRY(c, hipMemcpyAsync(d_tc, tc.data(), tc.size() * 16, hipMemcpyHostToDevice, c->stream));
-    int r = k_eval_constraints(c, d_coef, d_tc, bad_step);
+    int r = k_eval_constraints(c, d_coef, d_tc, bad_step, defer_check);
     if (r == DST_ERR_AIR) c->err = "transition constraints were not satisfied";
     return r;
 }
@@ -717,13 +720,16 @@ int dst_shard_info(dst_ctx* c, uint64_t* op_count, uint32_t* num_fri_layers, uin
 //   * the first small FRI layer: all-gather of its evaluations, the commit phase then finishes replicated;
 //   * openings: every rank gathers what it owns; the blobs are all-gathered and every rank fills the same proof template.
 // Failure handling.  A rank that fails locally keeps ISSUING the collectives of the protocol (its peers wait in them) but skips its own
-// work; its status travels with data that is exchanged anyway -- a 64-byte record per rank next to the subtree roots of every tree (no
-// host round trip of its own: the root read-back synchronises once for both), and inside the two host-value exchanges (failing step of
-// the constraint check, opening lengths).  Every rank returns the first failing rank's code.  (Round 2 agreed on a status word through a
-// host-staged all-gather after every phase: ~26 per proof.)
+// work; its status travels with data that is exchanged anyway -- ONE 96-byte record per rank and tree (subtree root + status; for the
+// constraint tree also the first failing step of the rank's constraint check, copied from the device word the kernels wrote: no host
+// exchange and no wait of its own after the evaluation), read back with the root, and inside the opening-length exchange.  Every rank
+// returns the first failing rank's code.  (Round 2 agreed on a status word through a host-staged all-gather after every phase: ~26 per
+// proof; round 3 sent roots and status in two collectives per tree and exchanged the failing step through the host.)
 namespace {
-struct StatusRec { int32_t rc; int32_t pad[3]; fe payload[3]; };      // 64 bytes per rank; payload: rank 0's last trace state (op counter, program hash)
+struct StatusRec { int32_t rc; int32_t pad; uint64_t bad_step; fe payload[3]; };      // 64 bytes per rank; bad_step: first trace step whose constraints fail on this rank's cosets (~0: none; constraint tree only); payload: rank 0's last trace state (op counter, program hash)
 static_assert(sizeof(StatusRec) == 64, "StatusRec is exchanged as 64 bytes");
+struct TreeRec { digest root; StatusRec st; };                         // what a rank contributes to the ONE small all-gather of a tree exchange: its subtree root and its status
+static_assert(sizeof(TreeRec) == 96, "TreeRec is exchanged as 96 bytes");
 
 struct Sharded {
     dst_ctx* c; dst_comm* comm;
@@ -761,7 +767,8 @@ int shard_boundary(dst_ctx* c, uint32_t what, uint32_t arg, const digest** src, 
 // Finishes a tree from the ranks' boundary nodes and returns its root (replicated).  The ranks' status records ride with the subtree
 // roots: on return S.agreed holds the first failing rank's code.  `payload` (rank 0 -> everyone), when given, is three field elements
 // read from rank 0's device memory at `payload_src[i]`.
-void tree_exchange(Sharded& S, uint32_t what, uint32_t arg, uint8_t root[32], const fe* const* payload_src = nullptr, fe* payload_out = nullptr) {
+void tree_exchange(Sharded& S, uint32_t what, uint32_t arg, uint8_t root[32], const fe* const* payload_src = nullptr, fe* payload_out = nullptr,
+                   const uint64_t* bad_src = nullptr, int64_t* first_bad = nullptr) {
     dst_ctx* c = S.c; dst_comm* comm = S.comm;
     const size_t G = comm->world;
     const digest* src = nullptr; size_t K = 0;
@@ -773,34 +780,44 @@ void tree_exchange(Sharded& S, uint32_t what, uint32_t arg, uint8_t root[32], co
     c->tree_krange[slot] = krange;
     if (getenv("DISTAFF_SHARD_DEBUG") && comm->rank == 0) fprintf(stderr, "[distaff] tree %u/%u: %zu boundary nodes per rank, %s\n", what, arg, K, krange ? "k-range exchange (all-to-all + root all-gather)" : "all-gather of boundary nodes");
     if ((krange ? K * 32 : K * 32 * G) > c->gather_bytes) { S.fail(DST_ERR_ARG, "tree_exchange: gather buffer too small"); S.agreed = DST_ERR_ARG; return; }   // the same on every rank
+    // this rank's record of the exchange: status (and rank 0's payload) staged now, the subtree root joins it below -- ONE small all-gather
+    // per tree carries both (the roots used to travel in a collective of their own)
+    StatusRec mine{}; mine.rc = S.rc; mine.bad_step = ~0ull;
+    TreeRec* recs = reinterpret_cast<TreeRec*>(c->d_status);
+    std::vector<TreeRec> all(G);
+    bool staged = hipMemcpyAsync(&recs[comm->rank].st, &mine, sizeof(mine), hipMemcpyHostToDevice, c->stream) == hipSuccess;
+    // the verdict of this rank's constraint evaluation, straight from the device word the kernels wrote (no host wait of its own)
+    if (staged && bad_src && S.rc == DST_OK) staged = hipMemcpyAsync(&recs[comm->rank].st.bad_step, bad_src, 8, hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
+    if (staged && payload_src && comm->rank == 0 && S.rc == DST_OK)
+        for (int i = 0; i < 3 && staged; i++) staged = hipMemcpyAsync(&recs[0].st.payload[i], payload_src[i], sizeof(fe), hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
+    if (!staged) S.fail(DST_ERR_HIP, "tree_exchange: staging of the status record failed");
     if (krange) {
         const size_t chunk = K / G;                              // boundary nodes per (sender, owner) pair
         if (!S.coll(S.timed([&] { return comm->all_to_all(src, c->gather_buf, chunk * 32, c->stream); }), "tree_exchange")) return;
         digest* mid = upper + 2 * G;                             // this rank's subtree heap: mid[1] = its root, mid[K + kl*G + r] = boundary node of rank r at k = g*K/G + kl
-        S.local([&] { k_upper_tree(c, (const digest*)c->gather_buf, mid, chunk, (uint32_t)G); return DST_OK; });
-        if (!S.coll(S.timed([&] { return comm->all_gather(mid + 1, upper + G, 32, c->stream); }), "tree_exchange")) return;
-        S.local([&] { k_merkle_upper(c, upper, G); return DST_OK; });                          // the top log2(G) levels, on every rank
+        S.local([&]() -> int {
+            k_upper_tree(c, (const digest*)c->gather_buf, mid, chunk, (uint32_t)G);
+            HIP_TRY(c, hipMemcpyAsync(&recs[comm->rank].root, mid + 1, sizeof(digest), hipMemcpyDeviceToDevice, c->stream));
+            return DST_OK;
+        });
+        if (!S.coll(S.timed([&] { return comm->all_gather(recs + comm->rank, recs, sizeof(TreeRec), c->stream); }), "tree_exchange")) return;
+        S.local([&] { k_digests_from_records(c, recs, sizeof(TreeRec), upper + G, G); k_merkle_upper(c, upper, G); return DST_OK; });      // the top log2(G) levels, on every rank
     } else {
         if (!S.coll(S.timed([&] { return comm->all_gather(src, c->gather_buf, K * 32, c->stream); }), "tree_exchange")) return;
         S.local([&] { k_upper_tree(c, (const digest*)c->gather_buf, upper, K, (uint32_t)G); return DST_OK; });
+        if (!S.coll(S.timed([&] { return comm->all_gather(recs + comm->rank, recs, sizeof(TreeRec), c->stream); }), "tree_exchange")) return;
     }
-    // status records (and rank 0's payload) of all ranks: [G] records, this rank's own at index rank (in-place all-gather)
-    StatusRec mine{}; mine.rc = S.rc;
-    StatusRec* recs = reinterpret_cast<StatusRec*>(c->d_status);
-    std::vector<StatusRec> all(G);
-    bool staged = hipMemcpyAsync(recs + comm->rank, &mine, sizeof(mine), hipMemcpyHostToDevice, c->stream) == hipSuccess;
-    if (staged && payload_src && comm->rank == 0 && S.rc == DST_OK)
-        for (int i = 0; i < 3 && staged; i++) staged = hipMemcpyAsync(&recs[0].payload[i], payload_src[i], sizeof(fe), hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
-    if (!staged) S.fail(DST_ERR_HIP, "tree_exchange: staging of the status record failed");
-    if (!S.coll(S.timed([&] { return comm->all_gather(recs + comm->rank, recs, sizeof(StatusRec), c->stream); }), "tree_exchange")) return;
     const double t_wait = wall_ms_shard();
-    bool ok = hipMemcpyAsync(all.data(), recs, G * sizeof(StatusRec), hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+    bool ok = hipMemcpyAsync(all.data(), recs, G * sizeof(TreeRec), hipMemcpyDeviceToHost, c->stream) == hipSuccess;
     ok = ok && hipMemcpyAsync(root, upper + 1, 32, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
     ok = ok && hipStreamSynchronize(c->stream) == hipSuccess && hipGetLastError() == hipSuccess;
     c->shard_ms[1] += wall_ms_shard() - t_wait;                 // the host waits here for everything queued before the root: kernels and exchanges
     if (!ok) { S.fail(DST_ERR_HIP, "tree_exchange: root read-back failed"); S.agreed = S.agreed ? S.agreed : DST_ERR_HIP; return; }
-    S.saw(all.data(), what == SH_TRACE_TREE ? "trace tree" : what == SH_CONSTRAINT_TREE ? "constraint tree" : "FRI tree");
-    if (payload_out) for (int i = 0; i < 3; i++) payload_out[i] = all[0].payload[i];
+    std::vector<StatusRec> sts(G);
+    for (size_t g = 0; g < G; g++) sts[g] = all[g].st;
+    S.saw(sts.data(), what == SH_TRACE_TREE ? "trace tree" : what == SH_CONSTRAINT_TREE ? "constraint tree" : "FRI tree");
+    if (payload_out) for (int i = 0; i < 3; i++) payload_out[i] = all[0].st.payload[i];
+    if (first_bad) { *first_bad = -1; for (size_t g = 0; g < G; g++) if (all[g].st.rc == DST_OK && all[g].st.bad_step != ~0ull && (*first_bad < 0 || (int64_t)all[g].st.bad_step < *first_bad)) *first_bad = (int64_t)all[g].st.bad_step; }
     if (S.agreed) return;
     if (what == SH_TRACE_TREE) memcpy(c->trace_root, root, 32);
     else if (what == SH_CONSTRAINT_TREE) memcpy(c->constraint_root, root, 32);
@@ -922,20 +939,9 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
     // step 3
     std::vector<fe> coef(344);
     prng_vector(trace_root, 344, coef.data());
-    int64_t bad = -1;
-    S.local([&] { const int r = dst_shard_eval_constraints(c, pub, (const uint8_t*)coef.data(), &bad); return r == DST_ERR_AIR ? DST_OK : r; });
-    {
-        struct BadRec { int64_t bad; int64_t rc; } mine{bad, S.rc};
-        std::vector<BadRec> all(G);
-        if (!S.coll(S.timed([&] { return comm->all_gather_host(&mine, all.data(), sizeof(BadRec)); }), "constraint evaluation")) return S.agreed;
-        int64_t first = -1;
-        for (size_t g = 0; g < G; g++) {
-            if (all[g].rc != DST_OK && S.agreed == DST_OK) { S.agreed = (int)all[g].rc; if (S.rc == DST_OK) c->err = "constraint evaluation: rank " + std::to_string(g) + " reported error " + std::to_string(all[g].rc); }
-            if (all[g].bad >= 0 && (first < 0 || all[g].bad < first)) first = all[g].bad;
-        }
-        if (S.agreed) return S.agreed;
-        if (first >= 0) { c->err = "transition constraints were not satisfied at step " + std::to_string(first); return DST_ERR_AIR; }
-    }
+    // the evaluation is queued; its verdict (first failing step of this rank's cosets, evaluator.rs:152-158) rides with the status records of the
+    // constraint tree's exchange below instead of a host exchange and a wait of its own -- a trace that fails is reported one phase later
+    S.local([&] { return shard_eval_constraints(c, pub, (const uint8_t*)coef.data(), nullptr, true); });
     mark(2);
     // steps 4-5: the transition evaluations of all ranks, then combination (replicated) and the constraint tree
     {
@@ -966,8 +972,12 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
         S.local([&] { return shard_combine_parts(c, part1_done ? 2 : 3); });
     }
     mark(3);
-    tree_exchange(S, SH_CONSTRAINT_TREE, 0, constraint_root);
-    if (S.agreed) return S.agreed;
+    {
+        int64_t first_bad = -1;
+        tree_exchange(S, SH_CONSTRAINT_TREE, 0, constraint_root, nullptr, nullptr, c->d_u64, &first_bad);
+        if (S.agreed) return S.agreed;
+        if (first_bad >= 0) { c->err = "transition constraints were not satisfied at step " + std::to_string(first_bad); return DST_ERR_AIR; }
+    }
     mark(4);
     // step 6
     std::vector<fe> draws(516);
