@@ -270,6 +270,7 @@ void k_merkle_upper(dst_ctx* c, digest* nodes, size_t count);       // nodes[1 .
 void k_digests_from_records(dst_ctx* c, const void* recs, size_t stride, digest* dst, size_t count);   // dst[i] = first 32 bytes of record i (count <= 8)
 void k_constraint_level1(dst_ctx* c);
 void k_fri_leaves_cm(dst_ctx* c, const fe* e, digest* leaves, size_t nd);
-void k_fri_fold_cm(dst_ctx* c, const fe* e, fe* out, size_t nd, int layer, fe special_x);
+void k_fri_fold_cm(dst_ctx* c, const fe* e, fe* out, size_t nd, int layer, fe special_x, const fe* alpha_dev = nullptr);
+void k_fri_draw_at(dst_ctx* c, const digest* nodes, fe* alpha_out, digest* root_out);    // x = prng(nodes[1]) on the device
 void k_copy(dst_ctx* c, void* dst, const void* src, size_t bytes);
 int k_field_op(dst_ctx* c, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t count);

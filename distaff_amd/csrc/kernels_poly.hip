@@ -588,10 +588,11 @@ __global__ void fri_draw_kernel(const digest* __restrict__ nodes, fe* __restrict
     *alpha_out = fri_prng(root);
     for (int i = 0; i < 8; i++) root_out->w[i] = root[i];
 }
-void k_fri_draw(dst_ctx* c, int layer, fe* alpha_out, digest* root_out) {
+void k_fri_draw_at(dst_ctx* c, const digest* nodes, fe* alpha_out, digest* root_out) {        // nodes[1] = the root
     KScope ks_(c, "fri_draw_kernel", 0.0);
-    hipLaunchKernelGGL(fri_draw_kernel, dim3(1), dim3(64), 0, c->stream, (const digest*)c->fri_nodes[layer], alpha_out, root_out);
+    hipLaunchKernelGGL(fri_draw_kernel, dim3(1), dim3(64), 0, c->stream, nodes, alpha_out, root_out);
 }
+void k_fri_draw(dst_ctx* c, int layer, fe* alpha_out, digest* root_out) { k_fri_draw_at(c, c->fri_nodes[layer], alpha_out, root_out); }
 // commits (and folds) the natural-order layers first .. num_fri_layers - 1 in one launch; roots_out: (num_fri_layers - first) x 32 bytes
 int k_fri_tail(dst_ctx* c, int first, uint8_t* roots_out) {
     const int L = c->num_fri_layers, count = L - first;
@@ -792,6 +793,7 @@ __global__ void __launch_bounds__(PT) fri_fold_cm_kernel(const fe* __restrict__ 
     size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     const size_t q = nd / 4;
     if (t >= q * Bc) return;
+    if (a.alpha_dev) a.alpha = *a.alpha_dev;
     size_t jl = t / q, k = t % q;
     const fe* base = e + jl * nd + k;
     uint64_t r = ((uint64_t)k << log_b) + j0 + jl;
@@ -803,10 +805,10 @@ void k_fri_fold_at(dst_ctx* c, const fe* e, fe* out, size_t R, int layer, fe spe
     a.alpha = special_x; a.iota = c->iota; a.quarter = c->four_inv; a.alpha_dev = alpha_dev;
     { KScope ks_(c, "fri_fold_kernel", 80.0 * R); hipLaunchKernelGGL(fri_fold_kernel, dim3((unsigned)((R + PT - 1) / PT)), dim3(PT), 0, c->stream, e, out, R, (uint32_t)(2 * layer), a); }
 }
-void k_fri_fold_cm(dst_ctx* c, const fe* e, fe* out, size_t nd, int layer, fe special_x) {
+void k_fri_fold_cm(dst_ctx* c, const fe* e, fe* out, size_t nd, int layer, fe special_x, const fe* alpha_dev) {
     FoldArgs a{};
     a.itw_lo = c->itw_lo; a.itw_hi = c->itw_hi; a.lo_bits = c->tw_lo_bits; a.log_N = c->log_N;
-    a.alpha = special_x; a.iota = c->iota; a.quarter = c->four_inv;
+    a.alpha = special_x; a.iota = c->iota; a.quarter = c->four_inv; a.alpha_dev = alpha_dev;
     size_t total = nd / 4 * c->Bc;
     { KScope ks_(c, "fri_fold_cm_kernel", 80.0 * total); hipLaunchKernelGGL(fri_fold_cm_kernel, dim3((unsigned)((total + PT - 1) / PT)), dim3(PT), 0, c->stream, e, out, nd, (uint32_t)c->Bc, c->log_b,
                        (uint32_t)c->j0, (uint32_t)(2 * layer), a); }

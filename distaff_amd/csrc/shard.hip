@@ -767,8 +767,12 @@ int shard_boundary(dst_ctx* c, uint32_t what, uint32_t arg, const digest** src, 
 // Finishes a tree from the ranks' boundary nodes and returns its root (replicated).  The ranks' status records ride with the subtree
 // roots: on return S.agreed holds the first failing rank's code.  `payload` (rank 0 -> everyone), when given, is three field elements
 // read from rank 0's device memory at `payload_src[i]`.
+// defer_slot != nullptr: nothing is waited for -- the records and the root are copied into that page-locked slot (G * 96 + 32 bytes) behind the
+// exchange, and tree_exchange_finish looks at them after the caller's next synchronisation (the sharded FRI layers: their x is drawn on
+// the device from the root, so the host needs neither root nor status before the end of the commit phase).
+void tree_exchange_finish(Sharded& S, uint32_t what, uint32_t arg, const uint8_t* slot, fe* payload_out, int64_t* first_bad);
 void tree_exchange(Sharded& S, uint32_t what, uint32_t arg, uint8_t root[32], const fe* const* payload_src = nullptr, fe* payload_out = nullptr,
-                   const uint64_t* bad_src = nullptr, int64_t* first_bad = nullptr) {
+                   const uint64_t* bad_src = nullptr, int64_t* first_bad = nullptr, uint8_t* defer_slot = nullptr) {
     dst_ctx* c = S.c; dst_comm* comm = S.comm;
     const size_t G = comm->world;
     const digest* src = nullptr; size_t K = 0;
@@ -784,7 +788,6 @@ void tree_exchange(Sharded& S, uint32_t what, uint32_t arg, uint8_t root[32], co
     // per tree carries both (the roots used to travel in a collective of their own)
     StatusRec mine{}; mine.rc = S.rc; mine.bad_step = ~0ull;
     TreeRec* recs = reinterpret_cast<TreeRec*>(c->d_status);
-    std::vector<TreeRec> all(G);
     bool staged = hipMemcpyAsync(&recs[comm->rank].st, &mine, sizeof(mine), hipMemcpyHostToDevice, c->stream) == hipSuccess;
     // the verdict of this rank's constraint evaluation, straight from the device word the kernels wrote (no host wait of its own)
     if (staged && bad_src && S.rc == DST_OK) staged = hipMemcpyAsync(&recs[comm->rank].st.bad_step, bad_src, 8, hipMemcpyDeviceToDevice, c->stream) == hipSuccess;
@@ -807,12 +810,29 @@ void tree_exchange(Sharded& S, uint32_t what, uint32_t arg, uint8_t root[32], co
         S.local([&] { k_upper_tree(c, (const digest*)c->gather_buf, upper, K, (uint32_t)G); return DST_OK; });
         if (!S.coll(S.timed([&] { return comm->all_gather(recs + comm->rank, recs, sizeof(TreeRec), c->stream); }), "tree_exchange")) return;
     }
+    if (defer_slot) {
+        bool okd = hipMemcpyAsync(defer_slot, recs, G * sizeof(TreeRec), hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+        okd = okd && hipMemcpyAsync(defer_slot + G * sizeof(TreeRec), upper + 1, 32, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+        if (!okd) S.fail(DST_ERR_HIP, "tree_exchange: read-back could not be queued");
+        return;
+    }
     const double t_wait = wall_ms_shard();
-    bool ok = hipMemcpyAsync(all.data(), recs, G * sizeof(TreeRec), hipMemcpyDeviceToHost, c->stream) == hipSuccess;
-    ok = ok && hipMemcpyAsync(root, upper + 1, 32, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+    std::vector<uint8_t> host(G * sizeof(TreeRec) + 32);
+    bool ok = hipMemcpyAsync(host.data(), recs, G * sizeof(TreeRec), hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(host.data() + G * sizeof(TreeRec), upper + 1, 32, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
     ok = ok && hipStreamSynchronize(c->stream) == hipSuccess && hipGetLastError() == hipSuccess;
     c->shard_ms[1] += wall_ms_shard() - t_wait;                 // the host waits here for everything queued before the root: kernels and exchanges
     if (!ok) { S.fail(DST_ERR_HIP, "tree_exchange: root read-back failed"); S.agreed = S.agreed ? S.agreed : DST_ERR_HIP; return; }
+    tree_exchange_finish(S, what, arg, host.data(), payload_out, first_bad);
+    if (root) memcpy(root, host.data() + G * sizeof(TreeRec), 32);
+}
+// the ranks' records and the root of a tree exchange, once they are on the host: first failing rank's code into S.agreed, else the root is filed
+void tree_exchange_finish(Sharded& S, uint32_t what, uint32_t arg, const uint8_t* slot, fe* payload_out, int64_t* first_bad) {
+    dst_ctx* c = S.c;
+    const size_t G = S.comm->world;
+    std::vector<TreeRec> all(G);
+    memcpy(all.data(), slot, G * sizeof(TreeRec));
+    const uint8_t* root = slot + G * sizeof(TreeRec);
     std::vector<StatusRec> sts(G);
     for (size_t g = 0; g < G; g++) sts[g] = all[g].st;
     S.saw(sts.data(), what == SH_TRACE_TREE ? "trace tree" : what == SH_CONSTRAINT_TREE ? "constraint tree" : "FRI tree");
@@ -988,15 +1008,38 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
     // step 7: sharded layers (leaves + local levels | tree exchange with status | draw + fold), then the replicated tail from one
     // all-gather of evaluations.  fri_rep_from is fixed by the parameters: every rank walks the same layers.
     const int rep_from = c->gather_buf ? c->fri_rep_from : fri_replicated_from(c);
+    // Sharded layers.  chained (default): no host wait per layer -- x = prng(root) is drawn on the device from the replicated root
+    // (fri_draw_kernel) and the fold reads it there; the layers' records and roots are looked at once, after the tail.
+    // DISTAFF_FRI_CHAIN=0: root read-back, host draw and status check per layer (tests).
+    const char* ce = getenv("DISTAFF_FRI_CHAIN");
+    const bool chained = !(ce && ce[0] == '0');
+    fe* d_alpha = reinterpret_cast<fe*>(c->d_fri_chain + DST_MAX_FRI_LAYERS * 32);
+    digest* d_roots = reinterpret_cast<digest*>(c->d_fri_chain);
+    auto slot_of = [&](int d) { return c->h_stage + 45056 + (size_t)d * 800; };       // page-locked: G * 96 + 32 <= 800 bytes per layer
     for (int d = 0; d < rep_from; d++) {
-        int more = 0;
-        S.local([&] { return dst_shard_fri_layer(c, &more); });
+        S.local([&]() -> int {
+            if (!c->composed || d != c->fri_committed || d != c->fri_folded) { c->err = "dst_prove_sharded: FRI layer out of order"; return DST_ERR_STATE; }
+            const size_t nd = fri_nd(c, d), nb = nd / 4;
+            k_fri_leaves_cm(c, c->fri_e[d], c->fri_leaves[d], nd);
+            k_merkle_levels_to(c, c->fri_leaves[d], c->fri_nodes[d], nb * c->Bc, nb);
+            c->fri_committed = d + 1;
+            return DST_OK;
+        });
         uint8_t root[32];
-        tree_exchange(S, SH_FRI_TREE, (uint32_t)d, root);
+        tree_exchange(S, SH_FRI_TREE, (uint32_t)d, root, nullptr, nullptr, nullptr, nullptr, chained ? slot_of(d) : nullptr);
         if (S.agreed) return S.agreed;
-        fe x;
-        prng_vector(root, 1, &x);                                 // fri/prover.rs:40 field::prng(root)
-        S.local([&] { return dst_shard_fri_fold(c, (const uint8_t*)&x); });
+        if (chained) {
+            S.local([&]() -> int {
+                k_fri_draw_at(c, c->fri_upper[d], d_alpha + d, d_roots + d);
+                k_fri_fold_cm(c, c->fri_e[d], c->fri_e[d + 1], fri_nd(c, d), d, fe_zero(), d_alpha + d);
+                c->fri_folded = d + 1;
+                return DST_OK;
+            });
+        } else {
+            fe x;
+            prng_vector(root, 1, &x);                                 // fri/prover.rs:40 field::prng(root)
+            S.local([&] { return dst_shard_fri_fold(c, (const uint8_t*)&x); });
+        }
     }
     {
         const int d = rep_from;
@@ -1007,6 +1050,15 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
         uint8_t root[32];
         if (!S.coll(S.timed([&] { return comm->all_gather(c->fri_e[d], c->gather_buf, bytes, c->stream); }), "FRI tail")) return S.agreed;
         S.local([&] { c->fri_tail_pending = true; return fri_replicated_tail(c, c->gather_buf, 1, root); });
+    }
+    if (chained && rep_from > 0) {
+        // the deferred records of the sharded layers: everything queued has completed once the stream is idle (a rank that failed locally
+        // did not run the tail's own wait)
+        const double t_wait = wall_ms_shard();
+        if (hipStreamSynchronize(c->stream) != hipSuccess) S.fail(DST_ERR_HIP, "dst_prove_sharded: stream synchronisation failed");
+        c->shard_ms[1] += wall_ms_shard() - t_wait;
+        for (int d = 0; d < rep_from && !S.agreed; d++) tree_exchange_finish(S, SH_FRI_TREE, (uint32_t)d, slot_of(d), nullptr, nullptr);
+        if (S.agreed) return S.agreed;
     }
     mark(6);
     // step 8 (replicated: every rank grinds the same seed and finds the same first nonce)

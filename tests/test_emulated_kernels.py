@@ -40,6 +40,7 @@ SELECTION = [
     "test_prove_sharded_behind_the_c_abi[2-8-None-False]",
     "test_prove_sharded_behind_the_c_abi[8-8-9-False]",
     "test_prove_sharded_behind_the_c_abi[4-10-9-True]",
+    "test_prove_sharded_fri_layers_with_host_draws",
     "test_prove_sharded_reports_an_invalid_trace_on_every_rank",
     "test_prove_sharded_rank_without_a_trace_on_fresh_contexts",
     "test_prove_sharded_in_separate_processes_sharing_the_gpu[2-12]",

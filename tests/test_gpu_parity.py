@@ -941,6 +941,32 @@ def test_prove_sharded_with_collectives_on_their_own_stream(oracle, monkeypatch,
         ctx.close()
 
 
+def test_prove_sharded_fri_layers_with_host_draws(oracle, monkeypatch):
+    """The sharded FRI layers are committed without host waits by default (x drawn on the device from the replicated root, the ranks'
+    records looked at after the commit phase); DISTAFF_FRI_CHAIN=0 keeps a root read-back, a host draw and a status check per layer --
+    the same proof, with sharded layers forced at a small size (DISTAFF_FRI_REPLICATE_LOG)."""
+    import distaff_amd as D
+    O = oracle
+    monkeypatch.setenv("DISTAFF_FRI_REPLICATE_LOG", "9")
+    t = O.fibonacci_trace(1 << 10)
+    op = O.Prover.from_trace(t, 1, grinding=8)
+    expected = op.prove()
+    for chain in ("0", None):
+        if chain is None:
+            monkeypatch.delenv("DISTAFF_FRI_CHAIN", raising=False)
+        else:
+            monkeypatch.setenv("DISTAFF_FRI_CHAIN", chain)
+        ctxs = []
+        for r in range(4):
+            ctx = D.Context(10, t.width, t.ctx_depth, t.loop_depth, rank=r, world=4, grinding=8)
+            ctx.upload_owned(t.columns)
+            ctxs.append(ctx)
+        for _ in range(2):
+            assert D.prove_sharded_local(ctxs, t.public_inputs, op.outputs) == expected
+        for ctx in ctxs:
+            ctx.close()
+
+
 def test_prove_sharded_over_rccl_with_one_rank(oracle):
     """The RCCL transport of dst_prove_sharded (librccl.so bound at run time: ncclCommInitRank, all-gathers of host values and of the
     constraint evaluations / FRI layer, the all-to-all as grouped send / receive) with the one rank a single-GPU box offers; more
