@@ -118,7 +118,7 @@ def test_bench_reads_the_stamped_counter_summary():
         return
     assert row is not None and float(row["SQ_INSTS_VALU"]) > 0 and int(row["fetch_bytes_per_launch_x2"]) > 0
     assert bench.pmc_row("air_kernel<2,1,4,8,0,240,6>")[0] is not None         # the library prints unsigned template arguments as 240, rocprofv3 as 240u
-    assert bench.pmc_row("ntt_pass_b<1024,8,1,10,2>")[0] is not None           # ... and template booleans as 0 / 1, rocprofv3 as false / true
+    assert bench.pmc_row("ntt_pass_b<1024,8,1,10,2,0>")[0] is not None           # ... and template booleans as 0 / 1, rocprofv3 as false / true
     assert bench.pmc_row("no_such_kernel")[0] is None
     newest = sorted(f for f in os.listdir(os.path.join(root, "profiles")) if f.endswith("_bench_default.json"))[-1]
     line = json.loads(open(os.path.join(root, "profiles", newest)).read().strip().splitlines()[-1])
