@@ -116,13 +116,35 @@ void orc_sponge_round(u128* state4, const u128* op_code, const u128* op_value, u
 void orc_hasher_round(u128* state6, uint64_t step) { hasher_apply_round(state6, step); }
 
 struct TraceHandle { ExecutionTrace t; Program p; };
-void* orc_vm_execute(const char* source, const u128* inputs, size_t nin) {
+static void* run_program(Program&& p, const u128* pub, size_t npub, const u128* sa, size_t na, const u128* sb, size_t nb) {
+    auto h = new TraceHandle();
     try {
-        Assembler a;
-        auto h = new TraceHandle();
-        h->p = a.compile(source);
-        h->t = vm_execute(h->p, vec(inputs, inputs + nin));
+        h->p = std::move(p);
+        h->t = vm_execute(h->p, ProgramInputs(vec(pub, pub + npub), vec(sa, sa + na), vec(sb, sb + nb)));
         return h;
+    } catch (...) { delete h; throw; }
+}
+void* orc_vm_execute(const char* source, const u128* inputs, size_t nin) {
+    try { Assembler a; return run_program(a.compile(source), inputs, nin, nullptr, 0, nullptr, 0); }
+    catch (const std::exception& e) { fail(e); return nullptr; }
+}
+// assembly source + public inputs + the two secret tapes (programs/inputs.rs:12)
+void* orc_vm_execute_inputs(const char* source, const u128* pub, size_t npub, const u128* sa, size_t na, const u128* sb, size_t nb) {
+    try { Assembler a; return run_program(a.compile(source), pub, npub, sa, na, sb, nb); }
+    catch (const std::exception& e) { fail(e); return nullptr; }
+}
+// a single-Span program from op codes, PUSH values assigned in order (the reference tests' build_program, src/tests/mod.rs:315-335)
+void* orc_vm_execute_ops(const uint8_t* ops, size_t nops, const u128* push_values, size_t npush, const u128* pub, size_t npub,
+                         const u128* sa, size_t na, const u128* sb, size_t nb) {
+    try {
+        std::vector<UserOp> code; HintMap hints; size_t j = 0;
+        for (size_t i = 0; i < nops; i++) {
+            if (!is_user_op(ops[i])) throw std::runtime_error("not a user operation code");
+            code.push_back((UserOp)ops[i]);
+            if (ops[i] == OP_PUSH) { if (j >= npush) throw std::runtime_error("not enough push values"); hints[i] = OpHint::push(push_values[j++]); }
+        }
+        if (j != npush) throw std::runtime_error("too many push values");
+        return run_program(Program::from_root_blocks({make_span(code, hints)}), pub, npub, sa, na, sb, nb);
     } catch (const std::exception& e) { fail(e); return nullptr; }
 }
 void orc_trace_dims(void* h, uint64_t* W, uint64_t* n, uint64_t* ctx, uint64_t* lp) {
@@ -131,6 +153,124 @@ void orc_trace_dims(void* h, uint64_t* W, uint64_t* n, uint64_t* ctx, uint64_t* 
 void orc_trace_copy(void* h, u128* out) { auto t = (TraceHandle*)h; size_t n = t->t.registers[0].size(); for (size_t c = 0; c < t->t.registers.size(); c++) std::copy(t->t.registers[c].begin(), t->t.registers[c].end(), out + c * n); }
 void orc_trace_program_hash(void* h, u128* out2) { auto t = (TraceHandle*)h; out2[0] = t->p.hash[0]; out2[1] = t->p.hash[1]; }
 void orc_trace_free(void* h) { delete (TraceHandle*)h; }
+
+// `{:?}` of the compiled program (programs/mod.rs:63-73), for the reference's assembler tests
+long orc_program_debug(const char* source, char* out, size_t cap) {
+    try { Assembler a; std::string s = a.compile(source).debug(); if (s.size() + 1 > cap) return -(long)s.size(); memcpy(out, s.c_str(), s.size() + 1); return (long)s.size(); }
+    catch (const std::exception& e) { return fail(e); }
+}
+void orc_hasher_digest(const u128* values, size_t n, u128* out2) { auto d = hasher_digest(vec(values, values + n)); out2[0] = d[0]; out2[1] = d[1]; }
+
+// The user stack alone (processor/stack/mod.rs), for the reference's stack unit tests: executes ops[i] with hint (kind, value) i and
+// writes after every operation the full register file (states: (nops + 1) x max_regs, row 0 = initial state) plus depth / max_depth.
+// Returns the number of registers, or -1 with the reference's panic text in orc_last_error().
+long orc_stack_run(const u128* pub, size_t npub, const u128* sa, size_t na, const u128* sb, size_t nb, size_t init_len,
+                   const uint8_t* ops, const uint8_t* hint_kinds, const u128* hint_values, size_t nops,
+                   u128* states, size_t max_regs, uint64_t* depth, uint64_t* max_depth) {
+    try {
+        StackVM s(ProgramInputs(vec(pub, pub + npub), vec(sa, sa + na), vec(sb, sb + nb)), init_len);
+        auto snap = [&](size_t k) {
+            for (size_t r = 0; r < max_regs; r++) states[k * max_regs + r] = r < s.registers.size() ? s.registers[r][s.step] : 0;
+            depth[k] = s.depth; max_depth[k] = s.max_depth;
+        };
+        snap(0);
+        for (size_t i = 0; i < nops; i++) {
+            if (!is_user_op(ops[i])) throw std::runtime_error("not a user operation code");
+            s.execute((UserOp)ops[i], OpHint::of((HintKind)hint_kinds[i], hint_values[i]));
+            if (s.registers.size() > max_regs) throw std::runtime_error("orc_stack_run: register file larger than max_regs");
+            snap(i + 1);
+        }
+        return (long)s.registers.size();
+    } catch (const std::exception& e) { return fail(e); }
+}
+
+// The reference's independent walk over a program (its test utility programs/tests/utils.rs:10-165: traverse, traverse_span,
+// close_block, traverse_loop) restated, so that programs/tests/mod.rs can be transcribed: `conditions` is the stack the walk pops
+// branch / loop decisions from (last element first).  Writes the hash state after the final close_block and the step count.
+namespace {
+struct Walk {
+    vec stack;
+    u128 pop() { if (stack.empty()) throw std::runtime_error("traverse: condition stack is empty"); u128 v = stack.back(); stack.pop_back(); return v; }
+    size_t span(const Span& b, u128* hash, bool is_first, size_t step) {
+        if (!is_first) { hash_op(hash, OP_NOOP, 0, step); step++; }
+        for (size_t i = 0; i < b.length(); i++) { hash_op(hash, b.ops[i], b.get_hint(i).value(), step); step++; }
+        return step;
+    }
+    size_t close(u128* hash, u128 parent_hash, u128 sibling_hash, bool is_true_branch, size_t step) {
+        hash_op(hash, OP_NOOP, 0, step); step++;
+        step++;  // TEND / FEND
+        if (is_true_branch) { hash[1] = hash[0]; hash[0] = parent_hash; hash[2] = sibling_hash; hash[3] = 0; }
+        else { hash[2] = hash[0]; hash[0] = parent_hash; hash[1] = sibling_hash; hash[3] = 0; }
+        for (size_t i = 0; i < HACC_NUM_ROUNDS; i++) { hash_op(hash, OP_NOOP, 0, step); step++; }
+        return step;
+    }
+    size_t loop(const Block& b, u128* hash, size_t step) {
+        step++;  // LOOP
+        u128 state[4] = {0, 0, 0, 0};
+        for (;;) {
+            step = blocks(b.body, state, step);
+            u128 c = pop();
+            if (c > 1) throw std::runtime_error("cannot exit loop based on a non-binary condition");
+            if (state[0] != loop_image(b)) throw std::runtime_error("loop image didn't match loop body hash");
+            step++;  // BREAK / WRAP
+            if (c == 0) break;
+            for (auto& v : state) v = 0;
+        }
+        step = span(b.alt[0].span, state, true, step);
+        step = close(state, hash[0], loop_skip_hash(b), true, step);
+        std::copy(state, state + 4, hash);
+        return step;
+    }
+    size_t blocks(const std::vector<Block>& bl, u128* hash, size_t step) {
+        if (!bl[0].is_span()) throw std::runtime_error("first block in a sequence must be a Span block");
+        step = span(bl[0].span, hash, true, step);
+        for (size_t k = 1; k < bl.size(); k++) {
+            const Block& b = bl[k];
+            u128 state[4] = {0, 0, 0, 0};
+            switch (b.kind) {
+                case B_SPAN: step = span(b.span, hash, false, step); break;
+                case B_GROUP:
+                    step++;  // BEGIN
+                    step = blocks(b.body, state, step);
+                    step = close(state, hash[0], 0, true, step);
+                    std::copy(state, state + 4, hash); break;
+                case B_SWITCH: {
+                    step++;
+                    u128 c = pop();
+                    if (c == 0) { step = blocks(b.alt, state, step); step = close(state, hash[0], seq_hash(b.body), false, step); }
+                    else if (c == 1) { step = blocks(b.body, state, step); step = close(state, hash[0], seq_hash(b.alt), true, step); }
+                    else throw std::runtime_error("cannot select a branch based on a non-binary condition");
+                    std::copy(state, state + 4, hash); break;
+                }
+                case B_LOOP: {
+                    u128 c = pop();
+                    if (c == 0) {
+                        step++;
+                        step = blocks(b.alt, state, step);
+                        step = close(state, hash[0], loop_body_hash(b), false, step);
+                        std::copy(state, state + 4, hash);
+                    } else if (c == 1) step = loop(b, hash, step);
+                    else throw std::runtime_error("cannot enter loop based on a non-binary condition");
+                    break;
+                }
+            }
+        }
+        return step;
+    }
+};
+}
+long orc_program_traverse(const char* source, const u128* conditions, size_t ncond, u128* hash4, u128* program_hash2) {
+    try {
+        Assembler a; Program p = a.compile(source);
+        Walk w; w.stack.assign(conditions, conditions + ncond);
+        u128 h[4] = {0, 0, 0, 0};
+        size_t step = w.blocks(p.root.body, h, 0);
+        step = w.close(h, 0, 0, true, step);
+        std::copy(h, h + 4, hash4);
+        program_hash2[0] = p.hash[0]; program_hash2[1] = p.hash[1];
+        return (long)step;
+    } catch (const std::exception& e) { return fail(e); }
+}
 
 // ---- AIR pieces --------------------------------------------------------------------------------------------------------
 // out: cf[8] ld[32] hd[4] begin noop op_code  (47 elements)

@@ -36,9 +36,9 @@ def lib():
         _lib = ctypes.CDLL(_LIB_PATH)
         L = _lib
         L.orc_last_error.restype = ctypes.c_char_p
-        for name in ("orc_vm_execute", "orc_prover_new"):
+        for name in ("orc_vm_execute", "orc_vm_execute_inputs", "orc_vm_execute_ops", "orc_prover_new"):
             getattr(L, name).restype = ctypes.c_void_p
-        for name in ("orc_merkle_prove_batch", "orc_prover_get"):
+        for name in ("orc_merkle_prove_batch", "orc_prover_get", "orc_program_debug", "orc_stack_run", "orc_program_traverse"):
             getattr(L, name).restype = ctypes.c_long
         L.orc_infer_degree.restype = ctypes.c_size_t
         L.orc_poly_div.restype = ctypes.c_size_t
@@ -276,12 +276,34 @@ def hasher_round(state6, step):
     return to_ints(s)
 
 
-class Trace:
-    """Execution trace of an assembly program (Span / Group subset): columns [W, n, 2], ctx/loop depths, program hash."""
+# operation codes (processor/opcodes.rs:42-86) and execution hint kinds (opcodes.rs:168-176) as the C entry points take them
+OPS = {"assert": 0x60, "asserteq": 0x61, "eq": 0x62, "drop": 0x63, "drop4": 0x64, "choose": 0x65, "choose2": 0x66, "cswap2": 0x67,
+       "add": 0x68, "mul": 0x69, "and": 0x6A, "or": 0x6B, "inv": 0x6C, "neg": 0x6D, "not": 0x6E,
+       "read": 0x70, "read2": 0x71, "dup": 0x72, "dup2": 0x73, "dup4": 0x74, "pad2": 0x75,
+       "swap": 0x78, "swap2": 0x79, "swap4": 0x7A, "roll4": 0x7B, "roll8": 0x7C, "binacc": 0x7D,
+       "push": 0x1F, "cmp": 0x3F, "rescr": 0x5F, "begin": 0x00, "noop": 0x7F}
+HINTS = {"none": 0, "eq_start": 1, "rc_start": 2, "cmp_start": 3, "pmpath_start": 4, "push_value": 5}
 
-    def __init__(self, source, public_inputs):
-        inp = to_arr(list(public_inputs)) if len(public_inputs) else np.zeros((0, 2), dtype=np.uint64)
-        h = lib().orc_vm_execute(source.encode(), _p(inp), ctypes.c_size_t(len(public_inputs)))
+
+def _vec(values):
+    return to_arr(list(values)) if len(values) else np.zeros((0, 2), dtype=np.uint64)
+
+
+def _opcodes(ops):
+    return np.array([OPS[o] if isinstance(o, str) else int(o) for o in ops], dtype=np.uint8)
+
+
+class Trace:
+    """Execution trace of a program (any block kind, the whole instruction set): columns [W, n, 2], ctx/loop depths, program hash.
+    ``Trace(source, public_inputs, secret_a, secret_b)`` compiles assembly; ``Trace.from_ops`` builds the single-Span program of the
+    reference's ``build_program`` test helper (src/tests/mod.rs:315-335)."""
+
+    def __init__(self, source, public_inputs, secret_a=(), secret_b=(), _handle=None):
+        if _handle is None:
+            pub, sa, sb = _vec(public_inputs), _vec(secret_a), _vec(secret_b)
+            _handle = lib().orc_vm_execute_inputs(source.encode(), _p(pub), ctypes.c_size_t(len(public_inputs)), _p(sa), ctypes.c_size_t(len(secret_a)),
+                                                  _p(sb), ctypes.c_size_t(len(secret_b)))
+        h = _handle
         if not h:
             raise RuntimeError(last_error())
         W = ctypes.c_uint64(); n = ctypes.c_uint64(); ctx = ctypes.c_uint64(); lp = ctypes.c_uint64()
@@ -296,8 +318,74 @@ class Trace:
         self.stack_depth = self.width - 15 - self.ctx_depth - self.loop_depth
         self.public_inputs = list(public_inputs)
 
+    @classmethod
+    def from_ops(cls, ops, push_values, public_inputs, secret_a=(), secret_b=()):
+        code = _opcodes(ops)
+        pv, pub, sa, sb = _vec(push_values), _vec(public_inputs), _vec(secret_a), _vec(secret_b)
+        h = lib().orc_vm_execute_ops(_p(code), ctypes.c_size_t(len(code)), _p(pv), ctypes.c_size_t(len(push_values)), _p(pub), ctypes.c_size_t(len(public_inputs)),
+                                     _p(sa), ctypes.c_size_t(len(secret_a)), _p(sb), ctypes.c_size_t(len(secret_b)))
+        return cls(None, public_inputs, _handle=h or 0)
+
     def row(self, step):
         return to_ints(self.columns[:, step, :])
+
+    def user_stack(self, step):
+        """user stack registers of a row, zero-padded to 8 like TraceState::user_stack() (trace_state.rs:60-66)"""
+        v = self.row(step)[15 + self.ctx_depth + self.loop_depth:]
+        return v + [0] * (8 - len(v))
+
+    def outputs(self, num_outputs):
+        """lib.rs:44-46: the top of the user stack at the last step"""
+        return self.user_stack(self.length - 1)[:num_outputs]
+
+    def trace_hash(self):
+        """the program hash the VM accumulated (sponge registers 0, 1 of the last row; lib.rs:55)"""
+        return to_arr(self.row(self.length - 1)[1:3]).tobytes()
+
+
+def program_debug(source):
+    """``format!("{:?}", program)`` of the compiled program (programs/mod.rs:63-73)"""
+    out = ctypes.create_string_buffer(1 << 20)
+    k = lib().orc_program_debug(source.encode(), out, ctypes.c_size_t(1 << 20))
+    if k < 0:
+        raise RuntimeError(last_error())
+    return out.value.decode()
+
+
+def program_traverse(source, conditions):
+    """programs/tests/utils.rs traverse + close_block: returns (hash state [4], program hash bytes, step count)"""
+    c = _vec(conditions); h = np.zeros((4, 2), dtype=np.uint64); ph = np.zeros((2, 2), dtype=np.uint64)
+    k = lib().orc_program_traverse(source.encode(), _p(c), ctypes.c_size_t(len(conditions)), _p(h), _p(ph))
+    if k < 0:
+        raise RuntimeError(last_error())
+    return to_ints(h), ph.tobytes(), k
+
+
+def hasher_digest(values):
+    """utils/hasher.rs:12-26"""
+    out = np.zeros((2, 2), dtype=np.uint64)
+    lib().orc_hasher_digest(_p(_vec(values)), ctypes.c_size_t(len(values)), _p(out))
+    return to_ints(out)
+
+
+def stack_run(public_inputs, secret_a, secret_b, ops, init_len=16, max_regs=32):
+    """The user stack alone (processor/stack/mod.rs).  ``ops``: names / codes or (op, hint_kind, hint_value) tuples.
+    Returns (states, depth, max_depth): states[k] = register file after k operations (as wide as the reference's ``registers``)."""
+    code, kinds, vals = [], [], []
+    for o in ops:
+        if isinstance(o, tuple):
+            code.append(o[0]); kinds.append(HINTS[o[1]]); vals.append(o[2] if len(o) > 2 else 0)
+        else:
+            code.append(o); kinds.append(0); vals.append(0)
+    code = _opcodes(code); kinds = np.array(kinds, dtype=np.uint8); vals = to_arr(vals) if len(vals) else np.zeros((1, 2), dtype=np.uint64)
+    n = len(code)
+    states = np.zeros((n + 1, max_regs, 2), dtype=np.uint64); depth = np.zeros(n + 1, dtype=np.uint64); md = np.zeros(n + 1, dtype=np.uint64)
+    pub, sa, sb = _vec(public_inputs), _vec(secret_a), _vec(secret_b)
+    k = lib().orc_stack_run(_p(pub), ctypes.c_size_t(len(public_inputs)), _p(sa), ctypes.c_size_t(len(secret_a)), _p(sb), ctypes.c_size_t(len(secret_b)),
+                            ctypes.c_size_t(init_len), _p(code), _p(kinds), _p(vals), ctypes.c_size_t(n), _p(states), ctypes.c_size_t(max_regs), _p(depth), _p(md))
+    if k < 0:
+        raise RuntimeError(last_error())
+    return [to_ints(states[i, :k]) for i in range(n + 1)], [int(x) for x in depth], [int(x) for x in md]
 
 
 def fibonacci_source(n_terms):
