@@ -66,7 +66,12 @@ SELECTION = [
     "test_trace_in_its_own_buffer",
     "test_small_fri_layers_in_one_launch_equal_the_per_layer_path",
     "test_prove_sharded_with_collectives_on_their_own_stream[2]",
-]
+    "test_isa_traces_cover_every_operation",
+] + ["test_whole_instruction_set_and_flow_blocks[%s-%s]" % (name, instance) for name, instance in (
+    ("stack_manipulation", ""), ("choose2", "generic"), ("cswap2", ""), ("math_inv_neg_not", ""), ("bool_and_or", "generic"), ("read_read2", ""), ("eq", ""),
+    ("rescr_double_hash", ""), ("cmp_128", ""), ("binacc_128", "generic"), ("if_true", "generic"), ("if_false", ""), ("while_skipped", ""),
+    ("while_5_iterations", ""), ("while_5_iterations", "generic"), ("nested_loops", ""), ("nested_loops", "generic"), ("example_comparison", ""),
+    ("example_merkle", ""), ("example_range", "generic"))]
 
 
 @pytest.fixture(scope="module")

@@ -237,6 +237,88 @@ def test_deep_stacks_and_nested_blocks(oracle, monkeypatch, instance):
         _check_all_phases(oracle, D, oracle.Trace(src, inputs), num_outputs=num_outputs)
 
 
+def _pad_ops(ops, n):
+    return ops + ["noop"] * (n - len(ops))
+
+
+def _isa_traces(O):
+    """Valid traces covering EVERY user operation and every flow operation (BEGIN / TEND / FEND / LOOP / WRAP / BREAK / VOID): the
+    reference's own end-to-end fixtures (src/tests/mod.rs:66-315, src/tests/comparisons.rs, src/processor/mod.rs:237-346) and its example
+    programs, as tests/test_oracle_isa.py pins them on the oracle.  name -> (trace, number of outputs)"""
+    import random
+    P = 2**128 - 45 * 2**40 + 1
+    rnd = random.Random(5)
+    a, b = rnd.randrange(P), rnd.randrange(P)
+    bits = lambda v, n: [(v >> i) & 1 for i in range(n)][::-1]
+    T = {}
+    T["stack_manipulation"] = (O.Trace.from_ops(
+        ["begin"] + ["noop"] * 7 + ["swap", "swap2", "swap4", "roll4", "roll8", "dup", "add", "pad2", "push", "swap4", "drop4", "dup2", "swap4", "add", "add", "dup4",
+                                    "push", "add", "add", "add", "add", "noop", "noop"], [11, 12], [7, 6, 5, 4, 3, 2, 1, 0]), 8)
+    T["choose"] = (O.Trace.from_ops(_pad_ops(["begin", "choose", "choose"], 15), [], [3, 4, 1, 5, 0, 6, 7, 8]), 8)
+    T["choose2"] = (O.Trace.from_ops(_pad_ops(_pad_ops(_pad_ops(["begin"], 8) + ["push"], 16) + ["push", "choose2", "choose2"], 31), [3, 4], [5, 6, 1, 0, 7, 8, 0, 0]), 8)
+    T["cswap2"] = (O.Trace.from_ops(_pad_ops(["begin", "cswap2", "pad2", "swap4", "cswap2"], 15), [], [3, 4, 1, 2, 1, 0, 5, 6]), 8)
+    T["math_inv_neg_not"] = (O.Trace.from_ops(_pad_ops(["begin", "add", "mul", "inv", "neg", "swap", "not"], 15), [], [7, 6, 5, 0, 2, 3]), 2)
+    T["bool_and_or"] = (O.Trace.from_ops(_pad_ops(["begin", "not", "or", "or", "and", "and", "not"], 15), [], [1, 0, 1, 1, 0]), 1)
+    T["read_read2"] = (O.Trace.from_ops(_pad_ops(_pad_ops(["begin", "read", "read2"], 8) + ["push"], 15), [5], [1], [2, 3], [4]), 5)
+    T["assert_asserteq"] = (O.Trace.from_ops(_pad_ops(["begin", "assert", "noop", "asserteq"], 15), [], [1, 3, 3]), 2)
+    T["eq"] = (O.Trace.from_ops(_pad_ops(["begin", "read", "eq", "swap2", "read", "eq"], 15), [], [1, 2, 3, 4, 4], [pow(P - 1, P - 2, P), 1]), 3)
+    T["rescr_double_hash"] = (O.Trace.from_ops(_pad_ops(["begin"], 16) + ["rescr"] * 10 + ["drop4", "noop", "pad2", "dup2", "noop", "noop"] + ["rescr"] * 10 + ["drop4"]
+                                               + ["noop"] * 4, [], [0, 0, 4, 3, 2, 1]), 2)
+    T["cmp_128"] = (O.Trace.from_ops(_pad_ops(_pad_ops(["begin", "pad2"], 8) + ["push"] + ["cmp"] * 128 + ["drop4"], 255), [1 << 127], [0, 0, 0, 0, 0, a, b],
+                                     bits(a, 128), bits(b, 128)), 4)
+    T["binacc_128"] = (O.Trace.from_ops(_pad_ops(["begin"] + ["binacc"] * 128 + ["drop"] * 3, 255), [], [0, 0, 1, 0, a], [(a >> (127 - i)) & 1 for i in range(128)][::-1]), 2)
+    T["if_true"] = (O.Trace("begin read if.true add push.3 else push.7 add push.8 end mul end", [5, 3], [1]), 2)
+    T["if_false"] = (O.Trace("begin read if.true add push.3 else push.7 add push.8 end mul end", [5, 3], [0]), 2)
+    T["while_skipped"] = (O.Trace("begin mul read while.true dup mul read end end", [5, 3], [0]), 1)
+    T["while_5_iterations"] = (O.Trace("begin mul read while.true dup mul read end end", [5, 3], [1, 1, 1, 1, 1, 0]), 1)
+    T["nested_loops"] = (O.Trace("begin read while.true read while.true push.2 mul read end push.3 add read end end", [1], [1, 1, 1, 0, 1, 0, 0, 0]), 1)
+    T["example_comparison"] = (O.Trace("begin push.9 read dup.2 lt.128 if.true mul else add end dup isodd.128 end", [], [6]), 2)
+    T["example_collatz"] = (O.Trace("begin pad read dup push.1 ne while.true swap push.1 add swap dup isodd.128 if.true push.3 mul push.1 add else push.2 div end "
+                                    "dup push.1 ne end swap end", [], [3]), 1)
+    path = [[rnd.randrange(P) for _ in range(3)] for _ in range(2)]
+    ta, tb, index = [path[0][0]], [path[1][0]], 2 + 4
+    for i in range(1, 3):
+        ta += [0, path[0][i]]; tb += [index & 1, path[1][i]]; index >>= 1
+    for i in range(1, 3):
+        ta.append(path[0][i]); tb.append(path[1][i])
+    T["example_merkle"] = (O.Trace("begin read.ab dup.2 smpath.3 swap.2 push.2 roll.4 swap swap.2 pmpath.3 end", [], ta, tb), 4)
+    T["example_range"] = (O.Trace("begin read rc.63 add read rc.63 add end", [0], [5, (1 << 63) + 17]), 1)
+    return T
+
+
+ISA_TRACE_NAMES = ["stack_manipulation", "choose", "choose2", "cswap2", "math_inv_neg_not", "bool_and_or", "read_read2", "assert_asserteq", "eq", "rescr_double_hash",
+                   "cmp_128", "binacc_128", "if_true", "if_false", "while_skipped", "while_5_iterations", "nested_loops", "example_comparison", "example_collatz",
+                   "example_merkle", "example_range"]
+
+
+@pytest.mark.parametrize("instance", ["", "generic"])
+@pytest.mark.parametrize("name", ISA_TRACE_NAMES)
+def test_whole_instruction_set_and_flow_blocks(oracle, monkeypatch, name, instance):
+    """a7 / a8 on valid traces of the whole instruction set and of if / while blocks (loop registers, LOOP / WRAP / BREAK / FEND rows): every
+    intermediate of every phase against the oracle, through the default constraint instance for the shape and through the per-operation
+    formulation (DISTAFF_AIR=generic).  The oracle side of these traces is pinned by the reference's literals in tests/test_oracle_isa.py."""
+    import distaff_amd as D
+    if instance:
+        monkeypatch.setenv("DISTAFF_AIR", instance)
+    trace, num_outputs = _isa_traces(oracle)[name]
+    assert trace.trace_hash() == trace.program_hash
+    _check_all_phases(oracle, D, trace, num_outputs=num_outputs, grinding=8)
+
+
+def test_isa_traces_cover_every_operation(oracle):
+    """the set above executes all 32 user operations and all 8 flow operations, with loop_depth 0, 1 and 2 and ctx_depth up to 3"""
+    users, flows, loop_depths = set(), set(), set()
+    for trace, _ in _isa_traces(oracle).values():
+        cols = trace.columns[:, :, 0].astype(np.int64)
+        flows |= set((cols[5] + 2 * cols[6] + 4 * cols[7]).tolist())
+        hacc = (cols[5] + cols[6] + cols[7]) == 0
+        users |= set(sum(cols[8 + i] << i for i in range(7))[hacc].tolist())
+        loop_depths.add(trace.loop_depth)
+    assert flows == set(range(8))
+    assert users == set(oracle.OPS.values())
+    assert loop_depths >= {0, 1, 2}
+
+
 def test_program_shapes_with_stack_depth_5_to_8(oracle):
     """Stack depth 5..8 (with and without a context register): the depth <= 8 kernel instance evaluates the low-degree stack
     operations as nested sums over all eight slots."""
