@@ -248,17 +248,44 @@ def error_line(message):
 
 
 def start_watchdog(seconds):
-    """a collective that never returns (a rank died, RCCL cannot reach a peer) must end the run with an error line, not hang the driver"""
+    """a collective that never returns (a rank died, RCCL cannot reach a peer) must end the run with an error line, not hang the driver.
+    It measures STALL time: every stage change and every finished step (progress()) re-arms it, so a long but progressing run (config 5's
+    trace generation, the CPU leg, the profiled steps) is not cut off."""
     import threading
+    _STATE["progress_at"] = time.monotonic()
+    stop = threading.Event()
 
-    def fire():
-        error_line("no progress for %d s in stage '%s' (BENCH_TIMEOUT_S): giving up instead of hanging" % (seconds, _STATE["stage"]))
-        sys.stdout.flush(); sys.stderr.flush()
-        os._exit(3)
-    t = threading.Timer(seconds, fire)
-    t.daemon = True
+    def watch():
+        while not stop.wait(1.0):
+            idle = time.monotonic() - _STATE["progress_at"]
+            if idle > seconds:
+                error_line("no progress for %d s in stage '%s' (BENCH_TIMEOUT_S): giving up instead of hanging" % (idle, _STATE["stage"]))
+                sys.stdout.flush(); sys.stderr.flush()
+                os._exit(3)
+    t = threading.Thread(target=watch, daemon=True)
     t.start()
+    t.cancel = stop.set
     return t
+
+
+def progress(stage=None):
+    if stage is not None:
+        _STATE["stage"] = stage
+    _STATE["progress_at"] = time.monotonic()
+
+
+def library_identity(D, allow_override):
+    """Which shared library this process measures.  Anything but the in-tree product build (distaff_amd/libdistaff_hip.so) is refused unless
+    --allow-lib-override is given -- DISTAFF_HIP_LIB can point the binding at any other build, the CPU emulation of the tests included --
+    and every DISTAFF_* / BENCH_* variable that is set goes into the line."""
+    product = os.path.join(os.path.dirname(os.path.abspath(__file__)), "distaff_amd", "libdistaff_hip.so")
+    loaded = os.path.realpath(D.LIB_PATH)
+    ident = {"path": os.path.relpath(loaded, os.path.dirname(os.path.abspath(__file__))), "is_product_build": loaded == os.path.realpath(product),
+             "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("DISTAFF_", "BENCH_"))}}
+    if not ident["is_product_build"] and not allow_override:
+        raise SystemExit("the loaded library is %s, not distaff_amd/libdistaff_hip.so (DISTAFF_HIP_LIB=%r): refusing to measure it; pass --allow-lib-override to do so anyway"
+                         % (loaded, os.environ.get("DISTAFF_HIP_LIB")))
+    return ident
 
 
 def main():
@@ -276,6 +303,7 @@ def main():
     ap.add_argument("--no-verify", action="store_true", help="skip the one-time check of the timed proof by the oracle's verifier (outside the timed regions)")
     ap.add_argument("--no-upload-leg", action="store_true", help="skip the second timed region (trace starting in pinned host memory)")
     ap.add_argument("--force-sharded", action="store_true", help="run the sharded (multi-GPU) code path even with one rank")
+    ap.add_argument("--allow-lib-override", action="store_true", help="measure whatever library DISTAFF_HIP_LIB names instead of refusing anything but distaff_amd/libdistaff_hip.so")
     args = ap.parse_args()
     if args.log_n is None:
         args.log_n = int(os.environ.get("BENCH_LOG_N", "16" if args.workload == "commit" else "20"))
@@ -307,6 +335,7 @@ def run(args):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("--gpus %d does not match WORLD_SIZE %d" % (args.gpus, world))
+    lib_ident = library_identity(D, args.allow_lib_override)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP prover has no CPU fallback")
     if world > 8 or (world & (world - 1)):
@@ -327,7 +356,7 @@ def run(args):
     if shared_devices:
         want = "callbacks"
     dist = None
-    _STATE["stage"] = "process group"
+    progress("process group")
     if world > 1 or args.force_sharded:
         import datetime
         import torch.distributed as dist
@@ -345,13 +374,13 @@ def run(args):
 
     log_n = args.log_n
     n = 1 << log_n
-    _STATE["stage"] = "trace"
+    progress("trace")
     if args.workload == "commit":
         cols, program_hash, result = splitmix_columns(log_n, W_FIB), None, None
     else:
         cols, program_hash, result = fibonacci_trace_cached(D, log_n)   # host: VM trace of `begin repeat.K swap dup.2 drop add end end`
     blowup = 1 << args.log_blowup
-    _STATE["stage"] = "context"
+    progress("context")
     ctx = D.Context(log_n, W_FIB, 1, 0, device=device, rank=rank, world=world, log_blowup=args.log_blowup, num_queries=args.queries)   # defaults = default ProofOptions: blowup 32, 50 queries, grinding 20
     c_orchestration = (world > 1 or args.force_sharded) and os.environ.get("DISTAFF_SHARD_ORCH", "c") != "python"
     if c_orchestration and world > 1:
@@ -359,9 +388,10 @@ def run(args):
     else:
         ctx.upload(cols)                                            # inputs resident in HBM before the timed region
 
-    _STATE["stage"] = "communicator"
+    progress("communicator")
     stage_of = None
     transport_note = None
+    comm_info = None
     if args.workload == "commit":
         def prove():
             return ctx.commit_trace()
@@ -405,6 +435,18 @@ def run(args):
                 transport = "dst_prove_sharded over the callback transport (torch.distributed %s%s)" % (
                     dist.get_backend(), ", host-staged, ranks sharing %d device(s)" % ndev if shared_devices else "")
 
+            # what the transport says about itself, from every rank: for RCCL the number of ranks the live communicator connected
+            # (ncclCommCount), each rank's index in it and the device it runs on -- the line's proof that RCCL saw `world` ranks
+            infos = [None] * world
+            dist.all_gather_object(infos, dict(comm.describe(), local_rank=local_rank, visible_device=device))
+            comm_info = {"transport": infos[0]["transport"], "ranks_per_rank": [i["rccl_ranks"] for i in infos] if infos[0]["transport"] == "rccl" else None,
+                         "rccl_rank_per_rank": [i["rccl_rank"] for i in infos] if infos[0]["transport"] == "rccl" else None,
+                         "rccl_version": infos[0]["rccl_version"] or None,
+                         "device_per_rank": [i["device"] if i["device"] >= 0 else i["visible_device"] for i in infos],
+                         "all_ranks_same_transport": len({i["transport"] for i in infos}) == 1}
+            if comm_info["transport"] == "rccl" and any(k != world for k in comm_info["ranks_per_rank"]):
+                raise SystemExit("the RCCL communicators report %s ranks, the job has %d" % (comm_info["ranks_per_rank"], world))
+
             def stage_of():
                 return ctx.shard_stage_ms()
 
@@ -441,13 +483,14 @@ def run(args):
             def prove():
                 return prover.prove([1, 0], [result])
 
-    _STATE["stage"] = "warm-up"
+    progress("warm-up")
     proof = None
     for _ in range(args.warmup):
         proof = prove()
+        progress()
     # timed region: HIP events around the heavy kernels only (NTT passes, constraint kernel, leaf hashing: the dominant kernel is one
     # of them); bracketing all ~300 launches of a proof costs ~5 % and is done on one extra, untimed step for the kernel table
-    _STATE["stage"] = "timed region"
+    progress("timed region")
     ctx.set_profiling(2)
     ctx.kernel_stats(reset=True)
     barrier()
@@ -459,6 +502,7 @@ def run(args):
         ts = time.perf_counter()
         proof = prove()
         step_ms.append((time.perf_counter() - ts) * 1e3)               # prove() returns the finished proof: no extra synchronisation
+        progress()
         for i, v in enumerate(ctx.phase_ms()):
             phase_sum[i] += v
         if stage_of is not None:
@@ -470,7 +514,7 @@ def run(args):
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if host_group else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    _STATE["stage"] = "kernel table"
+    progress("kernel table")
     stats = ctx.kernel_stats(reset=True)
     ctx.set_profiling(1)
     prove()                                                        # untimed: every launch bracketed, for the "kernels" table
@@ -481,7 +525,7 @@ def run(args):
     # the upload is asynchronous DMA and the registers are extended group by group as they arrive
     incl_upload_ms = None
     if transport == "none" and not args.no_upload_leg:
-        _STATE["stage"] = "upload leg"
+        progress("upload leg")
         table, handle = ctx.pinned_trace(cols)
         for _ in range(max(1, args.warmup)):
             ctx.upload_async(table); proof_u = prove()
@@ -501,7 +545,7 @@ def run(args):
             dist.barrier()                                             # rank 0 may still verify / time the CPU leg: leave together
             dist.destroy_process_group()
         return
-    _STATE["stage"] = "report"
+    progress("report")
 
     ms_per_step = elapsed / args.steps * 1e3
     cells = n * W_FIB
@@ -589,6 +633,7 @@ def run(args):
         "prover_ms": ms_per_step,
         "phase_ms": None if transport.startswith("torch") else {k: round(v / args.steps, 3) for k, v in zip(phase_names, phase_sum) if args.workload == "prove" or k in ("lde", "trace_merkle")},
         "proof_bytes": len(proof),
+        "library": lib_ident,
         "shard_stage_ms_rank0": {k: round(v / args.steps, 3) for k, v in stage_sum.items()} or None,
         "roofline": roofline,
         "roofline_transform": roofline_transform,
@@ -606,9 +651,10 @@ def run(args):
     if world > 1 or args.force_sharded:
         out["devices"] = {"visible": ndev, "ranks": world, "shared": shared_devices,
                           "note": ("%d ranks share %d device(s): a FUNCTIONAL run of the N-process path on this box, not a scaling measurement" % (world, ndev)) if shared_devices else None}
+        out["comm"] = comm_info
         if transport_note:
             out["transport_note"] = transport_note
-    _STATE["stage"] = "verification"
+    progress("verification")
     if args.workload == "commit":
         out["proof_bytes"] = None
         out["trace_root_hex"] = proof.hex()
@@ -619,7 +665,7 @@ def run(args):
         if not ok:
             raise SystemExit("the oracle's verifier rejects the timed proof: " + err)
         out["proof_verified"] = "accepted by oracle/verifier.hpp (restatement of stark::verify) after the timed regions"
-    _STATE["stage"] = "cpu baseline"
+    progress("cpu baseline")
     if world == 1 and not args.no_cpu_baseline:
         if args.workload == "commit":
             out["cpu_baseline"] = cpu_baseline_commit(cols, blowup)

@@ -11,6 +11,7 @@
 #include <stddef.h>
 #include <stdint.h>
 #include <string>
+#include <vector>
 #include "ctx.h"
 
 struct dst_comm {
@@ -22,8 +23,35 @@ struct dst_comm {
     // collectives overlap with kernels of other streams); the others return when the exchange is complete.  The host synchronises the
     // stream before it reads results.  all_gather may be in place: send == recv + rank * bytes_per_rank.
     virtual bool stream_ordered() const { return false; }
-    virtual int all_gather(const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream) = 0;      // recv = [world][bytes]
-    virtual int all_to_all(const void* send, void* recv, size_t chunk_bytes, hipStream_t stream) = 0;         // chunk g of send -> rank g; chunk r of recv <- rank r
+    int all_gather(const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream) { note('G', bytes_per_rank, stream); return all_gather_impl(send, recv, bytes_per_rank, stream); }   // recv = [world][bytes]
+    int all_to_all(const void* send, void* recv, size_t chunk_bytes, hipStream_t stream) { note('A', chunk_bytes, stream); return all_to_all_impl(send, recv, chunk_bytes, stream); }           // chunk g of send -> rank g; chunk r of recv <- rank r
     // small host values (status words, lengths, opening blobs)
-    virtual int all_gather_host(const void* send, void* recv, size_t bytes_per_rank) = 0;
+    int all_gather_host(const void* send, void* recv, size_t bytes_per_rank) { note('H', bytes_per_rank, nullptr); return all_gather_host_impl(send, recv, bytes_per_rank); }
+
+    // Issue-order record (dst_comm_trace; DISTAFF_SHARD_DEBUG=1 switches it on at creation): one entry per collective -- kind, bytes per
+    // rank, and which of the streams this communicator has seen it was queued on (index by first appearance; '-' = host values).  RCCL
+    // requires every rank to issue the collectives of a communicator in the same order; a transport that forgives a mismatch (gloo, the
+    // in-process one) hides it, so the multi-process tests compare these records across ranks.
+    struct CollRec { char kind; uint8_t stream; uint64_t bytes; };
+    bool tracing = false;
+    std::vector<CollRec> trace;
+    std::vector<hipStream_t> seen_streams;
+    void note(char kind, size_t bytes, hipStream_t s) {
+        if (!tracing) return;
+        uint8_t tag = 255;
+        if (kind != 'H') {
+            size_t i = 0;
+            while (i < seen_streams.size() && seen_streams[i] != s) i++;
+            if (i == seen_streams.size()) seen_streams.push_back(s);
+            tag = (uint8_t)i;
+        }
+        trace.push_back(CollRec{kind, tag, (uint64_t)bytes});
+    }
+    // what dst_comm_describe reports
+    virtual int transport_kind() const = 0;                      // DST_COMM_RCCL / DST_COMM_LOCAL / DST_COMM_CALLBACKS
+    virtual void fill_info(dst_comm_info* out) const {}
+protected:
+    virtual int all_gather_impl(const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream) = 0;
+    virtual int all_to_all_impl(const void* send, void* recv, size_t chunk_bytes, hipStream_t stream) = 0;
+    virtual int all_gather_host_impl(const void* send, void* recv, size_t bytes_per_rank) = 0;
 };

@@ -22,6 +22,10 @@ struct RcclApi {
     int (*Recv)(void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
+    int (*CommCount)(ncclComm_t, int*) = nullptr;
+    int (*CommCuDevice)(ncclComm_t, int*) = nullptr;
+    int (*CommUserRank)(ncclComm_t, int*) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     std::string error;
 };
@@ -43,6 +47,10 @@ RcclApi* rccl_api() {
         api.GroupStart = (int (*)())sym("ncclGroupStart");
         api.GroupEnd = (int (*)())sym("ncclGroupEnd");
         api.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
+        api.CommCount = (int (*)(ncclComm_t, int*))sym("ncclCommCount");
+        api.CommCuDevice = (int (*)(ncclComm_t, int*))sym("ncclCommCuDevice");
+        api.CommUserRank = (int (*)(ncclComm_t, int*))sym("ncclCommUserRank");
+        api.GetVersion = (int (*)(int*))sym("ncclGetVersion");
     });
     return &api;
 }
@@ -60,12 +68,21 @@ struct RcclComm : dst_comm {
         if (own_stream) hipStreamDestroy(own_stream);
     }
     bool stream_ordered() const override { return true; }
-    int all_gather(const void* send, void* recv, size_t bytes, hipStream_t stream) override {
+    int transport_kind() const override { return DST_COMM_RCCL; }
+    void fill_info(dst_comm_info* o) const override {
+        int v = 0;
+        // what RCCL itself says about this communicator: the number of ranks it connected, this rank's index and device
+        if (api->CommCount(comm, &v) == ncclSuccess) o->rccl_ranks = (uint32_t)v;
+        if (api->CommUserRank(comm, &v) == ncclSuccess) o->rccl_rank = (uint32_t)v;
+        if (api->CommCuDevice(comm, &v) == ncclSuccess) o->device = v;
+        if (api->GetVersion && api->GetVersion(&v) == ncclSuccess) o->rccl_version = (uint32_t)v;
+    }
+    int all_gather_impl(const void* send, void* recv, size_t bytes, hipStream_t stream) override {
         int r = api->AllGather(send, recv, bytes, ncclUint8, comm, stream);          // in place when send == recv + rank * bytes
         if (r != ncclSuccess) return fail(r, "ncclAllGather");
         return DST_OK;
     }
-    int all_to_all(const void* send, void* recv, size_t chunk, hipStream_t stream) override {
+    int all_to_all_impl(const void* send, void* recv, size_t chunk, hipStream_t stream) override {
         int r = api->GroupStart();
         if (r != ncclSuccess) return fail(r, "ncclGroupStart");
         for (uint32_t p = 0; p < world; p++) {
@@ -75,7 +92,7 @@ struct RcclComm : dst_comm {
         if ((r = api->GroupEnd()) != ncclSuccess) return fail(r, "ncclGroupEnd");
         return DST_OK;
     }
-    int all_gather_host(const void* send, void* recv, size_t bytes) override {
+    int all_gather_host_impl(const void* send, void* recv, size_t bytes) override {
         const size_t need = bytes * (world + 1);
         if (need > staging_bytes) {
             if (staging) hipFree(staging);
@@ -98,8 +115,9 @@ struct LocalShared {
     std::mutex mu; std::condition_variable cv;
     uint32_t arrived = 0; uint64_t generation = 0; bool aborted = false;
     std::vector<const void*> ptr;
+    std::vector<int> device;                          // device of every rank's thread (-1 until its first device collective)
     uint32_t refs;
-    explicit LocalShared(uint32_t w) : world(w), ptr(w, nullptr), refs(w) {}
+    explicit LocalShared(uint32_t w) : world(w), ptr(w, nullptr), device(w, -1), refs(w) {}
     bool barrier() {                                   // false: another rank gave up (dst_comm_destroy while peers wait)
         std::unique_lock<std::mutex> lk(mu);
         if (aborted) return false;
@@ -118,10 +136,33 @@ struct LocalComm : dst_comm {
         if (last) delete sh;
     }
     int broken() { err = "local communicator: a peer rank left the collective"; return DST_ERR_STATE; }
+    int transport_kind() const override { return DST_COMM_LOCAL; }
+    int my_device = -1;
+    bool peers_checked = false;
+    uint32_t peers_enabled = 0, peers_other_device = 0;
+    void fill_info(dst_comm_info* o) const override { o->device = my_device; o->peers_other_device = peers_other_device; o->peers_enabled = peers_enabled; }
+    // The ranks' buffers live on different devices when a single-process host drives all GPUs of the node (dst_prove_sharded_local):
+    // without peer access a device-to-device hipMemcpy between them is staged through the host instead of crossing xGMI.  Enabled once,
+    // from every rank's own thread towards every other rank's device; a pair that cannot be enabled stays on the staged path silently.
+    void enable_peer_access() {
+        peers_checked = true;
+        for (uint32_t p = 0; p < world; p++) {
+            const int pd = sh->device[p];
+            if (p == rank || pd < 0 || pd == my_device) continue;
+            peers_other_device++;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, my_device, pd) != hipSuccess || !can) { (void)hipGetLastError(); continue; }
+            const hipError_t e = hipDeviceEnablePeerAccess(pd, 0);
+            if (e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled) peers_enabled++;
+            (void)hipGetLastError();                   // "already enabled" is not an error of this call site
+        }
+    }
     int exchange(const void* send, hipStream_t stream, bool host, const std::function<hipError_t(uint32_t peer, const void* peer_send)>& take) {
         if (!host && hipStreamSynchronize(stream) != hipSuccess) { err = "local collective: stream synchronisation failed"; return DST_ERR_HIP; }
+        if (!host && my_device < 0) { if (hipGetDevice(&my_device) != hipSuccess) my_device = -1; sh->device[rank] = my_device; }
         sh->ptr[rank] = send;
         if (!sh->barrier()) return broken();
+        if (!host && !peers_checked && my_device >= 0) enable_peer_access();      // every rank has published its device before the barrier
         hipError_t e = hipSuccess;
         for (uint32_t p = 0; p < world && e == hipSuccess; p++) e = take(p, sh->ptr[p]);
         if (!host && e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -129,16 +170,16 @@ struct LocalComm : dst_comm {
         if (e != hipSuccess) { err = std::string("local collective: ") + hipGetErrorString(e); return DST_ERR_HIP; }
         return DST_OK;
     }
-    int all_gather(const void* send, void* recv, size_t bytes, hipStream_t stream) override {
+    int all_gather_impl(const void* send, void* recv, size_t bytes, hipStream_t stream) override {
         return exchange(send, stream, false, [&](uint32_t p, const void* src) {
             uint8_t* dst = (uint8_t*)recv + (size_t)p * bytes;
             return dst == src ? hipSuccess : hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, stream);          // in place: the own piece is already there
         });
     }
-    int all_to_all(const void* send, void* recv, size_t chunk, hipStream_t stream) override {
+    int all_to_all_impl(const void* send, void* recv, size_t chunk, hipStream_t stream) override {
         return exchange(send, stream, false, [&](uint32_t p, const void* src) { return hipMemcpyAsync((uint8_t*)recv + (size_t)p * chunk, (const uint8_t*)src + (size_t)rank * chunk, chunk, hipMemcpyDefault, stream); });
     }
-    int all_gather_host(const void* send, void* recv, size_t bytes) override {
+    int all_gather_host_impl(const void* send, void* recv, size_t bytes) override {
         return exchange(send, nullptr, true, [&](uint32_t p, const void* src) { memcpy((uint8_t*)recv + (size_t)p * bytes, src, bytes); return hipSuccess; });
     }
 };
@@ -153,12 +194,14 @@ struct CallbackComm : dst_comm {
         if (r) { err = "the host's collective callback returned " + std::to_string(r); return DST_ERR_STATE; }
         return DST_OK;
     }
-    int all_gather(const void* send, void* recv, size_t bytes, hipStream_t stream) override { return call(0, send, recv, bytes, stream); }
-    int all_to_all(const void* send, void* recv, size_t chunk, hipStream_t stream) override { return call(1, send, recv, chunk, stream); }
-    int all_gather_host(const void* send, void* recv, size_t bytes) override { return call(2, send, recv, bytes, nullptr); }
+    int transport_kind() const override { return DST_COMM_CALLBACKS; }
+    int all_gather_impl(const void* send, void* recv, size_t bytes, hipStream_t stream) override { return call(0, send, recv, bytes, stream); }
+    int all_to_all_impl(const void* send, void* recv, size_t chunk, hipStream_t stream) override { return call(1, send, recv, chunk, stream); }
+    int all_gather_host_impl(const void* send, void* recv, size_t bytes) override { return call(2, send, recv, bytes, nullptr); }
 };
 }  // namespace
 
+static bool shard_debug_env() { const char* e = getenv("DISTAFF_SHARD_DEBUG"); return e && e[0] && e[0] != '0'; }
 static thread_local std::string g_comm_error;      // errors before a communicator exists, per calling thread (ranks may be threads)
 
 extern "C" {
@@ -187,6 +230,7 @@ int dst_comm_init(const uint8_t id[128], uint32_t rank, uint32_t world, int devi
     int r = api->CommInitRank(&c->comm, (int)world, u, (int)rank);
     if (r != ncclSuccess) { g_comm_error = std::string("ncclCommInitRank: ") + api->GetErrorString(r); c->comm = nullptr; delete c; return DST_ERR_HIP; }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { g_comm_error = "dst_comm_init: stream creation failed"; delete c; return DST_ERR_HIP; }
+    c->tracing = shard_debug_env();
     *out = c;
     return DST_OK;
 }
@@ -194,7 +238,7 @@ int dst_comm_init(const uint8_t id[128], uint32_t rank, uint32_t world, int devi
 int dst_comm_init_local(uint32_t world, dst_comm** out) {
     if (!out || world == 0 || world > 64) { g_comm_error = "dst_comm_init_local: bad arguments"; return DST_ERR_ARG; }
     LocalShared* sh = new LocalShared(world);
-    for (uint32_t r = 0; r < world; r++) { LocalComm* c = new LocalComm(); c->rank = r; c->world = world; c->sh = sh; out[r] = c; }
+    for (uint32_t r = 0; r < world; r++) { LocalComm* c = new LocalComm(); c->rank = r; c->world = world; c->sh = sh; c->tracing = shard_debug_env(); out[r] = c; }
     return DST_OK;
 }
 
@@ -202,11 +246,37 @@ int dst_comm_init_callbacks(uint32_t rank, uint32_t world, dst_comm_fn fn, void*
     if (!out || !fn || world == 0 || rank >= world) { g_comm_error = "dst_comm_init_callbacks: bad arguments"; return DST_ERR_ARG; }
     CallbackComm* c = new CallbackComm();
     c->rank = rank; c->world = world; c->fn = fn; c->user = user;
+    c->tracing = shard_debug_env();
     *out = c;
     return DST_OK;
 }
 
 void dst_comm_destroy(dst_comm* comm) { delete comm; }
+
+int dst_comm_describe(const dst_comm* comm, dst_comm_info* out) {
+    if (!comm || !out) return DST_ERR_ARG;
+    memset(out, 0, sizeof(*out));
+    out->transport = (uint32_t)comm->transport_kind(); out->rank = comm->rank; out->world = comm->world; out->device = -1;
+    comm->fill_info(out);
+    return DST_OK;
+}
+
+// enable: 1 start (clears the record), 0 stop, -1 leave as is.  Writes the record so far as text, one collective per line:
+// "<kind> <bytes per rank> <stream>" with kind G all-gather, A all-to-all, H all-gather of host values; stream = index of the stream
+// among those this communicator has queued collectives on, in order of first use ('-' for host values).
+int dst_comm_trace(dst_comm* comm, int enable, char* out, size_t cap, size_t* len) {
+    if (!comm) return DST_ERR_ARG;
+    std::string text;
+    for (const auto& r : comm->trace) {
+        text += r.kind; text += ' '; text += std::to_string(r.bytes); text += ' ';
+        text += r.stream == 255 ? std::string("-") : std::to_string((unsigned)r.stream); text += '\n';
+    }
+    if (len) *len = text.size();
+    if (out && cap) { const size_t k = text.size() < cap - 1 ? text.size() : cap - 1; memcpy(out, text.data(), k); out[k] = 0; }
+    if (enable == 1) { comm->tracing = true; comm->trace.clear(); comm->seen_streams.clear(); }
+    else if (enable == 0) comm->tracing = false;
+    return DST_OK;
+}
 
 // For hosts whose own transport (dst_comm_init_callbacks) stages through memory the library did not allocate: one synchronous copy
 // between any two of {host memory, memory of the current device}; the direction follows from the pointers.

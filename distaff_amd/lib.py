@@ -24,7 +24,8 @@ EXPORTS = ["dst_ctx_create", "dst_ctx_destroy", "dst_last_error", "dst_phase_ms"
            "dst_read_buffer", "dst_bench_mulmod", "dst_bench_mad", "dst_bench_code", "dst_trace_upload_async", "dst_pinned_alloc", "dst_pinned_free", "dst_set_profiling", "dst_kernel_stats", "dst_field_op",
            "dst_shard_commit_trace", "dst_shard_eval_constraints", "dst_shard_combine", "dst_shard_fri_layer", "dst_shard_fri_fold",
            "dst_shard_export_size", "dst_shard_export", "dst_shard_import", "dst_shard_read", "dst_shard_fri_begin", "dst_shard_fri_end", "dst_shard_fri_roots", "dst_shard_open", "dst_shard_assemble", "dst_shard_info",
-           "dst_comm_unique_id", "dst_comm_init", "dst_comm_init_local", "dst_comm_init_callbacks", "dst_comm_destroy", "dst_comm_last_error", "dst_comm_copy", "dst_prove_sharded", "dst_prove_sharded_local", "dst_shard_stage_ms"]
+           "dst_comm_unique_id", "dst_comm_init", "dst_comm_init_local", "dst_comm_init_callbacks", "dst_comm_destroy", "dst_comm_last_error", "dst_comm_copy", "dst_prove_sharded", "dst_prove_sharded_local", "dst_shard_stage_ms",
+           "dst_comm_describe", "dst_comm_trace"]
 
 
 class DistaffError(RuntimeError):
@@ -42,6 +43,12 @@ class Params(ctypes.Structure):
 class Public(ctypes.Structure):
     _fields_ = [("num_inputs", ctypes.c_uint32), ("num_outputs", ctypes.c_uint32),
                 ("inputs", (ctypes.c_uint8 * 16) * 8), ("outputs", (ctypes.c_uint8 * 16) * 8)]
+
+
+class CommInfo(ctypes.Structure):
+    _fields_ = [("transport", ctypes.c_uint32), ("rank", ctypes.c_uint32), ("world", ctypes.c_uint32), ("device", ctypes.c_int32),
+                ("rccl_ranks", ctypes.c_uint32), ("rccl_rank", ctypes.c_uint32), ("rccl_version", ctypes.c_uint32),
+                ("peers_other_device", ctypes.c_uint32), ("peers_enabled", ctypes.c_uint32)]
 
 
 _lib = None
@@ -151,6 +158,30 @@ class Comm:
 
     def __init__(self, handle):
         self.lib, self._h = load(), handle
+
+    def describe(self):
+        """dst_comm_describe: transport, rank / world, and what the transport says about itself -- for RCCL the number of ranks the live
+        communicator connected (ncclCommCount), this rank's index and device; for the in-process transport the peer-access picture."""
+        info = CommInfo()
+        if self.lib.dst_comm_describe(self._h, ctypes.byref(info)) != DST_OK:
+            raise DistaffError(DST_ERR_ARG, "dst_comm_describe failed")
+        d = {f: int(getattr(info, f)) for f, _ in CommInfo._fields_}
+        d["transport"] = ("rccl", "local", "callbacks")[d["transport"]]
+        return d
+
+    def trace(self, enable=-1):
+        """dst_comm_trace: the collectives this rank has issued so far as [(kind, bytes per rank, stream index or None)]; enable = 1 starts a
+        fresh record, 0 stops, -1 leaves recording as it is."""
+        n = ctypes.c_size_t(0)
+        self.lib.dst_comm_trace(self._h, ctypes.c_int(-1), None, ctypes.c_size_t(0), ctypes.byref(n))
+        buf = ctypes.create_string_buffer(n.value + 1)
+        if self.lib.dst_comm_trace(self._h, ctypes.c_int(enable), buf, ctypes.c_size_t(n.value + 1), ctypes.byref(n)) != DST_OK:
+            raise DistaffError(DST_ERR_ARG, "dst_comm_trace failed")
+        out = []
+        for line in buf.value.decode().splitlines():
+            k, b, st = line.split()
+            out.append((k, int(b), None if st == "-" else int(st)))
+        return out
 
     @staticmethod
     def unique_id():

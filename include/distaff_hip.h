@@ -206,6 +206,22 @@ int dst_comm_init_local(uint32_t world, dst_comm** out /* [world] */);
 typedef int (*dst_comm_fn)(void* user, int kind, const void* send, void* recv, size_t bytes);
 int dst_comm_init_callbacks(uint32_t rank, uint32_t world, dst_comm_fn fn, void* user, dst_comm** out);
 void dst_comm_destroy(dst_comm* comm);
+/* What a communicator is and what its transport says about itself.  For the RCCL transport rccl_ranks / rccl_rank / device come from
+ * ncclCommCount / ncclCommUserRank / ncclCommCuDevice on the live communicator (the proof that RCCL connected `world` ranks);
+ * for the in-process transport peers_other_device = ranks whose buffers live on another device than this rank's and peers_enabled = how many
+ * of those this rank reaches with peer access (hipDeviceEnablePeerAccess; the others are staged through the host), both known after the
+ * first device collective. */
+enum { DST_COMM_RCCL = 0, DST_COMM_LOCAL = 1, DST_COMM_CALLBACKS = 2 };
+typedef struct dst_comm_info {
+    uint32_t transport, rank, world;
+    int32_t device;                     /* -1 when the transport does not know it */
+    uint32_t rccl_ranks, rccl_rank, rccl_version;
+    uint32_t peers_other_device, peers_enabled;
+} dst_comm_info;
+int dst_comm_describe(const dst_comm* comm, dst_comm_info* out);
+/* Issue-order record of the collectives of this rank (see comm.h): enable = 1 start / 0 stop / -1 unchanged; `out` receives the record so
+ * far as text ("<G|A|H> <bytes per rank> <stream index|->" per line), *len its full length.  DISTAFF_SHARD_DEBUG=1 starts it at creation. */
+int dst_comm_trace(dst_comm* comm, int enable, char* out, size_t cap, size_t* len);
 /* helper for callback transports that stage through their own buffers: one synchronous copy of `bytes` between host memory and memory of
  * the calling thread's current device, in either direction or device to device (the direction follows from the pointers) */
 int dst_comm_copy(void* dst, const void* src, size_t bytes);

@@ -54,5 +54,5 @@ def _comm_on_cpu(self, dist_, device=None, device_path=False):
 
 
 sharded.TorchComm.__init__ = _comm_on_cpu
-sys.argv = [os.path.join(ROOT, "bench.py")] + sys.argv[1:]
+sys.argv = [os.path.join(ROOT, "bench.py"), "--allow-lib-override"] + sys.argv[1:]     # the emulated build is not the product: bench.py refuses it otherwise
 runpy.run_path(sys.argv[0], run_name="__main__")

@@ -65,7 +65,7 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { return emu_atomic_ad
 
 // ---- runtime API (the subset the library uses) --------------------------------------------------------------------------------
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100, hipErrorPeerAccessAlreadyEnabled = 704 };
 typedef struct emu_stream* hipStream_t;
 typedef struct emu_event* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
@@ -77,6 +77,8 @@ hipError_t hipGetLastError();
 hipError_t hipGetDeviceCount(int* n);
 hipError_t hipSetDevice(int d);
 hipError_t hipGetDevice(int* d);
+inline hipError_t hipDeviceCanAccessPeer(int* can, int, int) { *can = 0; return hipSuccess; }      // one emulated device
+inline hipError_t hipDeviceEnablePeerAccess(int, unsigned) { return hipErrorInvalidValue; }
 hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d);
 hipError_t hipDeviceSynchronize();
 hipError_t hipMalloc(void** p, size_t bytes);

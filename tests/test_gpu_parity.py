@@ -1058,11 +1058,60 @@ def test_prove_sharded_over_rccl_with_one_rank(oracle):
     t = O.fibonacci_trace(1 << 10)
     op = O.Prover.from_trace(t, 1, grinding=8)
     comm = D.Comm.rccl(D.Comm.unique_id(), 0, 1, 0)
+    info = comm.describe()                                    # what RCCL itself reports for the live communicator (bench.py prints it for N > 1)
+    assert info["transport"] == "rccl" and (info["rccl_ranks"], info["rccl_rank"], info["device"]) == (1, 0, 0) and info["rccl_version"] > 0
+    comm.trace(1)
     ctx = D.Context(10, t.width, t.ctx_depth, t.loop_depth, grinding=8)
     ctx.upload(t.columns)
     assert ctx.prove_sharded(comm, t.public_inputs, op.outputs) == op.prove()
+    assert [k for k, _, _ in comm.trace(0)][-2:] == ["H", "H"]
     ctx.close()
     comm.close()
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_thread_rank_transport_issue_order_and_peer_access(oracle, world):
+    """The in-process transport with one Python thread per rank (what dst_prove_sharded_local does with C++ threads): every rank issues
+    the same collective sequence, and each reports the peer-access picture of its device -- on this box all ranks share GPU 0, so no
+    peer is on another device (on a multi-GPU node every other rank's device is enabled with hipDeviceEnablePeerAccess once, so that the
+    device-to-device copies of the exchanges cross xGMI instead of being staged through the host)."""
+    import threading
+    import distaff_amd as D
+    O = oracle
+    t = O.fibonacci_trace(1 << 9)
+    op = O.Prover.from_trace(t, 1, grinding=8)
+    expected = op.prove()
+    comms = D.Comm.local(world)
+    ctxs = []
+    for r in range(world):
+        ctx = D.Context(9, t.width, t.ctx_depth, t.loop_depth, rank=r, world=world, grinding=8)
+        ctx.upload(t.columns)
+        ctxs.append(ctx)
+        comms[r].trace(1)
+    proofs, errors = [None] * world, []
+
+    def run(r):
+        try:
+            proofs[r] = ctxs[r].prove_sharded(comms[r], t.public_inputs, op.outputs)
+        except Exception as e:                                # noqa: BLE001
+            errors.append((r, e))
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    assert all(p == expected for p in proofs)
+    records = [cm.trace(0) for cm in comms]
+    assert all(rec == records[0] for rec in records) and len(records[0]) > 10
+    for r, cm in enumerate(comms):
+        info = cm.describe()
+        assert info["transport"] == "local" and (info["rank"], info["world"]) == (r, world)
+        assert info["device"] == 0 and info["peers_other_device"] == 0 and info["peers_enabled"] == 0
+    for ctx in ctxs:
+        ctx.close()
+    for cm in comms:
+        cm.close()
 
 
 def test_prove_sharded_reports_an_invalid_trace_on_every_rank(oracle):
@@ -1219,6 +1268,8 @@ import distaff_amd as D
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 log_n = int(sys.argv[1])
+if sys.argv[3] == "overlap":
+    os.environ["DISTAFF_SHARD_FORCE_OVERLAP"] = "1"                         # the stream / event choreography of a stream-ordered transport (RCCL)
 cols, program_hash, result = D.fibonacci_trace(log_n)
 ctx = D.Context(log_n, 20, 1, 0, device=0, rank=rank, world=world)       # every rank on GPU 0
 if rank %% 2:
@@ -1226,11 +1277,24 @@ if rank %% 2:
 else:
     ctx.upload_owned(cols)                                                  # only the registers this rank interpolates
 comm = D.Comm.over_torch(dist)                                              # dst_comm_init_callbacks, gloo carrying the library's collectives
+info = comm.describe()
+assert info["transport"] == "callbacks" and info["rank"] == rank and info["world"] == world
+comm.trace(1)
 for k in range(2):                                                          # twice: buffers of the first proof are reused
     proof = ctx.prove_sharded(comm, [1, 0], [result])
     open(os.path.join(sys.argv[2], "proof_%%d_%%d.bin" %% (rank, k)), "wb").write(proof)
 stages = ctx.shard_stage_ms()
 assert stages["tree_exchanges"] >= 2 and stages["transport_calls"] > 0
+# RCCL deadlocks when two ranks issue the collectives of a communicator in different orders; gloo forgives it.  Every rank's record
+# of what it issued (kind, bytes per rank, stream) must be the same sequence.
+mine = comm.trace(0)
+every = [None] * world
+dist.all_gather_object(every, mine)
+assert all(e == every[0] for e in every), "ranks issued different collective sequences"
+assert len(mine) %% 2 == 0 and mine[:len(mine) // 2] == mine[len(mine) // 2:], "the second proof issued another sequence than the first"
+if rank == 0:
+    import json
+    json.dump(mine[:len(mine) // 2], open(os.path.join(sys.argv[2], "collectives.json"), "w"))
 ctx.close(); comm.close()
 dist.barrier()
 dist.destroy_process_group()
@@ -1238,13 +1302,16 @@ print("ok")
 """
 
 
-@pytest.mark.parametrize("world,log_n", [(2, 12), (4, 12), (2, 16), (4, 16), (8, 12)])
-def test_prove_sharded_in_separate_processes_sharing_the_gpu(tmp_path, world, log_n):
+@pytest.mark.parametrize("world,log_n,streams", [(2, 12, "one"), (4, 12, "overlap"), (2, 16, "overlap"), (4, 16, "one"), (8, 12, "one"), (8, 12, "overlap")])
+def test_prove_sharded_in_separate_processes_sharing_the_gpu(tmp_path, world, log_n, streams):
     """`world` OS processes, each with its own HIP runtime, context and communicator handle, all on GPU 0, each calling
     dst_prove_sharded: the library's own orchestration (column-split interpolation, k-range tree exchange, status records) with its
     all-gathers / all-to-alls on DEVICE buffers carried between the processes by gloo through the callback transport
     (dst_comm_init_callbacks + dst_comm_copy).  RCCL refuses several ranks on one device, so this is the closest a one-GPU box gets to
-    the driver's N-process run; every rank must write the single-context proof, twice."""
+    the driver's N-process run; every rank must write the single-context proof, twice.  The ranks also compare the ORDER in which they issued
+    the collectives (dst_comm_trace): kind, size and stream of every one -- with `streams` = overlap in the two-stream choreography the
+    RCCL transport uses (coefficient all-gathers and the exchange of the constraint evaluations on the collective stream)."""
+    import json
     import os
     import socket
     import subprocess
@@ -1257,9 +1324,14 @@ def test_prove_sharded_in_separate_processes_sharing_the_gpu(tmp_path, world, lo
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, str(script), str(log_n), str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+        procs.append(subprocess.Popen([sys.executable, str(script), str(log_n), str(tmp_path), streams], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
     outs = [p.communicate(timeout=600)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+    seq = json.load(open(tmp_path / "collectives.json"))
+    kinds = "".join(k for k, _, _ in seq)
+    rounds = (20 + world - 1) // world
+    assert kinds.startswith("G" * rounds + "AG") and kinds.endswith("HH") and kinds.count("A") >= 2      # coefficient rounds, trace tree (all-to-all + records), ..., openings
+    assert {st for _, _, st in seq if st is not None} == ({0, 1} if streams == "overlap" else {0})
     cols, program_hash, result = D.fibonacci_trace(log_n)
     ctx = D.Context(log_n, 20, 1, 0)
     ctx.upload(cols)
@@ -1294,6 +1366,8 @@ def test_bench_with_n_processes_on_one_device(ranks):
     assert "error" not in d, d
     assert d["n_gpus"] == ranks and d["steps"] == 2 and d["scaling"] == "strong" and d["value"] > 0 and d["proof_verified"]
     assert d["devices"]["shared"] and d["devices"]["ranks"] == ranks and "callback transport" in d["config"]["parallelism"]
+    assert d["comm"]["transport"] == "callbacks" and d["comm"]["all_ranks_same_transport"] and len(d["comm"]["device_per_rank"]) == ranks
+    assert d["library"]["path"].endswith(".so") and isinstance(d["library"]["env"], dict)
     assert set(d["phase_ms"]) >= {"lde", "trace_merkle", "constraint_eval", "fri", "openings"} and all(v >= 0 for v in d["phase_ms"].values())
     st = d["shard_stage_ms_rank0"]
     assert st and st["transport_calls"] > 0 and st["tree_exchanges"] >= 2

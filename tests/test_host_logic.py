@@ -168,3 +168,20 @@ def test_merged_stack_terms_equal_the_per_operation_sum(tmp_path):
     subprocess.check_call(["g++", "-x", "c++", "-std=c++17", "-O1", "-pthread", "-I", emu, "-w", "-DFE_EMULATE_GFX950=1", os.path.join(emu, "air_merge_test.cpp"), "-o", str(exe)])
     out = subprocess.run([str(exe)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=600)
     assert out.returncode == 0 and b" 0 mismatches" in out.stdout, out.stdout.decode()[-2000:]
+
+
+def test_bench_refuses_another_library_than_the_product_build(tmp_path):
+    """DISTAFF_HIP_LIB points the binding at any other build (the tests' CPU emulation included): bench.py must not measure that silently.
+    It ends with the contract's error line; --allow-lib-override is the explicit way (tests/emu/bench_harness.py passes it)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    other = tmp_path / "libother.so"
+    other.write_bytes(open(os.path.join(root, "distaff_amd", "libdistaff_hip.so"), "rb").read())
+    env = dict(os.environ, DISTAFF_HIP_LIB=str(other))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1", "--warmup", "0"], cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert r.returncode != 0
+    d = json.loads([ln for ln in r.stdout.decode().splitlines() if ln.startswith("{")][-1])
+    assert d["value"] is None and "refusing to measure" in d["error"] and "libother.so" in d["error"]
