@@ -115,7 +115,7 @@ def valu_issue(stats, proof_ms, steps):
 
 
 
-def box_fingerprint(ctx, mad_peak, mulmod_peak):
+def box_fingerprint(cal, mad_peak, mulmod_peak):
     """What tells one box of the pool from another: the two arithmetic calibrations, the straight-line-code probe (dst_bench_code: time per
     instruction of 176 KiB of code against 16 KiB -- 1.0 on a healthy device), device name / CU count and rocm-smi's clocks and partition modes."""
     import subprocess
@@ -129,7 +129,7 @@ def box_fingerprint(ctx, mad_peak, mulmod_peak):
     except Exception as e:                                           # noqa: BLE001
         box["device_error"] = str(e)
     try:
-        t16, t176, t176c = ctx.bench_code(16), ctx.bench_code(176), ctx.bench_code(177)
+        t16, t176, t176c = cal.bench_code(16), cal.bench_code(176), cal.bench_code(177)
         box["code_probe"] = {"ms_16KiB": round(t16, 4), "ms_176KiB": round(t176, 4), "per_instruction_ratio": round((t176 / 176.0) / (t16 / 16.0), 3),
                              "ms_176KiB_convoy": round(t176c, 4), "convoy_per_instruction_ratio": round((t176c / 176.0) / (t16 / 16.0), 3),
                              "note": "2^23 lanes, 128 per workgroup, two waves per SIMD, every wavefront runs the code once (kernels_probe.hip); "
@@ -279,7 +279,7 @@ def library_identity(D, allow_override):
     --allow-lib-override is given -- DISTAFF_HIP_LIB can point the binding at any other build, the CPU emulation of the tests included --
     and every DISTAFF_* / BENCH_* variable that is set goes into the line."""
     product = os.path.join(os.path.dirname(os.path.abspath(__file__)), "distaff_amd", "libdistaff_hip.so")
-    loaded = os.path.realpath(D.LIB_PATH)
+    loaded = os.path.realpath(D.library_path())
     ident = {"path": os.path.relpath(loaded, os.path.dirname(os.path.abspath(__file__))), "is_product_build": loaded == os.path.realpath(product),
              "env": {k: v for k, v in sorted(os.environ.items()) if k.startswith(("DISTAFF_", "BENCH_"))}}
     if not ident["is_product_build"] and not allow_override:
@@ -328,6 +328,7 @@ def main():
 
 def run(args):
     import torch
+    os.environ.pop("DISTAFF_TEST_HOOKS", None)                       # bench.py measures the product library, whatever its caller's tests bound
     import distaff_amd as D
 
     rank = int(os.environ.get("RANK", "0"))
@@ -581,7 +582,8 @@ def run(args):
     # on this device, against the multiply-adds the kernels execute: NTT launches count theirs (18 per table-pair multiplication), the
     # constraint kernels are priced with the static instruction counts of the current build (distaff_amd/_build_info.json)
     mad_iters = 2048
-    mad_ms = ctx.bench_mad(1 << 21, mad_iters)
+    cal = D.Calibration(device)                                      # calibration kernels: test / bench build (libdistaff_hip_hooks.so), beside the measured product library
+    mad_ms = cal.bench_mad(1 << 21, mad_iters)
     mad_peak = (1 << 21) * mad_iters * 32 / (mad_ms * 1e-3)
     air_isa = {}
     try:
@@ -613,7 +615,7 @@ def run(args):
     except Exception as e:                                           # noqa: BLE001  (never lose the bench line over a summary file)
         alu["valu_issue"] = {"error": str(e)}
     # ALU ceiling: dependent-chain modular multiplications per second measured on this device with the same fe_mul
-    mm_ms = ctx.bench_mulmod(1 << 21, 512)
+    mm_ms = cal.bench_mulmod(1 << 21, 512)
     mulmod_peak = (1 << 21) * 512 * 4 / (mm_ms * 1e-3)
     if args.workload == "commit":
         workload = ("BASELINE config 2: LDE (iNTT + coset NTTs) + BLAKE3 row hashing + Merkle tree of %d uniform random columns (splitmix64, SURVEY.md 8(d)) of 2^%d steps, "
@@ -639,7 +641,7 @@ def run(args):
         "roofline_transform": roofline_transform,
         "rooflines": rooflines,
         "step_ms": {"min": round(min(step_ms), 3), "median": round(float(np.median(step_ms)), 3), "max": round(max(step_ms), 3), "all": [round(x, 3) for x in step_ms]},
-        "box": box_fingerprint(ctx, mad_peak, mulmod_peak),
+        "box": box_fingerprint(cal, mad_peak, mulmod_peak),
         "alu_roofline": dict(alu, mulmod_peak_measured=mulmod_peak, mulmod_kernel="mulmod_bench_kernel: general fe_mul, 4 dependent chains per lane (21 mads + 50 other VALU instructions each)"),
         "phase_hbm": phase_hbm,
         "prover_ms_incl_upload": incl_upload_ms,
@@ -675,6 +677,7 @@ def run(args):
         else:
             out["cpu_baseline"] = cpu_baseline(args.cpu_log_n, blowup, args.queries)
     print(json.dumps(out), flush=True)
+    cal.close()
     ctx.close()
     if dist is not None:
         dist.barrier()

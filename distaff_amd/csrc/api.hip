@@ -105,6 +105,7 @@ static void free_all(dst_ctx* c) {
 }
 
 static int ctx_init(dst_ctx* c) {
+    c->read_switches();                                  // the DISTAFF_* variables as they are NOW; nothing reads the environment after this
     const dst_params& p = c->prm;
     if (p.log_trace_length < 4 || p.log_trace_length > 24) { c->err = "log_trace_length must be in [4, 24]"; return DST_ERR_ARG; }      // lib.rs:82 MIN_TRACE_LENGTH = 16
     if (p.log_blowup < 4 || p.log_blowup > 8) { c->err = "extension factor must be in [16, 256]"; return DST_ERR_ARG; }
@@ -124,13 +125,13 @@ static int ctx_init(dst_ctx* c) {
     c->device = p.device;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamCreate(&c->stream));
-    HIP_TRY(c, hipHostMalloc((void**)&c->h_stage, 65536, hipHostMallocDefault));
+    HIP_TRY(c, hipHostMalloc((void**)&c->h_stage, HS_TOTAL, hipHostMallocDefault));
     for (hipEvent_t& e : c->ph_ev) HIP_TRY(c, hipEventCreate(&e));
 
     // NTT plan: n = n1 * n2 in two HBM passes, tiles bounded by 64 KiB of LDS; from n = 2^21 (measured cross-over) three passes n = n1 * nm * n3 with
     // 16-column tiles (256-byte HBM segments) instead of 4096-point tiles that hold one or two columns
     NttPlan& pl = c->plan;
-    const char* force = getenv("DISTAFF_NTT");
+    const char* force = c->sw("DISTAFF_NTT");
     // n = 2^21, 2^22: still two passes -- their 2048-point factors run as a register pre-stage + 1024-point LDS tiles (NttArgs::pre);
     // DISTAFF_NTT=pre forces the pre-stages onto smaller transforms (tests), DISTAFF_NTT=3pass keeps the three-pass plan from 2^21 on
     const bool force_3 = force && !strcmp(force, "3pass"), force_pre = force && !strcmp(force, "pre") && c->log_n >= 10 && c->log_n <= 22;
@@ -141,7 +142,7 @@ static int ctx_init(dst_ctx* c) {
         // shape n1 * nm * n3 with n1 >= nm >= n3 as balanced as possible, at most 2^8 each; DISTAFF_NTT_SHAPE=a,b overrides n1, nm (tests)
         uint32_t a = (c->log_n + 2) / 3, b = (c->log_n - a + 1) / 2;
         if (a > 8) { a = 8; b = 8; }
-        if (const char* sh = getenv("DISTAFF_NTT_SHAPE")) { unsigned x = 0, y = 0; if (sscanf(sh, "%u,%u", &x, &y) == 2 && x >= 4 && y >= 4 && x <= 8 && y <= 8 && x + y + 4 <= c->log_n && c->log_n - x - y <= 8) { a = x; b = y; } }
+        if (const char* sh = c->sw("DISTAFF_NTT_SHAPE")) { unsigned x = 0, y = 0; if (sscanf(sh, "%u,%u", &x, &y) == 2 && x >= 4 && y >= 4 && x <= 8 && y <= 8 && x + y + 4 <= c->log_n && c->log_n - x - y <= 8) { a = x; b = y; } }
         pl.log_n1 = a; pl.log_n2 = c->log_n - a; pl.log_n3 = c->log_n - a - b;
     }
     else { pl.log_n1 = (c->log_n + 1) / 2; pl.log_n2 = c->log_n / 2; pl.log_n3 = 0; }
@@ -228,7 +229,7 @@ static int ctx_init(dst_ctx* c) {
     // a whole number of rounds
     if ((r = dev_alloc(c, &c->polys, (c->W + c->prm.world - 1) / c->prm.world * c->prm.world * n))) return r;
     if ((r = dev_alloc(c, &c->lde, c->W * Nl))) return r;
-    if (c->j0 == 0 && c->Bc > 1 && !(getenv("DISTAFF_TRACE_BUFFER") && getenv("DISTAFF_TRACE_BUFFER")[0] == '1')) { c->trace = c->lde; c->trace_stride = Nl; }     // see ctx.h; DISTAFF_TRACE_BUFFER=1: separate buffer + copy (tests)
+    if (c->j0 == 0 && c->Bc > 1 && !c->sw_is("DISTAFF_TRACE_BUFFER", "1")) { c->trace = c->lde; c->trace_stride = Nl; }     // see ctx.h; DISTAFF_TRACE_BUFFER=1: separate buffer + copy (tests)
     else { if ((r = dev_alloc(c, &c->trace, c->W * n))) return r; c->trace_stride = n; }
     // staging buffer of the two-pass transforms: tmp_regs registers x Bc cosets per pair of launches.  Every launch ends with a partly
     // filled last wave of workgroups (4 registers x 31 cosets at n = 2^20: 7.75 waves of 512 resident workgroups), so as many registers per
@@ -239,7 +240,7 @@ static int ctx_init(dst_ctx* c) {
     { size_t free_b = 0, total_b = 0; if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 4 < stage_cap) stage_cap = free_b / 4; }
     c->tmp_regs = 4;
     while (c->tmp_regs < c->W && (c->tmp_regs + 1) * (pl.log_n3 ? 2 : 1) * c->Bc * n * sizeof(fe) <= stage_cap) c->tmp_regs++;
-    if (const char* e = getenv("DISTAFF_TMP_REGS")) { const long k = atol(e); if (k >= 4 && k <= (long)c->W) c->tmp_regs = (size_t)k; }
+    if (const char* e = c->sw("DISTAFF_TMP_REGS")) { const long k = atol(e); if (k >= 4 && k <= (long)c->W) c->tmp_regs = (size_t)k; }
     if ((r = dev_alloc(c, &c->tmp, c->Bc * c->tmp_regs * n))) return r;
     if (pl.log_n3 && (r = dev_alloc(c, &c->tmp2, c->Bc * c->tmp_regs * n))) return r;
     if ((r = dev_alloc(c, &c->trace_leaves, Nl))) return r;
@@ -421,6 +422,17 @@ int dst_commit_trace(dst_ctx* c, uint8_t trace_root[32]) {
 // ---- steps 3-5 ------------------------------------------------------------------------------------------------------------------
 // constraint degrees in constraint-index order (decoder/mod.rs:31-47, stack/mod.rs:40-41) and the coefficient each
 // constraint receives when they are visited in degree-group order (evaluator.rs:335-358,385-406; coefficients.rs:140-185)
+// the 344 constraint coefficients and the compacted transition coefficients -> device, queued from the page-locked staging area (the
+// callers' vectors go out of scope while the copies may still be pending: the evaluation's verdict is not waited for)
+int dst_internal_upload_draws(dst_ctx* c, const fe* draws344, const std::vector<fe>& tc, fe* d_coef, fe* d_tc) {
+    if ((344 + tc.size()) * sizeof(fe) > HS_DRAWS_BYTES) { c->err = "too many transition coefficients for the staging area"; return DST_ERR_ARG; }
+    fe* h = reinterpret_cast<fe*>(c->h_stage + HS_DRAWS);
+    memcpy(h, draws344, 344 * sizeof(fe));
+    memcpy(h + 344, tc.data(), tc.size() * sizeof(fe));
+    HIP_TRY(c, hipMemcpyAsync(d_coef, h, 344 * sizeof(fe), hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(d_tc, h + 344, tc.size() * sizeof(fe), hipMemcpyHostToDevice, c->stream));
+    return DST_OK;
+}
 void dst_internal_transition_coefficients(const dst_ctx* c, const fe* draws344, std::vector<fe>& tc) {
     const size_t cl = c->prm.ctx_depth > 1 ? c->prm.ctx_depth : 1, ll = c->prm.loop_depth > 1 ? c->prm.loop_depth : 1;
     const size_t sl = c->stack_depth > 8 ? c->stack_depth : 8;
@@ -446,7 +458,7 @@ void dst_internal_transition_coefficients(const dst_ctx* c, const fe* draws344, 
 // linear combinations of the trace polynomials: A = sum_k cc_k v_k at [0, n) and A' = sum_k cc'_k v_k at [p, p + n).  Nothing is
 // evaluated and nothing is interpolated: ip / fp (8n coefficients each, before the divisions) are written directly.
 // DISTAFF_BOUNDARY=eval keeps the evaluate-and-interpolate route (the tests compare its evaluation vectors with the oracle's).
-bool dst_internal_boundary_by_evaluation() { const char* e = getenv("DISTAFF_BOUNDARY"); return e && !strcmp(e, "eval"); }
+bool dst_internal_boundary_by_evaluation(const dst_ctx* c) { return DST_TEST_HOOKS && c->sw_is("DISTAFF_BOUNDARY", "eval"); }
 int dst_internal_boundary_polys(dst_ctx* c, const fe* draws344, fe* ip, fe* fp, fe* o0, fe* o1, fe* o2, fe* o3) {
     const size_t n = c->n, D = 8 * n, W = c->W, p = 6 * n + 2;
     const uint32_t ctx_depth = c->prm.ctx_depth, loop_depth = c->prm.loop_depth;
@@ -483,8 +495,8 @@ int dst_internal_boundary_polys(dst_ctx* c, const fe* draws344, fe* ip, fe* fp, 
     for (size_t i = 0; i < 4 * W; i++) up[i] = fe_from_u128(w[i]);
     for (int i = 0; i < 4; i++) up[4 * W + i] = fe_from_u128(g[i]);
     fe* d_w = (fe*)c->d_stage;                           // staging area is free until the openings
-    // through the page-locked staging area: the copy is queued and the host moves on (the weights fit: 4 W + 4 elements < 64 KiB / 2)
-    fe* h_w = reinterpret_cast<fe*>(c->h_stage);
+    // through the page-locked staging area: the copy is queued and the host moves on
+    fe* h_w = reinterpret_cast<fe*>(c->h_stage + HS_WEIGHTS);
     memcpy(h_w, up.data(), up.size() * sizeof(fe));
     HIP_TRY(c, hipMemcpyAsync(d_w, h_w, up.size() * sizeof(fe), hipMemcpyHostToDevice, c->stream));
     fe* outs[4] = {o0, o1, o2, o3};                       // [pass][adj]
@@ -501,7 +513,7 @@ int dst_internal_boundary_polys(dst_ctx* c, const fe* draws344, fe* ip, fe* fp, 
 // DISTAFF_COMBINE=steps: combine_polys and the DEEP composition as the reference's sequence of whole-array steps (boundary polynomials of
 // 8n coefficients, their divisions, additions; copy / division / multiply-adds of the composition) instead of the fused passes.  Tests
 // run both; the boundary-by-evaluation route implies it.
-bool dst_internal_combine_by_steps() { const char* e = getenv("DISTAFF_COMBINE"); return (e && !strcmp(e, "steps")) || dst_internal_boundary_by_evaluation(); }
+bool dst_internal_combine_by_steps(const dst_ctx* c) { return DST_TEST_HOOKS && (c->sw_is("DISTAFF_COMBINE", "steps") || dst_internal_boundary_by_evaluation(c)); }
 
 // What the fused combination (k_combine_fused) reads of the two boundary constraints: I = A + x^p A', F = C + x^p C' (see
 // dst_internal_boundary_polys), p = 6n + 2, each of A, A', C, C' a linear combination of the trace polynomials with n coefficients.  Written
@@ -539,11 +551,10 @@ int dst_eval_constraints(dst_ctx* c, const dst_public* pub, const uint8_t* coeff
     dst_internal_transition_coefficients(c, draws.data(), tc);
     fe* d_coef = c->scratch + c->scratch_elems - 1024;           // tail of the scratch area
     fe* d_tc = d_coef + 344;
-    HIP_TRY(c, hipMemcpyAsync(d_coef, draws.data(), 344 * 16, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(d_tc, tc.data(), tc.size() * 16, hipMemcpyHostToDevice, c->stream));
+    if (int ru = dst_internal_upload_draws(c, draws.data(), tc, d_coef, d_tc)) return ru;
     // The host does not wait for the evaluation's verdict (evaluator.rs:152-158) before it queues the combination: the flag travels back
     // with the constraint root, and a trace that fails is reported then (the work queued behind it is wasted only in that case).
-    const bool steps = dst_internal_combine_by_steps();
+    const bool steps = dst_internal_combine_by_steps(c);
     int r = k_eval_constraints(c, d_coef, d_tc, bad_step, /*defer_check=*/!steps);   // prover.rs:53-64
     if (r == DST_ERR_AIR) { c->err = "transition constraints were not satisfied"; return r; }
     if (r != DST_OK) return r;
@@ -553,7 +564,7 @@ int dst_eval_constraints(dst_ctx* c, const dst_public* pub, const uint8_t* coeff
     fe* work = c->cwork + 3 * D;
     if (steps) {
         fe* ip = c->cwork; fe* fp = c->cwork + D; fe* tp = c->cwork + 2 * D;
-        if (dst_internal_boundary_by_evaluation()) {
+        if (dst_internal_boundary_by_evaluation(c)) {
             k_intt8_cosets(c, c->ceval, ip, work);
             k_intt8_cosets(c, c->ceval + D, fp, work);
         } else if ((r = dst_internal_boundary_polys(c, draws.data(), ip, fp))) return r;
@@ -580,7 +591,7 @@ int dst_eval_constraints(dst_ctx* c, const dst_public* pub, const uint8_t* coeff
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipGetLastError());
     if (!steps) {
-        c->air_flag_host = *reinterpret_cast<unsigned long long*>(c->h_stage + 65536 - 64);
+        c->air_flag_host = *reinterpret_cast<unsigned long long*>(c->h_stage + HS_AIR_FLAG);
         if ((r = k_constraint_check(c, bad_step)) != DST_OK) { c->err = "transition constraints were not satisfied"; return r; }
     }
     memcpy(constraint_root, c->constraint_root, 32);
@@ -597,8 +608,8 @@ int dst_eval_constraints(dst_ctx* c, const dst_public* pub, const uint8_t* coeff
 static void finish_deep_values(dst_ctx* c) {
     if (!c->deep_pending) return;
     const size_t W = c->W;
-    c->deep_z1.assign(c->h_stage + 32768, c->h_stage + 32768 + W * 16);
-    c->deep_z2.assign(c->h_stage + 32768 + 2048, c->h_stage + 32768 + 2048 + W * 16);
+    c->deep_z1.assign(c->h_stage + HS_DEEP, c->h_stage + HS_DEEP + W * 16);
+    c->deep_z2.assign(c->h_stage + HS_DEEP + HS_DEEP_HALF, c->h_stage + HS_DEEP + HS_DEEP_HALF + W * 16);
     c->deep_pending = false;
 }
 static int compose_impl(dst_ctx* c, const uint8_t* draws_bytes, uint8_t* trace_at_z1, uint8_t* trace_at_z2, bool wait);
@@ -618,9 +629,13 @@ static int compose_impl(dst_ctx* c, const uint8_t* draws_bytes, uint8_t* trace_a
     const fe k1 = draws[513], k2 = draws[514], k3 = draws[515];
     fe* d_draws = c->scratch + c->scratch_elems - 1024;           // [516] draws, then [W] T(z), [W] T(z*g), [1] C(z)
     fe* d_tz1 = d_draws + 520; fe* d_tz2 = d_tz1 + 128; fe* d_cz = d_tz2 + 128;
-    HIP_TRY(c, hipMemcpyAsync(d_draws, draws.data(), 516 * 16, hipMemcpyHostToDevice, c->stream));
+    {   // queued from the page-locked staging area: `draws` goes out of scope while the copy may still be pending (wait == false)
+        fe* h_draws = reinterpret_cast<fe*>(c->h_stage + HS_COMPOSE);
+        memcpy(h_draws, draws.data(), 516 * 16);
+        HIP_TRY(c, hipMemcpyAsync(d_draws, h_draws, 516 * 16, hipMemcpyHostToDevice, c->stream));
+    }
     // trace_table.rs:206-261
-    const bool steps = dst_internal_combine_by_steps();
+    const bool steps = dst_internal_combine_by_steps(c);
     const fe zz[2] = {z, next_z};
     k_horner(c, c->polys, W, n, z, d_tz1);
     k_horner(c, c->polys, W, n, next_z, d_tz2);
@@ -654,8 +669,8 @@ static int compose_impl(dst_ctx* c, const uint8_t* draws_bytes, uint8_t* trace_a
     // evaluate over the LDE domain (prover.rs:98-101)
     k_lde_fold8(c, c->comp_poly, c->comp);
     HIP_TRY(c, hipEventRecord(c->ph_ev[1], c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->h_stage + 32768, d_tz1, W * 16, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(c->h_stage + 32768 + 2048, d_tz2, W * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_stage + HS_DEEP, d_tz1, W * 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_stage + HS_DEEP + HS_DEEP_HALF, d_tz2, W * 16, hipMemcpyDeviceToHost, c->stream));
     c->deep_pending = true;
     if (wait) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -698,7 +713,7 @@ int dst_fri_commit_layer(dst_ctx* c, uint8_t layer_root[32], int* more) {
 int dst_internal_fri_tail(dst_ctx* c, std::vector<uint8_t>& roots) {
     const int d = c->fri_committed;
     if (d < 1 || d != c->fri_folded || d >= c->num_fri_layers || c->fri_size[d] > DST_FRI_TAIL_MAX_SIZE) return 0;
-    if (const char* e = getenv("DISTAFF_FRI_TAIL")) if (e[0] == '0') return 0;
+    if (const char* e = c->sw("DISTAFF_FRI_TAIL")) if (e[0] == '0') return 0;
     double t0 = wall_ms();
     const int count = c->num_fri_layers - d;
     std::vector<uint8_t> r((size_t)count * 32);
@@ -781,7 +796,7 @@ static int fri_commit_all(dst_ctx* c, std::vector<uint8_t>& roots, bool chained)
     const int L = c->num_fri_layers;
     digest* d_roots = reinterpret_cast<digest*>(c->d_fri_chain);
     fe* d_alpha = reinterpret_cast<fe*>(c->d_fri_chain + DST_MAX_FRI_LAYERS * 32);
-    const char* te = getenv("DISTAFF_FRI_TAIL");
+    const char* te = c->sw("DISTAFF_FRI_TAIL");
     const bool tail_on = !(te && te[0] == '0');
     int d = 0;
     for (; d < L; d++) {
@@ -792,7 +807,7 @@ static int fri_commit_all(dst_ctx* c, std::vector<uint8_t>& roots, bool chained)
         if (d + 1 < L) k_fri_fold_dev(c, d, d_alpha + d);
     }
     const int big = d;                                                // layers committed by the per-layer kernels
-    uint8_t* h_roots = c->h_stage + 40960;                            // page-locked: queued, picked up after the wait below
+    uint8_t* h_roots = c->h_stage + HS_FRI_ROOTS;                      // page-locked: queued, picked up after the wait below
     if (big) HIP_TRY(c, hipMemcpyAsync(h_roots, d_roots, (size_t)big * 32, hipMemcpyDeviceToHost, c->stream));
     c->fri_committed = big; c->fri_folded = big < L ? big : L - 1;
     std::vector<uint8_t> tail_roots;
@@ -831,7 +846,7 @@ int dst_prove(dst_ctx* c, const dst_public* pub, uint8_t* proof_out, size_t cap,
     if ((rc = compose_impl(c, (const uint8_t*)draws.data(), z1.data(), z2.data(), false))) return rc;
     std::vector<uint8_t> roots;
     {
-        const char* ce = getenv("DISTAFF_FRI_CHAIN");
+        const char* ce = c->sw("DISTAFF_FRI_CHAIN");
         if ((rc = fri_commit_all(c, roots, !(ce && ce[0] == '0')))) return rc;
         // the commit phase's first wait covered the composition too: split at the device's own boundary (events of compose_impl)
         const double both = wall_ms() - t_compose;
@@ -952,6 +967,10 @@ int dst_kernel_stats(dst_ctx* c, char* json_out, size_t cap, int reset) {
     return DST_OK;
 }
 
+// Calibration kernels (dependent multiplication chains, the multiply-add peak, the straight-line-code probe): laboratory instruments of
+// bench.py and the tests, compiled only into the test / bench build (libdistaff_hip_hooks.so).  The product library keeps the entry
+// points and answers DST_ERR_STATE.
+#if DST_TEST_HOOKS
 int dst_bench_mulmod(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms) {
     if (!c || !ms) return DST_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -967,5 +986,13 @@ int dst_bench_mad(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms) {
     HIP_TRY(c, hipSetDevice(c->device));
     return k_bench_mad(c, lanes, iters, ms);
 }
+#else
+static int no_hooks(dst_ctx* c) { if (c) c->err = "calibration kernels are part of the test / bench build (libdistaff_hip_hooks.so) only"; return c ? DST_ERR_STATE : DST_ERR_ARG; }
+int dst_bench_mulmod(dst_ctx* c, uint64_t, uint32_t, double*) { return no_hooks(c); }
+int dst_bench_code(dst_ctx* c, uint32_t, double*) { return no_hooks(c); }
+int dst_bench_mad(dst_ctx* c, uint64_t, uint32_t, double*) { return no_hooks(c); }
+#endif
+// 1 when this is the test / bench build
+int dst_test_hooks(void) { return DST_TEST_HOOKS; }
 
 }  // extern "C"

@@ -39,6 +39,72 @@ typedef fe tw4_t;
 
 #define DST_MAX_FRI_LAYERS 24
 
+// Every DISTAFF_* variable the library looks at, in one place (INTEGRATION.md section 6 prints this table; a test keeps both in step).
+// They are read ONCE per context, when it is created (dst_ctx_create -> dst_ctx::sw), never per call.  `product` switches are operational
+// choices every build honours; the others select alternative formulations that exist for the tests to compare with the default ones and are
+// honoured only by the test / bench build (libdistaff_hip_hooks.so, -DDISTAFF_TEST_HOOKS): the product library does not even read them.
+// (DISTAFF_SHARD_DEBUG is also looked at by dst_comm_init*, which has no context: once, when the communicator is created.)
+struct dst_switch_def { const char* name; bool product; const char* values; const char* what; };
+static const dst_switch_def DST_SWITCHES[] = {
+    {"DISTAFF_SHARD_DEBUG",        true,  "1",               "stderr line per tree exchange on rank 0; communicators record the order of their collectives (dst_comm_trace)"},
+    {"DISTAFF_SHARD_TREE_GATHER",  true,  "1",               "sharded Merkle trees: all-gather of all boundary nodes + upper levels repeated on every rank (BASELINE north_star's all-gather-only form) instead of the k-range all-to-all"},
+    {"DISTAFF_SHARD_NO_OVERLAP",   true,  "1",               "sharded prover: every collective on the context's main stream (no second stream / events) also on a stream-ordered transport"},
+    {"DISTAFF_TMP_REGS",           true,  "4..W",            "registers per transform launch = size of the staging array (default: as many as 12 GiB hold, at most W)"},
+    {"DISTAFF_AIR",                false, "small|deep|generic", "force a more general constraint-kernel instance set than the trace shape needs (generic = per-operation formulation)"},
+    {"DISTAFF_BOUNDARY",           false, "eval",            "boundary combinations by evaluation on the 8n domain (the reference's route) instead of coefficient form"},
+    {"DISTAFF_COMBINE",            false, "steps",           "combine_polys / DEEP composition as the reference's sequence of whole-array steps instead of the fused passes"},
+    {"DISTAFF_NTT",                false, "pre|3pass|reg|lds", "force a transform plan family"},
+    {"DISTAFF_NTT_SHAPE",          false, "a,b",             "three-pass plans: log2 of the first two pass lengths"},
+    {"DISTAFF_NTT_ORDER",          false, "0",               "first pass of an extension in coset-slow block order"},
+    {"DISTAFF_NTT_WAVES",          false, "4|8",             "force the 512- or 1024-lane instances of the LDS passes"},
+    {"DISTAFF_NTT_FIXED",          false, "0",               "use the any-shape instances where a shape-compiled one exists"},
+    {"DISTAFF_NTT_DIF",            false, "0|1|2",           "first pass of an extension: coset DIT (0), pre-scale + DIF (1), DIT with last-stage twiddles from global memory (2)"},
+    {"DISTAFF_NTT_DEBUG",          false, "bits",            "1: print the occupancy of every launch shape once; 2: skip the four-step twiddle (timing ablation, wrong results)"},
+    {"DISTAFF_LDE_BATCH",          false, "cols,cosets",     "registers x cosets per transform launch"},
+    {"DISTAFF_FOLD8_DFT",          false, "0",               "8n-coefficient extensions without the fused fold + 8-point step"},
+    {"DISTAFF_TRACE_BUFFER",       false, "1",               "give the trace its own buffer instead of coset 0 of the extension"},
+    {"DISTAFF_MERKLE_LEVEL2_LOG",  false, "k",               "build two tree levels per launch from 2^k nodes on (default 2^15)"},
+    {"DISTAFF_MERKLE_LEVELS",      false, "1",               "one launch per tree level"},
+    {"DISTAFF_SYN_DIV_TABLES",     false, "1",               "synthetic division by power tables + scan instead of the blocked form"},
+    {"DISTAFF_FRI_TAIL",           false, "0|k",             "0: no single-launch tail; k: tail from layers of 2^k elements on"},
+    {"DISTAFF_FRI_CHAIN",          false, "0",               "FRI commit phase with a root read-back and a host draw per layer"},
+    {"DISTAFF_FRI_REPLICATE_LOG",  false, "k",               "sharded prover: replicate FRI layers from 2^k elements on (default 2^17)"},
+    {"DISTAFF_SHARD_FORCE_OVERLAP", false, "1",              "sharded prover: the two-stream choreography of a stream-ordered transport over a blocking one"},
+};
+// Layout of the page-locked staging area dst_ctx::h_stage (HS_TOTAL bytes): every small upload / read-back that must be QUEUED rather than
+// waited for has its own region, so that the lifetime of the host side of an asynchronous copy is explicit (a pageable source would be
+// staged by the runtime -- which makes the host wait for the stream -- or go out of scope).  Regions are reused per proof: the host
+// synchronises the stream at least once between two uses of the same region.
+enum : size_t {
+    HS_WEIGHTS = 0,                    // boundary weights: 4 W + 4 elements                                   (api.hip dst_internal_boundary_polys)
+    HS_WEIGHTS_BYTES = (4 * 128 + 4) * 16,
+    HS_DEEP = 32768,                   // read-back of T(z) at +0 and T(z g) at +HS_DEEP_HALF, W elements each   (api.hip compose_impl)
+    HS_DEEP_HALF = 2048,
+    HS_FRI_ROOTS = 40960,              // read-back of the FRI roots: 32 bytes per layer                          (api.hip / shard.hip FRI commit)
+    HS_FRI_SLOTS = 45056,              // sharded FRI layers: deferred tree records, HS_FRI_SLOT_BYTES per layer  (shard.hip dst_prove_sharded)
+    HS_FRI_SLOT_BYTES = 800,           //   G records of 96 bytes + the 32-byte root, G <= 8
+    HS_AIR_FLAG = 65536 - 64,          // read-back of the failing step of the constraint check                   (kernels_air.hip)
+    HS_DRAWS = 65536,                  // upload of the 344 constraint coefficients + the compacted transition coefficients (<= 156)
+    HS_DRAWS_BYTES = (344 + 160) * 16,
+    HS_COMPOSE = 65536 + 8192,         // upload of the 516 composition draws
+    HS_COMPOSE_BYTES = 516 * 16,
+    HS_STATUS = 65536 + 8192 + 8320,   // upload of this rank's status record of a tree exchange: a ring of HS_STATUS_SLOTS records of 64 bytes
+    HS_STATUS_SLOTS = 32,
+    HS_TOTAL = 131072
+};
+static_assert(HS_WEIGHTS + HS_WEIGHTS_BYTES <= HS_DEEP, "boundary weights overlap the DEEP values");
+static_assert(HS_DEEP_HALF >= 128 * 16 && HS_DEEP + 2 * HS_DEEP_HALF <= HS_FRI_ROOTS, "DEEP values: W <= 128 registers");
+static_assert(HS_FRI_ROOTS + DST_MAX_FRI_LAYERS * 32 <= HS_FRI_SLOTS, "FRI roots overlap the layer slots");
+static_assert(8 * 96 + 32 <= HS_FRI_SLOT_BYTES && HS_FRI_SLOTS + DST_MAX_FRI_LAYERS * HS_FRI_SLOT_BYTES <= HS_AIR_FLAG, "FRI layer slots: G <= 8 ranks, DST_MAX_FRI_LAYERS layers");
+static_assert(HS_DRAWS + HS_DRAWS_BYTES <= HS_COMPOSE && HS_COMPOSE + HS_COMPOSE_BYTES <= HS_STATUS && HS_STATUS + HS_STATUS_SLOTS * 64 <= HS_TOTAL, "upload regions overlap");
+static_assert(HS_STATUS_SLOTS >= 2 + DST_MAX_FRI_LAYERS, "one status slot per tree exchange of a proof");
+
+#ifdef DISTAFF_TEST_HOOKS
+#define DST_TEST_HOOKS 1
+#else
+#define DST_TEST_HOOKS 0
+#endif
+
 // ids for dst_read_buffer
 enum {
     DST_BUF_POLYS = 0,        // [W][n]
@@ -70,6 +136,16 @@ struct NttPlan {
 struct dst_ctx {
     dst_params prm{};
     std::string err;
+    // the DISTAFF_* switches as they were when the context was created (see DST_SWITCHES); sw() returns nullptr for an unset one
+    std::map<std::string, std::string> sw_values;
+    const char* sw(const char* name) const { auto it = sw_values.find(name); return it == sw_values.end() ? nullptr : it->second.c_str(); }
+    bool sw_is(const char* name, const char* value) const { const char* v = sw(name); return v && !strcmp(v, value); }
+    bool sw_flag(const char* name) const { const char* v = sw(name); return v && v[0] && v[0] != '0'; }
+    void read_switches() {
+        sw_values.clear();
+        for (const dst_switch_def& d : DST_SWITCHES)
+            if (d.product || DST_TEST_HOOKS) if (const char* v = getenv(d.name)) sw_values[d.name] = v;
+    }
     int device = 0;
     hipStream_t stream = nullptr;
 
@@ -140,7 +216,7 @@ struct dst_ctx {
     bool tree_krange[2 + DST_MAX_FRI_LAYERS] = {false};
     uint64_t *d_u64 = nullptr;                        // small device scalars (pow result, AIR failure flag)
     uint8_t *d_fri_chain = nullptr;                   // dst_prove's FRI commit phase without host round trips: [24] roots (32 B) then [24] draws (16 B)
-    uint8_t *h_stage = nullptr;                       // page-locked host staging (64 KiB): small uploads / read-backs that must not make the host wait
+    uint8_t *h_stage = nullptr;                       // page-locked host staging (HS_TOTAL bytes, layout HS_* above): small uploads / read-backs that must not make the host wait
     unsigned long long air_flag_host = ~0ull;         // read-back of the AIR failure flag (deferred check)
     hipEvent_t ph_ev[6] = {nullptr};                  // phase boundaries on the stream (phase times without host waits)
     uint8_t *d_stage = nullptr;                       // staging buffer for gathers
@@ -210,9 +286,9 @@ struct KScope {
 
 // ---- kernel launchers (kernels_*.hip) ------------------------------------------------------------------------------------
 // NTT / LDE
-extern "C" bool dst_internal_boundary_by_evaluation();                                  // api.hip: DISTAFF_BOUNDARY=eval
+extern "C" bool dst_internal_boundary_by_evaluation(const dst_ctx* c);                             // api.hip: DISTAFF_BOUNDARY=eval (test build only)
 extern "C" int dst_internal_boundary_polys(dst_ctx* c, const fe* draws344, fe* ip, fe* fp, fe* o0 = nullptr, fe* o1 = nullptr, fe* o2 = nullptr, fe* o3 = nullptr);   // api.hip: boundary combinations in coefficient form (ip / fp: 8n coefficients each; or the four n-coefficient pieces)
-extern "C" bool dst_internal_combine_by_steps();                                        // api.hip: DISTAFF_COMBINE=steps (the reference's sequence of whole-array steps)
+extern "C" bool dst_internal_combine_by_steps(const dst_ctx* c);                                   // api.hip: DISTAFF_COMBINE=steps (the reference's sequence of whole-array steps; test build only)
 extern "C" int dst_internal_boundary_quotients(dst_ctx* c, const fe* draws344, fe* q4, size_t stride);   // api.hip: the n-coefficient quotients the fused combination reads
 int k_build_twiddle_tables(dst_ctx* c);                                                 // fills tw4_lde / tw4_fwd / tw4_inv (context creation)
 void k_intt_columns(dst_ctx* c, const fe* src, size_t src_stride, fe* dst, size_t ncols); // size-n inverse NTT of ncols columns src_stride apart -> contiguous columns

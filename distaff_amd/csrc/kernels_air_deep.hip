@@ -4,7 +4,9 @@
 // formulation of kernels_air.hip stays as an independent statement of the same constraints (DISTAFF_AIR=generic).
 #include "air_kernel.h"
 void air_launch_deep(dst_ctx* c, const AirArgs& a, uint32_t Q) {
-    if (dst_internal_boundary_by_evaluation()) launch_air<16, 8, 0, 12, 1, 0, 0>(c, a, Q);          // boundary constraints
+#if DST_TEST_HOOKS
+    if (dst_internal_boundary_by_evaluation(c)) launch_air<16, 8, 0, 12, 1, 0, 0>(c, a, Q);          // boundary constraints
+#endif
     launch_air<16, 8, 0, 12, 2, 0, AF_FIRST>(c, a, Q);                                              // op bits (starts the partial sums)
     launch_air<16, 8, 0, 12, 4, 0, 0>(c, a, Q);                                                     // sponge
     launch_air<16, 8, 0, 12, 128, 0, 0>(c, a, Q);                                                   // loop image, context / loop stacks

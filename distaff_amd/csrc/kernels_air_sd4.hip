@@ -4,7 +4,9 @@
 #include "air_kernel.h"
 void air_launch_sd4(dst_ctx* c, const AirArgs& a, uint32_t Q) {
     // the boundary combinations are normally written in coefficient form (api.hip dst_internal_boundary_polys), not evaluated
-    if (dst_internal_boundary_by_evaluation()) launch_air<2, 1, 4, 8, 1, 0, 0>(c, a, Q);           // boundary constraints
+#if DST_TEST_HOOKS
+    if (dst_internal_boundary_by_evaluation(c)) launch_air<2, 1, 4, 8, 1, 0, 0>(c, a, Q);           // boundary constraints
+#endif
     launch_air<2, 1, 4, 8, 130, 0, AF_FIRST>(c, a, Q);                                             // op bits, loop image, context / loop stacks (starts the partial sums)
     launch_air<2, 1, 4, 8, 4, 0, 0>(c, a, Q);                                                      // sponge
     launch_air<2, 1, 4, 8, 0, AG_HIGH, AF_EV_OUT>(c, a, Q);                                        // stack: PUSH, CMP, RESCR, BEGIN / NOOP

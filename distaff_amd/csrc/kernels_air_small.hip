@@ -3,7 +3,9 @@
 // scratch and inside the 64 KiB instruction cache of a CU pair.
 #include "air_kernel.h"
 void air_launch_small(dst_ctx* c, const AirArgs& a, uint32_t Q) {
-    if (dst_internal_boundary_by_evaluation()) launch_air<2, 1, 0, 8, 1, 0, 0>(c, a, Q);           // boundary constraints
+#if DST_TEST_HOOKS
+    if (dst_internal_boundary_by_evaluation(c)) launch_air<2, 1, 0, 8, 1, 0, 0>(c, a, Q);           // boundary constraints
+#endif
     launch_air<2, 1, 0, 8, 130, 0, AF_FIRST>(c, a, Q);                                             // op bits, loop image, context / loop stacks (starts the partial sums)
     launch_air<2, 1, 0, 8, 4, 0, 0>(c, a, Q);                                                      // sponge
     launch_air<2, 1, 0, 8, 0, AG_RESCR, AF_EV_OUT>(c, a, Q);                                       // stack: RESCR

@@ -128,8 +128,8 @@ __global__ void __launch_bounds__(HASH_THREADS) merkle_level2_kernel(const diges
 // children[0 .. 4 * count) -> nodes[2 * count .. 4 * count) and nodes[count .. 2 * count)   (heap positions of the two levels above)
 static bool merkle_two_levels(dst_ctx* c, const digest* children, digest* nodes, size_t count) {
     size_t min_count = MERKLE_LEVEL2_MIN;
-    if (const char* e = getenv("DISTAFF_MERKLE_LEVEL2_LOG")) min_count = (size_t)1 << (atoi(e) < 0 ? 0 : atoi(e) > 40 ? 40 : atoi(e));      // tests: the fused form on small trees
-    if (count < min_count || count == 0 || getenv("DISTAFF_MERKLE_LEVELS")) return false;
+    if (const char* e = c->sw("DISTAFF_MERKLE_LEVEL2_LOG")) min_count = (size_t)1 << (atoi(e) < 0 ? 0 : atoi(e) > 40 ? 40 : atoi(e));      // tests: the fused form on small trees
+    if (count < min_count || count == 0 || c->sw("DISTAFF_MERKLE_LEVELS")) return false;
     KScope ks_(c, "merkle_level2_kernel", 96.0 * 3 * count);
     hipLaunchKernelGGL(merkle_level2_kernel, dim3((unsigned)((count + HASH_THREADS - 1) / HASH_THREADS)), dim3(HASH_THREADS), 0, c->stream, children, nodes + 2 * count, nodes + count, count);
     return true;
@@ -191,7 +191,7 @@ __global__ void __launch_bounds__(HASH_THREADS) merkle_subtree_kernel(digest* no
 // builds nodes[1 .. count) from an already filled level nodes[count .. 2*count)
 static void merkle_upper_levels(dst_ctx* c, digest* nodes, size_t count) {
     while (count > 1024) {
-        if (count <= MERKLE_SUBTREE_MAX && count % 512 == 0 && !getenv("DISTAFF_MERKLE_LEVELS")) {
+        if (count <= MERKLE_SUBTREE_MAX && count % 512 == 0 && !c->sw("DISTAFF_MERKLE_LEVELS")) {
             { KScope ks_(c, "merkle_subtree_kernel", 64.0 * count); hipLaunchKernelGGL(merkle_subtree_kernel, dim3((unsigned)(count / 512)), dim3(HASH_THREADS), 0, c->stream, nodes, count); }
             count /= 512;
             continue;

@@ -504,8 +504,8 @@ static uint32_t ntt_tiles_per_block(uint32_t tiles, size_t arrays) {
 // Block order of an extension's first pass (ntt_block): every (coset, register) of a tile group before the next group, so that the
 // coefficient tiles (the same for every coset) and the four-step twiddles (the same for every register) are re-read while they are still
 // in the XCD's L2: FETCH_SIZE of the 2^20 launches 1.29 against 1.57 GB, time unchanged.  DISTAFF_NTT_ORDER=0: coset-slow order (tests).
-static uint32_t ntt_coset_fast(size_t groups, size_t cosets) {
-    const char* e = getenv("DISTAFF_NTT_ORDER");
+static uint32_t ntt_coset_fast(const dst_ctx* c, size_t groups, size_t cosets) {
+    const char* e = c->sw("DISTAFF_NTT_ORDER");
     return (cosets > 1 && groups % 8 == 0 && !(e && e[0] == '0')) ? 1u : 0u;
 }
 static void ntt_raise_lds_limit(dst_ctx* c) {                  // tile + stage twiddles exceed the 64 KiB default
@@ -561,9 +561,9 @@ static void ntt_launch(dst_ctx* c, bool pass_b, NttArgs& a, size_t groups, size_
     if (a.pre) mults += (!pass_b && a.dit) ? 1.0 : 0.5;        // register pre-stage: c * x[m + len] in both halves of a coset DIT, the twiddle of the odd half otherwise
     const double elements = (double)groups * a.tiles_per_block * ((size_t)1 << a.tile) * ((size_t)1 << stages) * cosets * cols;
     KScope ks_(c, name, bytes, true, 18.0 * mults * elements);
-    const char* wv = getenv("DISTAFF_NTT_WAVES");
+    const char* wv = c->sw("DISTAFF_NTT_WAVES");
     const bool two = lds <= NTT_LDS_TWO_PER_CU, eight = two && (wv ? wv[0] == '8' : stages >= 10);
-    const bool any_shape = getenv("DISTAFF_NTT_FIXED") && getenv("DISTAFF_NTT_FIXED")[0] == '0';
+    const bool any_shape = c->sw_is("DISTAFF_NTT_FIXED", "0");
     const bool fixed = stages == 10 && a.tile == 2 && !any_shape;      // 1024 x 4 tiles (n = 2^20) have their own instances,
     const bool fixed84 = stages == 8 && a.tile == 4 && !any_shape;     // and so have 256 x 16 tiles (n = 2^16, the first two passes of three-pass plans)
     if (a.debug & 1u) ntt_report_occupancy(name, pass_b, eight || !two ? 1024 : 512, eight, lds);
@@ -602,8 +602,8 @@ static void ntt_launch(dst_ctx* c, bool pass_b, NttArgs& a, size_t groups, size_
 // DISTAFF_NTT_DIF=1 / 0 forces one or the other (the tests run both).
 // returns 0: pre-scale + DIF, 1: coset DIT with the whole table in LDS, 2: coset DIT whose last-stage twiddles (half of the table) are read
 // from global memory (tile + the other half fit 80 KiB)
-static int ntt_first_pass_mode(size_t n1, size_t tile) {
-    if (const char* e = getenv("DISTAFF_NTT_DIF")) return e[0] == '0' ? 1 : e[0] == '2' ? 2 : 0;
+static int ntt_first_pass_mode(const dst_ctx* c, size_t n1, size_t tile) {
+    if (const char* e = c->sw("DISTAFF_NTT_DIF")) return e[0] == '0' ? 1 : e[0] == '2' ? 2 : 0;
     if (n1 * tile * sizeof(fe) + n1 * sizeof(fe_tw) <= NTT_LDS_TWO_PER_CU) return 1;
     if (n1 * tile * sizeof(fe) + (n1 / 2) * sizeof(fe_tw) <= NTT_LDS_TWO_PER_CU) return 2;
     return 0;
@@ -613,7 +613,7 @@ static NttArgs ntt_common_args(dst_ctx* c, bool inverse, bool lde, uint32_t skip
     a.log_N = c->log_N; a.log_b = c->log_b;
     a.j0 = lde ? (uint32_t)c->j0 + skip : 0u;
     a.scale = c->n_inv_tw;
-    { const char* dbg = getenv("DISTAFF_NTT_DEBUG"); a.debug = dbg ? (uint32_t)atoi(dbg) : 0u; }
+    { const char* dbg = c->sw("DISTAFF_NTT_DEBUG"); a.debug = dbg ? (uint32_t)atoi(dbg) : 0u; }
     (void)inverse;
     return a;
 }
@@ -632,13 +632,13 @@ static void launch_pass_lds(dst_ctx* c, bool pass_b, const fe* src, size_t src_c
         a.pre = p.pre_a; a.pre_tw = inverse ? c->w1pi : c->w1pf;
         a.log_n1 = p.log_n1 - p.pre_a;                                 // the kernel's LDS transform; with the pre-stage the pass covers twice that
         const size_t n1 = (size_t)1 << a.log_n1;
-        int mode = lde ? ntt_first_pass_mode(n1, p.tile_a) : 0;
+        int mode = lde ? ntt_first_pass_mode(c, n1, p.tile_a) : 0;
         if (p.pre_a && lde && mode == 0) mode = 2;                     // the pre-stage is written for the coset DIT (tiles of at most 1024 x 4: always fits)
         a.dit = mode ? 1u : 0u; a.dit_last = mode == 2 ? c->dit_last : nullptr;
         const size_t lds_a = n1 * p.tile_a * sizeof(fe) + (mode == 1 ? n1 : n1 / 2) * sizeof(fe_tw);
         const uint32_t tiles = (1u << p.log_n2) / p.tile_a;
         a.tiles_per_block = ntt_tiles_per_block(tiles, (cosets * cols) << p.pre_a);
-        a.coset_fast = ntt_coset_fast((size_t)(tiles / a.tiles_per_block) << p.pre_a, cosets);
+        a.coset_fast = ntt_coset_fast(c, (size_t)(tiles / a.tiles_per_block) << p.pre_a, cosets);
         ntt_launch(c, false, a, (size_t)(tiles / a.tiles_per_block) << p.pre_a, cosets, cols, lds_a, "ntt_pass_a", 16.0 * c->n * cols * (lde ? (1 + cosets) : 2 * cosets));
     } else {
         a.stage_tw = inverse ? c->w2i : c->w2f; a.tile = (uint32_t)__builtin_ctz(p.tile_b);
@@ -669,14 +669,14 @@ static void launch_three_pass(dst_ctx* c, const fe* src, size_t src_col_stride, 
     a.prescale = lde ? c->prescale : nullptr; a.has_scale = 0;
     a.tw4 = lde ? c->tw4_lde + (size_t)skip * n : (inverse ? c->tw4_inv : c->tw4_fwd); a.tw4_coset_stride = lde ? n : 0;
     a.stage_tw = inverse ? c->w1i : c->w1f;
-    const int mode = lde ? ntt_first_pass_mode(n1, p.tile_a) : 0;
+    const int mode = lde ? ntt_first_pass_mode(c, n1, p.tile_a) : 0;
     a.dit = mode ? 1u : 0u; a.dit_last = mode == 2 ? c->dit_last : nullptr;
     a.src = src; a.src_col_stride = src_col_stride; a.src_coset_stride = src_coset_stride;
     a.dst = c->tmp; a.dst_col_stride = n * cosets; a.dst_coset_stride = n;
     {
         const uint32_t tiles = (uint32_t)(nrow / p.tile_a);
         a.tiles_per_block = ntt_tiles_per_block(tiles, cosets * cols);
-        a.coset_fast = ntt_coset_fast(tiles / a.tiles_per_block, cosets);
+        a.coset_fast = ntt_coset_fast(c, tiles / a.tiles_per_block, cosets);
         const size_t lds = n1 * p.tile_a * sizeof(fe) + (mode == 1 ? n1 : n1 / 2) * sizeof(fe_tw);
         ntt_launch(c, false, a, tiles / a.tiles_per_block, cosets, cols, lds, "ntt_pass_a", 16.0 * n * cols * (lde ? (1 + cosets) : 2 * cosets));
     }
@@ -775,7 +775,7 @@ void k_lde_columns(dst_ctx* c, const fe* polys, fe* lde, size_t ncols) {
         (void)hipMemcpy2DAsync(lde, c->Bc * c->n * sizeof(fe), c->trace + ((polys - c->polys) / c->n) * c->trace_stride, c->trace_stride * sizeof(fe), c->n * sizeof(fe), ncols, hipMemcpyDeviceToDevice, c->stream);
     // launch granularity: `bcols` registers x `bcos` cosets per pair of passes (the staging buffer holds tmp_capacity_arrays arrays)
     size_t bcols = tmp_capacity_arrays(c) / c->Bc, bcos = c->Bc - skip;
-    if (const char* e = getenv("DISTAFF_LDE_BATCH")) { unsigned x = 0, y = 0; if (sscanf(e, "%u,%u", &x, &y) == 2 && x >= 1 && y >= 1 && (size_t)x * y <= tmp_capacity_arrays(c)) { bcols = x; bcos = y; } }
+    if (const char* e = c->sw("DISTAFF_LDE_BATCH")) { unsigned x = 0, y = 0; if (sscanf(e, "%u,%u", &x, &y) == 2 && x >= 1 && y >= 1 && (size_t)x * y <= tmp_capacity_arrays(c)) { bcols = x; bcos = y; } }
     for (size_t done = 0; done < ncols;) {
         const size_t cols = ncols - done < bcols ? ncols - done : bcols;
         for (size_t s = skip; s < c->Bc;) {
@@ -866,7 +866,7 @@ __global__ void __launch_bounds__(256) fold8_dft_kernel(const fe* __restrict__ p
 void k_lde_fold8(dst_ctx* c, const fe* poly8n, fe* out) {
     // stage the folded inputs in `out` itself, then transform each coset in place (pass A reads out, pass B writes out)
     dim3 g((unsigned)((c->n + 255) / 256));
-    const char* e = getenv("DISTAFF_FOLD8_DFT");
+    const char* e = c->sw("DISTAFF_FOLD8_DFT");
     const bool all_cosets = c->Bc == c->B && c->j0 == 0 && !(e && e[0] == '0');
     const double bytes = 16.0 * c->n * (8 + c->Bc);
 #define FOLD8_DFT(S_) { KScope ks_(c, "fold8_dft_kernel", bytes); hipLaunchKernelGGL(fold8_dft_kernel<S_>, g, dim3(256), 0, c->stream, poly8n, out, c->tw_lo, c->tw_hi, c->tw_lo_bits, c->log_n, c->log_N); }

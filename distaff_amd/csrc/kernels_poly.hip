@@ -286,7 +286,7 @@ static void syn_div_batch_rec(dst_ctx* c, fe* const* a, const fe* b, int count, 
     { KScope ks_(c, "syn_div_chunk_batch_kernel", 32.0 * len * count); hipLaunchKernelGGL(syn_div_chunk_batch_kernel, dim3((unsigned)chunks, (unsigned)count), dim3(PT), 0, c->stream, B, len, chunks > 1 ? 1 : 0); }
 }
 void k_syn_div_batch(dst_ctx* c, fe* const* a, const fe* b, int count, size_t len) {
-    for (int k = 0; k < count; k++) if (fe_is_zero(b[k]) || getenv("DISTAFF_SYN_DIV_TABLES")) { for (int q = 0; q < count; q++) k_syn_div(c, a[q], len, b[q]); return; }   // the special forms keep their own path
+    for (int k = 0; k < count; k++) if (fe_is_zero(b[k]) || c->sw("DISTAFF_SYN_DIV_TABLES")) { for (int q = 0; q < count; q++) k_syn_div(c, a[q], len, b[q]); return; }   // the special forms keep their own path
     syn_div_batch_rec(c, a, b, count, len, c->scratch);
 }
 
@@ -299,7 +299,7 @@ void k_syn_div(dst_ctx* c, fe* a, size_t len, fe b) {
         return;
     }
     if (fe_eq(b, fe_one())) { suffix_scan(c, a, len, scr); return; }     // division by (x - 1): q_i = sum_{t > i} a_t, the exclusive scan itself (first-step boundary polynomial)
-    if (!getenv("DISTAFF_SYN_DIV_TABLES")) { syn_div_blocked(c, a, len, b, scr); return; }
+    if (!c->sw("DISTAFF_SYN_DIV_TABLES")) { syn_div_blocked(c, a, len, b, scr); return; }
     // the first formulation, kept as an independent statement (tests run both): scale by b^t, additive suffix scan, scale by b^-(i+1)
     size_t te = pow_table_elems(len + 1);
     PowTab fw = build_pow_table(c, scr, b, len + 1);
@@ -688,6 +688,7 @@ void k_gather_rows(dst_ctx* c, const uint64_t* positions_dev, size_t count, fe* 
                        (uint32_t)c->j0, (uint32_t)c->W, positions_dev, count, out); }
 }
 
+#if DST_TEST_HOOKS            // calibration kernels: test / bench build only
 // ---- mulmod micro-benchmark (bench.py's ALU ceiling) --------------------------------------------------------------------------------------
 template <int VARIANT>
 __global__ void __launch_bounds__(PT) mulmod_bench_kernel(fe* out, uint32_t iters) {
@@ -752,6 +753,8 @@ int k_bench_mad(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms) {
     hipEventDestroy(e0); hipEventDestroy(e1);
     return DST_OK;
 }
+
+#endif  // DST_TEST_HOOKS
 
 // ---- element-wise field operations on caller data (test hook behind dst_field_op) ---------------------------------------------------------
 __global__ void field_op_kernel(int op, const fe* a, const fe* b, fe* out, size_t count) {

@@ -4,6 +4,7 @@
 // which code beyond the 64 KiB instruction cache of a CU pair is slow -- one lease in round 2 ran a 172 KB constraint kernel at a third
 // of its speed -- shows up as code_ratio >> 1.  No product kernel is that large any more (the build gate, __graft_entry__.py).
 #include "ctx.h"
+#if DST_TEST_HOOKS            // a laboratory instrument: not part of the product library
 
 #define PROBE_STR_(x) #x
 #define PROBE_STR(x) PROBE_STR_(x)
@@ -59,3 +60,4 @@ int k_bench_code(dst_ctx* c, uint32_t code_kib, double* ms) {
     c->err = "dst_bench_code: code size must be 16, 176 or 177 (= 176 KiB in the convoy form)";
     return DST_ERR_ARG;
 }
+#endif  // DST_TEST_HOOKS

@@ -16,6 +16,7 @@
 using namespace dsth;
 
 extern "C" void dst_internal_transition_coefficients(const dst_ctx* c, const fe* draws344, std::vector<fe>& tc);   // api.hip
+extern "C" int dst_internal_upload_draws(dst_ctx* c, const fe* draws344, const std::vector<fe>& tc, fe* d_coef, fe* d_tc);   // api.hip: queued from the page-locked staging area
 
 enum { SH_TRACE_TREE = 0, SH_CONSTRAINT_TREE = 1, SH_FRI_TREE = 2, SH_CEVAL = 3, SH_FRI_LAST = 4, SH_FRI_SEND_CAP = 5 };
 enum { RD_TRACE_LEAF = 0, RD_TRACE_NODE = 1, RD_TRACE_UPPER = 2, RD_CEVAL = 3, RD_C_NODE = 4, RD_C_UPPER = 5, RD_FRI_E = 6, RD_FRI_LEAF = 7,
@@ -30,7 +31,7 @@ static size_t fri_nd(const dst_ctx* c, int d) { return c->fri_size[d] / c->B; } 
 // own in natural order (same kernels as the single-GPU path): no further exchanges, and no limit on the blowup factor.  The
 // remainder layer always qualifies, so the tail is never empty.
 static int fri_replicated_from(const dst_ctx* c) {
-    const char* e = getenv("DISTAFF_FRI_REPLICATE_LOG");                      // tests lower the limit to get sharded layers at small sizes
+    const char* e = c->sw("DISTAFF_FRI_REPLICATE_LOG");                      // tests lower the limit to get sharded layers at small sizes
     int log_limit = e ? atoi(e) : 17;
     log_limit = log_limit < 0 ? 0 : (log_limit > 40 ? 40 : log_limit);
     for (int d = 0; d < c->num_fri_layers; d++)
@@ -124,8 +125,7 @@ static int shard_eval_constraints(dst_ctx* c, const dst_public* pub, const uint8
     dst_internal_transition_coefficients(c, draws.data(), tc);
     fe* d_coef = c->scratch + c->scratch_elems - 1024;
     fe* d_tc = d_coef + 344;
-    HIP_TRY(c, hipMemcpyAsync(d_coef, draws.data(), 344 * 16, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipMemcpyAsync(d_tc, tc.data(), tc.size() * 16, hipMemcpyHostToDevice, c->stream));
+    if (int ru = dst_internal_upload_draws(c, draws.data(), tc, d_coef, d_tc)) return ru;
     int r = k_eval_constraints(c, d_coef, d_tc, bad_step, defer_check);
     if (r == DST_ERR_AIR) c->err = "transition constraints were not satisfied";
     return r;
@@ -138,14 +138,14 @@ static int shard_eval_constraints(dst_ctx* c, const dst_public* pub, const uint8
 static int shard_combine_parts(dst_ctx* c, int parts) {
     const size_t n = c->n, D = 8 * n;
     fe* ip = c->cwork; fe* fp = c->cwork + D; fe* tp = c->cwork + 2 * D; fe* work = c->cwork + 3 * D;
-    const bool steps = dst_internal_combine_by_steps();         // the reference's sequence of whole-array steps (tests), else the fused pass of the single-GPU path
+    const bool steps = dst_internal_combine_by_steps(c);         // the reference's sequence of whole-array steps (tests), else the fused pass of the single-GPU path
     fe* q4 = c->cwork; const size_t qs = n + 16;
     if (parts & 1) {
         if (!steps) {
             int rb = dst_internal_boundary_quotients(c, c->shard_draws.data(), q4, qs);
             if (rb) return rb;
         } else {
-            if (dst_internal_boundary_by_evaluation()) {
+            if (dst_internal_boundary_by_evaluation(c)) {
                 k_intt8_cosets(c, c->ceval, ip, work);
                 k_intt8_cosets(c, c->ceval + D, fp, work);
             } else {
@@ -222,7 +222,7 @@ int dst_shard_export_size(dst_ctx* c, uint32_t what, uint32_t arg, size_t* bytes
     switch (what) {
         case SH_TRACE_TREE: case SH_CONSTRAINT_TREE: *bytes = c->n * 32; return DST_OK;
         case SH_FRI_TREE: if ((int)arg >= c->num_fri_layers) return DST_ERR_ARG; *bytes = fri_nd(c, arg) / 4 * 32; return DST_OK;
-        case SH_CEVAL: *bytes = (dst_internal_boundary_by_evaluation() ? 3 : 1) * (c->Bc / (c->B / 8)) * c->n * 16; return DST_OK;   // [i, f,] t
+        case SH_CEVAL: *bytes = (dst_internal_boundary_by_evaluation(c) ? 3 : 1) * (c->Bc / (c->B / 8)) * c->n * 16; return DST_OK;   // [i, f,] t
         case SH_FRI_LAST: *bytes = c->fri_size[c->num_fri_layers - 1] * 16; return DST_OK;       // the whole remainder, natural order (replicated)
         case SH_FRI_SEND_CAP: {                                  // the largest item dst_shard_fri_begin hands out
             const int t = c->gather_buf ? c->fri_rep_from : fri_replicated_from(c);    // fixed once the shard buffers exist
@@ -243,7 +243,7 @@ int dst_shard_export(dst_ctx* c, uint32_t what, uint32_t arg, void* dst, int dst
         case SH_TRACE_TREE: src = c->trace_nodes + c->n; break;
         case SH_CONSTRAINT_TREE: src = c->cnodes + c->n; break;
         case SH_FRI_TREE: src = c->fri_nodes[arg] + fri_nd(c, arg) / 4; break;
-        case SH_CEVAL: src = dst_internal_boundary_by_evaluation() ? c->ceval : c->ceval + 2 * (c->Bc / (c->B / 8)) * c->n; break;   // local layout [3][Q][n]
+        case SH_CEVAL: src = dst_internal_boundary_by_evaluation(c) ? c->ceval : c->ceval + 2 * (c->Bc / (c->B / 8)) * c->n; break;   // local layout [3][Q][n]
         case SH_FRI_LAST:
             if (c->fri_committed != c->num_fri_layers) { c->err = "dst_shard_export: FRI commit phase not finished"; return DST_ERR_STATE; }
             src = fri_layer_natural(c, c->num_fri_layers - 1); break;
@@ -272,7 +272,7 @@ int dst_shard_import(dst_ctx* c, uint32_t what, uint32_t arg, const void* src, i
     if (what == SH_CEVAL) {
         c->ceval_inverted = false;                                  // dst_prove_sharded sets it after importing arrays it has inverse-transformed
         const size_t Q = c->Bc / (c->B / 8), blk = Q * c->n;        // gathered [G][V][Q][n] -> ceval [3][8][n], V = 3 (i, f, t) or 1 (t)
-        const size_t V = dst_internal_boundary_by_evaluation() ? 3 : 1;
+        const size_t V = dst_internal_boundary_by_evaluation(c) ? 3 : 1;
         HIP_TRY(c, hipStreamSynchronize(c->stream));
         for (size_t g = 0; g < G; g++)
             for (size_t v = 0; v < V; v++)
@@ -376,12 +376,12 @@ static int fri_replicated_tail(dst_ctx* c, const void* gathered, int src_is_devi
     fe* nat0 = d0 == 0 ? c->fri_nat0 : c->fri_e[d0];
     k_coset_to_natural_len(c, (const fe*)c->gather_buf, c->B, fri_nd(c, d0), nat0);
     if (c->fri_roots.size() < (size_t)L) c->fri_roots.resize(L);
-    const char* tail_env = getenv("DISTAFF_FRI_TAIL");
+    const char* tail_env = c->sw("DISTAFF_FRI_TAIL");
     // layers above the single-launch tail: no host round trip per layer -- x = prng(root) is drawn on the device (fri_draw_kernel) and the
     // fold reads it there; their roots come back with the tail's (as in dst_prove's commit phase, api.hip)
     digest* d_roots = reinterpret_cast<digest*>(c->d_fri_chain);
     fe* d_alpha = reinterpret_cast<fe*>(c->d_fri_chain + DST_MAX_FRI_LAYERS * 32);
-    uint8_t* h_roots = c->h_stage + 40960;
+    uint8_t* h_roots = c->h_stage + HS_FRI_ROOTS;
     int d = d0;
     for (; d < L; d++) {
         if (d >= 1 && c->fri_size[d] <= ((size_t)1 << 13) && !(tail_env && tail_env[0] == '0')) break;
@@ -780,13 +780,15 @@ void tree_exchange(Sharded& S, uint32_t what, uint32_t arg, uint8_t root[32], co
     digest* upper = what == SH_TRACE_TREE ? c->trace_upper : what == SH_CONSTRAINT_TREE ? c->c_upper : c->fri_upper[arg];
     const int slot = what == SH_TRACE_TREE ? 0 : what == SH_CONSTRAINT_TREE ? 1 : 2 + (int)arg;
     c->shard_trees++;
-    const bool krange = G > 1 && K >= G && K % G == 0 && !getenv("DISTAFF_SHARD_TREE_GATHER");
+    const bool krange = G > 1 && K >= G && K % G == 0 && !c->sw_flag("DISTAFF_SHARD_TREE_GATHER");
     c->tree_krange[slot] = krange;
-    if (getenv("DISTAFF_SHARD_DEBUG") && comm->rank == 0) fprintf(stderr, "[distaff] tree %u/%u: %zu boundary nodes per rank, %s\n", what, arg, K, krange ? "k-range exchange (all-to-all + root all-gather)" : "all-gather of boundary nodes");
+    if (c->sw_flag("DISTAFF_SHARD_DEBUG") && comm->rank == 0) fprintf(stderr, "[distaff] tree %u/%u: %zu boundary nodes per rank, %s\n", what, arg, K, krange ? "k-range exchange (all-to-all + root all-gather)" : "all-gather of boundary nodes");
     if ((krange ? K * 32 : K * 32 * G) > c->gather_bytes) { S.fail(DST_ERR_ARG, "tree_exchange: gather buffer too small"); S.agreed = DST_ERR_ARG; return; }   // the same on every rank
     // this rank's record of the exchange: status (and rank 0's payload) staged now, the subtree root joins it below -- ONE small all-gather
     // per tree carries both (the roots used to travel in a collective of their own)
-    StatusRec mine{}; mine.rc = S.rc; mine.bad_step = ~0ull;
+    // (queued from a slot of the page-locked staging area: with defer_slot nothing below waits for the stream before `mine` would go out of scope)
+    StatusRec& mine = reinterpret_cast<StatusRec*>(c->h_stage + HS_STATUS)[(c->shard_trees - 1) % HS_STATUS_SLOTS];
+    mine = StatusRec{}; mine.rc = S.rc; mine.bad_step = ~0ull;
     TreeRec* recs = reinterpret_cast<TreeRec*>(c->d_status);
     bool staged = hipMemcpyAsync(&recs[comm->rank].st, &mine, sizeof(mine), hipMemcpyHostToDevice, c->stream) == hipSuccess;
     // the verdict of this rank's constraint evaluation, straight from the device word the kernels wrote (no host wait of its own)
@@ -863,7 +865,7 @@ void commit_trace_columns(Sharded& S) {
     // a stream-ordered transport runs the all-gathers on their own stream, ordered against the transforms by events
     // (DISTAFF_SHARD_FORCE_OVERLAP=1: the same stream / event choreography over a blocking transport -- how the tests reach this path
     // without several RCCL ranks)
-    const bool overlap = (comm->stream_ordered() || getenv("DISTAFF_SHARD_FORCE_OVERLAP")) && G > 1 && !getenv("DISTAFF_SHARD_NO_OVERLAP");
+    const bool overlap = (comm->stream_ordered() || c->sw_flag("DISTAFF_SHARD_FORCE_OVERLAP")) && G > 1 && !c->sw_flag("DISTAFF_SHARD_NO_OVERLAP");
     if (overlap) S.local([&]() -> int {
         if (!c->comm_stream) HIP_TRY(c, hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking));
         while (c->comm_events.size() < 2 * rounds) { hipEvent_t e; HIP_TRY(c, hipEventCreateWithFlags(&e, hipEventDisableTiming)); c->comm_events.push_back(e); }
@@ -968,8 +970,8 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
         size_t bytes = 0;
         if (dst_shard_export_size(c, SH_CEVAL, 0, &bytes) || bytes * G > c->gather_bytes) { c->err = "dst_prove_sharded: gather buffer too small for the constraint evaluations"; return DST_ERR_ARG; }   // the same on every rank
         const size_t Q = c->Bc / (c->B / 8);
-        const void* send = dst_internal_boundary_by_evaluation() ? (const void*)c->ceval : (const void*)(c->ceval + 2 * Q * c->n);
-        const bool invert_first = !dst_internal_boundary_by_evaluation();
+        const void* send = dst_internal_boundary_by_evaluation(c) ? (const void*)c->ceval : (const void*)(c->ceval + 2 * Q * c->n);
+        const bool invert_first = !dst_internal_boundary_by_evaluation(c);
         if (invert_first) S.local([&]() -> int {
             // the size-n inverse transforms of this rank's evaluation cosets, before the exchange (in place through the scratch area)
             fe* mine = c->ceval + 2 * Q * c->n; fe* work = c->cwork + 3 * 8 * c->n;
@@ -980,7 +982,7 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
         // On a stream-ordered transport the exchange runs on the collective stream while this rank writes the boundary combinations
         // (they need nothing from other ranks); otherwise in sequence.  In boundary-by-evaluation mode part 1 reads the gathered arrays.
         bool part1_done = false;
-        const bool side = (comm->stream_ordered() || getenv("DISTAFF_SHARD_FORCE_OVERLAP")) && G > 1 && invert_first && S.rc == DST_OK && c->comm_stream && c->comm_events.size() >= 2 && !getenv("DISTAFF_SHARD_NO_OVERLAP");
+        const bool side = (comm->stream_ordered() || c->sw_flag("DISTAFF_SHARD_FORCE_OVERLAP")) && G > 1 && invert_first && S.rc == DST_OK && c->comm_stream && c->comm_events.size() >= 2 && !c->sw_flag("DISTAFF_SHARD_NO_OVERLAP");
         if (side) {
             S.local([&]() -> int { HIP_TRY(c, hipEventRecord(c->comm_events[0], c->stream)); HIP_TRY(c, hipStreamWaitEvent(c->comm_stream, c->comm_events[0], 0)); return DST_OK; });
             if (!S.coll(S.timed([&] { return comm->all_gather(send, c->gather_buf, bytes, c->comm_stream); }), "constraint evaluations")) return S.agreed;
@@ -1011,11 +1013,11 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
     // Sharded layers.  chained (default): no host wait per layer -- x = prng(root) is drawn on the device from the replicated root
     // (fri_draw_kernel) and the fold reads it there; the layers' records and roots are looked at once, after the tail.
     // DISTAFF_FRI_CHAIN=0: root read-back, host draw and status check per layer (tests).
-    const char* ce = getenv("DISTAFF_FRI_CHAIN");
+    const char* ce = c->sw("DISTAFF_FRI_CHAIN");
     const bool chained = !(ce && ce[0] == '0');
     fe* d_alpha = reinterpret_cast<fe*>(c->d_fri_chain + DST_MAX_FRI_LAYERS * 32);
     digest* d_roots = reinterpret_cast<digest*>(c->d_fri_chain);
-    auto slot_of = [&](int d) { return c->h_stage + 45056 + (size_t)d * 800; };       // page-locked: G * 96 + 32 <= 800 bytes per layer
+    auto slot_of = [&](int d) { return c->h_stage + HS_FRI_SLOTS + (size_t)d * HS_FRI_SLOT_BYTES; };       // page-locked: G * 96 + 32 bytes per layer
     for (int d = 0; d < rep_from; d++) {
         S.local([&]() -> int {
             if (!c->composed || d != c->fri_committed || d != c->fri_folded) { c->err = "dst_prove_sharded: FRI layer out of order"; return DST_ERR_STATE; }

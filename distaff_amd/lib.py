@@ -10,7 +10,25 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("DISTAFF_HIP_LIB") or os.path.join(_HERE, "libdistaff_hip.so")
+PRODUCT_LIB = os.path.join(_HERE, "libdistaff_hip.so")             # the product: what a host binds, what bench.py measures, what smoke() runs
+HOOKS_LIB = os.path.join(_HERE, "libdistaff_hip_hooks.so")          # the same sources with -DDISTAFF_TEST_HOOKS (tests, bench.py's calibration kernels)
+# DISTAFF_HIP_LIB names any other build (the tests' CPU emulation); DISTAFF_TEST_HOOKS=1 selects the test / bench build (tests/conftest.py)
+LIB_PATH = os.environ.get("DISTAFF_HIP_LIB") or (HOOKS_LIB if os.environ.get("DISTAFF_TEST_HOOKS") == "1" else PRODUCT_LIB)
+
+
+def use_test_hooks():
+    """Bind the test / bench build (libdistaff_hip_hooks.so) instead of the product library -- before the first load(); child processes that
+    import this package inherit the choice through DISTAFF_TEST_HOOKS=1 (bench.py removes the variable: it measures the product)."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("use_test_hooks() must be called before the library is loaded")
+    os.environ["DISTAFF_TEST_HOOKS"] = "1"
+    if not os.environ.get("DISTAFF_HIP_LIB"):
+        LIB_PATH = HOOKS_LIB
+
+
+def library_path():
+    return LIB_PATH
 
 DST_OK, DST_ERR_ARG, DST_ERR_HIP, DST_ERR_AIR, DST_ERR_STATE = 0, -1, -2, -3, -4
 
@@ -25,7 +43,7 @@ EXPORTS = ["dst_ctx_create", "dst_ctx_destroy", "dst_last_error", "dst_phase_ms"
            "dst_shard_commit_trace", "dst_shard_eval_constraints", "dst_shard_combine", "dst_shard_fri_layer", "dst_shard_fri_fold",
            "dst_shard_export_size", "dst_shard_export", "dst_shard_import", "dst_shard_read", "dst_shard_fri_begin", "dst_shard_fri_end", "dst_shard_fri_roots", "dst_shard_open", "dst_shard_assemble", "dst_shard_info",
            "dst_comm_unique_id", "dst_comm_init", "dst_comm_init_local", "dst_comm_init_callbacks", "dst_comm_destroy", "dst_comm_last_error", "dst_comm_copy", "dst_prove_sharded", "dst_prove_sharded_local", "dst_shard_stage_ms",
-           "dst_comm_describe", "dst_comm_trace"]
+           "dst_comm_describe", "dst_comm_trace", "dst_test_hooks"]
 
 
 class DistaffError(RuntimeError):
@@ -75,17 +93,33 @@ def _share_hip_runtime_with_torch():
         pass
 
 
+def _open(path):
+    if not os.path.exists(path):
+        raise ImportError("%s is missing: the HIP extension must be built (python -c 'import __graft_entry__ as g; g.build()'), there is no CPU fallback" % path)
+    _share_hip_runtime_with_torch()
+    lib = ctypes.CDLL(path)
+    lib.dst_last_error.restype = ctypes.c_char_p
+    lib.dst_last_error.argtypes = [ctypes.c_void_p]
+    return lib
+
+
 def load():
     """Loads the shared library (raises if it has not been built: run ``python -c 'import __graft_entry__ as g; g.build()'``)."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
-            raise ImportError("libdistaff_hip.so is missing (%s): the HIP extension must be built, there is no CPU fallback" % LIB_PATH)
-        _share_hip_runtime_with_torch()
-        _lib = ctypes.CDLL(LIB_PATH)
-        _lib.dst_last_error.restype = ctypes.c_char_p
-        _lib.dst_last_error.argtypes = [ctypes.c_void_p]
+        _lib = _open(LIB_PATH)
     return _lib
+
+
+_hooks_lib = None
+
+
+def load_hooks():
+    """The test / bench build as a SECOND handle beside the product library (bench.py: the calibration kernels live only there)."""
+    global _hooks_lib
+    if _hooks_lib is None:
+        _hooks_lib = load() if os.path.realpath(LIB_PATH) == os.path.realpath(HOOKS_LIB) or os.environ.get("DISTAFF_HIP_LIB") else _open(HOOKS_LIB)
+    return _hooks_lib
 
 
 def _ptr(a):
@@ -297,6 +331,28 @@ class Comm:
             self._h = None
 
 
+class Calibration:
+    """The calibration kernels of the test / bench build (dependent multiplication chains, multiply-add peak, straight-line-code probe) on
+    `device`, through a small context of libdistaff_hip_hooks.so -- the product library does not contain them."""
+
+    def __init__(self, device=0):
+        self.ctx = Context(10, 20, 1, 0, device=device, lib=load_hooks())
+        if not self.ctx.lib.dst_test_hooks():
+            raise RuntimeError("the calibration kernels need the test / bench build (libdistaff_hip_hooks.so)")
+
+    def bench_mad(self, lanes=1 << 21, iters=2048):
+        return self.ctx.bench_mad(lanes, iters)
+
+    def bench_mulmod(self, lanes=1 << 20, iters=256, portable=False):
+        return self.ctx.bench_mulmod(lanes, iters, portable)
+
+    def bench_code(self, code_kib):
+        return self.ctx.bench_code(code_kib)
+
+    def close(self):
+        self.ctx.close()
+
+
 def prove_sharded_local(contexts, inputs, outputs, cap=1 << 22):
     """dst_prove_sharded_local: one proof over `len(contexts)` contexts (rank r of world, trace uploaded on each), one thread per
     context inside the library, in-process transport."""
@@ -316,8 +372,8 @@ def prove_sharded_local(contexts, inputs, outputs, cap=1 << 22):
 class Context:
     """One proving job on one GPU (``dst_ctx``): owns the device buffers; phases mirror stark::prove (prover.rs:17-168)."""
 
-    def __init__(self, log_n, width, ctx_depth, loop_depth, log_blowup=5, num_queries=50, grinding=20, device=0, rank=0, world=1):
-        self.lib = load()
+    def __init__(self, log_n, width, ctx_depth, loop_depth, log_blowup=5, num_queries=50, grinding=20, device=0, rank=0, world=1, lib=None):
+        self.lib = lib or load()
         self.params = Params(log_n, log_blowup, width, ctx_depth, loop_depth, num_queries, grinding, device, rank, world)
         self.n, self.B, self.W = 1 << log_n, 1 << log_blowup, width
         self.N = self.n * self.B

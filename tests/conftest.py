@@ -13,12 +13,20 @@ def pytest_configure(config):
 
 
 def pytest_sessionstart(session):
-    """A fresh checkout has no libdistaff_hip.so (built artefacts are git-ignored): build it once, exactly as
-    __graft_entry__.build() does (hipcc cross-compiles gfx950 without a GPU).  The tests never fall back to anything else."""
-    lib = os.path.join(ROOT, "distaff_amd", "libdistaff_hip.so")
-    if not os.path.exists(lib) and os.environ.get("DISTAFF_HIP_LIB") is None:
+    """A fresh checkout has no shared libraries (built artefacts are git-ignored): build them once, exactly as __graft_entry__.build()
+    does (hipcc cross-compiles gfx950 without a GPU).  The tests never fall back to anything else.
+
+    The tests bind the TEST build of the library, distaff_amd/libdistaff_hip_hooks.so: the same sources as the product
+    (distaff_amd/libdistaff_hip.so) compiled with -DDISTAFF_TEST_HOOKS, which additionally honours the test-only DISTAFF_* switches
+    (alternative formulations the tests compare with the default ones), and contains the per-operation constraint instance and the
+    calibration kernels.  What is NOT run through it: bench.py (it removes DISTAFF_TEST_HOOKS and refuses anything but the product
+    library), __graft_entry__.smoke(), the plain-C hosts of examples/ and tests/test_product_library.py -- they bind the product."""
+    libs = [os.path.join(ROOT, "distaff_amd", n) for n in ("libdistaff_hip.so", "libdistaff_hip_hooks.so")]
+    if not all(os.path.exists(p) for p in libs) and os.environ.get("DISTAFF_HIP_LIB") is None:
         import subprocess
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "distaff_amd", "csrc"), "-j8"])
+    import distaff_amd
+    distaff_amd.use_test_hooks()
 
 
 @pytest.fixture(scope="session")

@@ -39,8 +39,8 @@ dist.init_process_group = _init_gloo
 import distaff_amd as D
 from distaff_amd import sharded
 
-D.Context.bench_mulmod = lambda self, lanes, iters: 1.0          # the ALU calibration kernels would take minutes on the host
-D.Context.bench_mad = lambda self, lanes, iters: 1.0
+D.Calibration.bench_mulmod = lambda self, lanes, iters: 1.0       # the ALU calibration kernels would take minutes on the host
+D.Calibration.bench_mad = lambda self, lanes, iters: 1.0
 
 
 # bench.py finds no device here (torch.cuda.device_count() == 0 counts as one), so with N > 1 ranks it takes its "ranks share a device"

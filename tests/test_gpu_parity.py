@@ -915,26 +915,28 @@ def test_small_fri_layers_in_one_launch_equal_the_per_layer_path(oracle, monkeyp
         t = O.fibonacci_trace(1 << log_n)
         op = O.Prover.from_trace(t, 1, ext=1 << log_b, grinding=8)
         expected = op.prove()
-        ctx = D.Context(log_n, t.width, t.ctx_depth, t.loop_depth, log_blowup=log_b, grinding=8)
-        ctx.upload(t.columns)
-        monkeypatch.delenv("DISTAFF_FRI_TAIL", raising=False)
-        ctx.set_profiling(1); ctx.kernel_stats(reset=True)
-        assert ctx.prove(t.public_inputs, op.outputs) == expected
-        assert ctx.kernel_stats(reset=True).get("fri_tail_kernel", {}).get("launches") == 1
-        monkeypatch.setenv("DISTAFF_FRI_TAIL", "0")
-        assert ctx.prove(t.public_inputs, op.outputs) == expected
-        stats = ctx.kernel_stats(reset=True)
+        def stats_of_a_proof(**switches):
+            # the library reads its switches once, when a context is created: one context per setting
+            for k in ("DISTAFF_FRI_TAIL", "DISTAFF_FRI_CHAIN"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in switches.items():
+                monkeypatch.setenv(k, v)
+            ctx = D.Context(log_n, t.width, t.ctx_depth, t.loop_depth, log_blowup=log_b, grinding=8)
+            ctx.upload(t.columns)
+            ctx.set_profiling(1); ctx.kernel_stats(reset=True)
+            assert ctx.prove(t.public_inputs, op.outputs) == expected
+            stats = ctx.kernel_stats(reset=True)
+            ctx.close()
+            return stats
+        assert stats_of_a_proof().get("fri_tail_kernel", {}).get("launches") == 1
+        stats = stats_of_a_proof(DISTAFF_FRI_TAIL="0")
         assert "fri_tail_kernel" not in stats and stats.get("fri_draw_kernel", {}).get("launches", 0) >= 2      # every layer's x drawn on the device
         # dst_prove commits the layers above the tail without host round trips (x = prng(root) drawn by fri_draw_kernel, the fold reads it
         # from device memory); DISTAFF_FRI_CHAIN=0 keeps one root read-back and one host draw per layer: the same proof either way
-        for tail in ("0", None):
-            if tail is None:
-                monkeypatch.delenv("DISTAFF_FRI_TAIL", raising=False)
-            monkeypatch.setenv("DISTAFF_FRI_CHAIN", "0")
-            assert ctx.prove(t.public_inputs, op.outputs) == expected
-            assert "fri_draw_kernel" not in ctx.kernel_stats(reset=True)
-            monkeypatch.delenv("DISTAFF_FRI_CHAIN", raising=False)
-        ctx.close()
+        assert "fri_draw_kernel" not in stats_of_a_proof(DISTAFF_FRI_TAIL="0", DISTAFF_FRI_CHAIN="0")
+        assert "fri_draw_kernel" not in stats_of_a_proof(DISTAFF_FRI_CHAIN="0")
+    for k in ("DISTAFF_FRI_TAIL", "DISTAFF_FRI_CHAIN"):
+        monkeypatch.delenv(k, raising=False)
 
 
 def test_fibonacci_2_16_proof_bytes_equal_oracle(oracle):
@@ -1434,7 +1436,7 @@ def test_bench_config2_line(tmp_path):
 @pytest.mark.parametrize("instance", ["small", "deep", "generic"])
 def test_general_constraint_instances_on_the_fibonacci_trace(oracle, monkeypatch, instance):
     """The depth <= 8 and the two any-shape instances of the constraint kernel, forced onto a trace the depth-4 instance would take:
-    same evaluations, same proof (DISTAFF_AIR is read by the library at every evaluation)."""
+    same evaluations, same proof (DISTAFF_AIR is read when the context is created)."""
     import distaff_amd as D
     monkeypatch.setenv("DISTAFF_AIR", instance)
     _check_all_phases(oracle, D, oracle.fibonacci_trace(1 << 10))

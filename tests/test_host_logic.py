@@ -128,22 +128,28 @@ def test_bench_reads_the_stamped_counter_summary():
 
 
 def test_kernel_gate_on_the_built_library():
-    """What build() enforces (__graft_entry__._kernel_gate): every kernel of the product library is at most 64 KiB of code (the instruction
-    cache of a gfx950 CU pair), spills no vector register and uses no scratch -- except the kernels listed with their reason.  Read from
-    the code objects of the built .so (tools/codeobj_info.py), no GPU needed.  The constraint launches of the bench path are named."""
+    """What build() enforces (__graft_entry__._kernel_gate): EVERY kernel of the product library is at most 64 KiB of code (the instruction
+    cache of a gfx950 CU pair), spills no vector register and uses no scratch -- no exceptions; the laboratory kernels that do exceed the
+    limits (listed with their reasons) exist only in the test / bench build.  Read from the code objects of the built libraries
+    (tools/codeobj_info.py), no GPU needed.  The constraint launches of the bench path are named."""
     import os, re, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "tools"))
     import __graft_entry__ as G
     import codeobj_info
     so = os.path.join(root, "distaff_amd", "libdistaff_hip.so")
-    if not os.path.exists(so):
+    hooks_so = os.path.join(root, "distaff_amd", "libdistaff_hip_hooks.so")
+    if not os.path.exists(so) or not os.path.exists(hooks_so):
         G.build()
     kernels = codeobj_info.kernels_of(so)
+    hooks = codeobj_info.kernels_of(hooks_so)
     assert len(kernels) > 60
-    assert G._kernel_gate(kernels) == []
-    for pat in G.GATE_EXCEPTIONS:                                     # no stale exception
-        assert any(re.match(re.escape(pat), k) for k in kernels), pat
+    assert G._kernel_gate(kernels) == []                              # the product: no exception list at all
+    assert G._kernel_gate(hooks, G.GATE_EXCEPTIONS) == [] and set(kernels) < set(hooks)
+    for pat in G.GATE_EXCEPTIONS:                                     # no stale exception, and none of them is in the product
+        assert any(re.match(re.escape(pat), k) for k in hooks), pat
+        assert not any(re.match(re.escape(pat), k) for k in kernels), pat
+    assert not any(k.startswith(("code_probe_kernel", "mulmod_bench_kernel", "mad_peak_kernel", "air_kernel<16,8,0,32,")) for k in kernels)
     bench_path = [k for k in kernels if k.startswith("air_kernel<2,1,4,8,") and not k.startswith("air_kernel<2,1,4,8,1,")]
     assert len(bench_path) == 5
     for k in bench_path:
