@@ -62,15 +62,33 @@ def cpu_baseline(log_n, blowup=32, queries=50):
             "same_size_note": "a 2^%d sample beside a 2^%d headline: the CPU's cost per cell grows with n (log n transforms, caches), so this rate flatters the CPU at the headline size" % (log_n, int(os.environ.get("BENCH_LOG_N", "20")))}
 
 
+PMC_WORKLOAD = {"tag": ""}        # which committed counter summary belongs to the workload of this run: "" = default (config 3), "config4_", "config5_", "config2_"
+
+
+def pmc_workload_tag(workload, log_n, blowup, queries, world):
+    """The rocprofv3 counter passes are taken per configuration (tools/profile_round.sh: config 3; tools/profile_config.sh: configs 2, 4, 5):
+    '' / 'config2_' / 'config4_' / 'config5_' for the workloads they exist for, None otherwise."""
+    if world != 1:
+        return None
+    if workload == "commit":
+        return "config2_" if (log_n, blowup) == (16, 32) else None
+    return {(20, 32, 50): "", (22, 32, 50): "config4_", (24, 16, 100): "config5_"}.get((log_n, blowup, queries))
+
+
 def pmc_row(kernel):
-    """Row of `kernel` in the newest committed PMC summary (profiles/*_pmc_per_kernel.csv) -- or (None, reason) when there is none, when
-    it carries no stamp, or when its stamp (digest of distaff_amd/csrc at the time of the rocprofv3 passes) differs from the sources of
-    this run.  Kernel names are compared without blanks and with template booleans as 0 / 1 (the library's event names print them so)."""
+    """Row of `kernel` in the newest committed PMC summary of this run's workload (profiles/r<N>_[config<k>_]pmc_per_kernel.csv) -- or
+    (None, reason) when there is none, when it carries no stamp, or when its stamp (digest of distaff_amd/csrc at the time of the rocprofv3
+    passes) differs from the sources of this run.  Kernel names are compared without blanks and with template booleans as 0 / 1 (the
+    library's event names print them so)."""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_per_kernel.csv")))
+    import re
+    if PMC_WORKLOAD["tag"] is None:
+        return None, "no counter passes exist for this workload"
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_kernel.csv"))
+                   if re.fullmatch(r"r\d+_%spmc_per_kernel\.csv" % PMC_WORKLOAD["tag"], os.path.basename(f)))
     if not files:
-        return None, "no PMC summary under profiles/"
+        return None, "no PMC summary of this workload under profiles/"
     meta_path = files[-1].replace("_pmc_per_kernel.csv", "_meta.json")
     if not os.path.exists(meta_path):
         return None, os.path.basename(files[-1]) + " carries no stamp"
@@ -156,7 +174,7 @@ def kernel_rooflines(stats, steps, default_workload, top=5):
         per_launch_ms = st["ms"] / st["launches"]
         per_launch_bytes = st["bytes"] / st["launches"]
         achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
-        row, source = pmc_row(name) if default_workload else (None, "PMC passes exist for the default workload only")
+        row, source = pmc_row(name) if default_workload else (None, "no counter passes exist for this workload")
         traffic = None
         if row is not None and row.get("fetch_bytes_per_launch_x2") and row.get("write_bytes_per_launch_raw"):
             traffic = int(row["fetch_bytes_per_launch_x2"]) + int(row["write_bytes_per_launch_raw"])
@@ -258,7 +276,8 @@ def start_watchdog(seconds):
     def watch():
         while not stop.wait(1.0):
             idle = time.monotonic() - _STATE["progress_at"]
-            if idle > seconds:
+            # one blocking host call each: the VM's trace generation (minutes at 2^24) and the CPU leg get a longer leash
+            if idle > seconds * (6 if _STATE["stage"] in ("trace", "cpu baseline") else 1):
                 error_line("no progress for %d s in stage '%s' (BENCH_TIMEOUT_S): giving up instead of hanging" % (idle, _STATE["stage"]))
                 sys.stdout.flush(); sys.stderr.flush()
                 os._exit(3)
@@ -309,7 +328,8 @@ def main():
         args.log_n = int(os.environ.get("BENCH_LOG_N", "16" if args.workload == "commit" else "20"))
     _STATE["args"] = args
     _STATE["rank"] = int(os.environ.get("RANK", "0"))
-    watchdog = start_watchdog(int(os.environ.get("BENCH_TIMEOUT_S", "1500")))
+    # stall limit: with several ranks a stage that makes no progress for minutes is a collective that will never return
+    watchdog = start_watchdog(int(os.environ.get("BENCH_TIMEOUT_S", "1500" if args.gpus == 1 else "420")))
     try:
         run(args)
     except SystemExit as e:
@@ -554,7 +574,8 @@ def run(args):
     # kernels by device time, measured with HIP events on the launch stream inside the timed region.  `roofline` is the kernel with the
     # largest total time IN THIS RUN; `roofline_transform` is always the first pass of the transforms (the kernel profiles/README.md
     # describes), so that the two can be told apart when another kernel is dominant on some box; `rooflines` lists the top five.
-    default_workload = args.workload == "prove" and log_n == 20 and world == 1 and (blowup, args.queries) == (32, 50)     # what the committed PMC passes were taken on
+    PMC_WORKLOAD["tag"] = pmc_workload_tag(args.workload, log_n, blowup, args.queries, world)      # which committed counter passes (if any) were taken on this workload
+    default_workload = PMC_WORKLOAD["tag"] is not None
     rooflines = kernel_rooflines(stats, args.steps, default_workload)
     note = ("the path is 128-bit modular integer arithmetic on the VALU (valu_issue_frac, alu_roofline, DESIGN.md section 3), not HBM-bound; `frac` is the per-KERNEL figure: "
             "its algorithmic bytes include the staging array the two-pass transform writes in pass A and re-reads in pass B, which SURVEY section 8(d) does not count -- "
