@@ -91,6 +91,29 @@ FE_HD fe fe_add(const fe& a, const fe& b) {
     fe_cf s = c | d;
     return fe_make(fe_sel(s, z0, s0), fe_sel(s, z1, s1), fe_sel(s, z2, s2), fe_sel(s, z3, s3));
 }
+// A store the L2 should not keep: data that streams out of a kernel and is next read by ANOTHER kernel (the staging array between the two
+// passes of a transform).  global_store_dwordx4 ... nt: the line is marked for early eviction, so the tiles a pass re-reads (four-step
+// twiddles shared by the registers, coefficient tiles shared by the cosets) stay resident in the XCD's 4 MiB L2 instead of being pushed
+// out by 40 MiB of output per tile group.
+FE_HD void fe_store_stream(fe* p, const fe& v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t fe_u32x4 __attribute__((ext_vector_type(4)));
+    const fe_u32x4 t = {v.v[0], v.v[1], v.v[2], v.v[3]};
+    __builtin_nontemporal_store(t, reinterpret_cast<fe_u32x4*>(p));
+#else
+    *p = v;
+#endif
+}
+// the matching load: data read exactly once by this kernel (global_load_dwordx4 ... nt)
+FE_HD fe fe_load_stream(const fe* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    typedef uint32_t fe_u32x4 __attribute__((ext_vector_type(4)));
+    const fe_u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const fe_u32x4*>(p));
+    return fe_make(t.x, t.y, t.z, t.w);
+#else
+    return *p;
+#endif
+}
 // canonical subtraction: d = a - b; on borrow add p, i.e. subtract C128 modulo 2^128
 FE_HD fe fe_sub(const fe& a, const fe& b) {
     fe_cf c, d;

@@ -104,10 +104,28 @@ struct OutB {                                          // natural-order store X[
     __device__ __forceinline__ Tok pre(uint32_t, uint32_t) const { return Tok{}; }
     __device__ __forceinline__ void put(uint32_t row, uint32_t t, const fe& v, const Tok&) const {
         const uint32_t k2 = ((log_n2 ? (__brev(row) >> (32 - log_n2)) : 0u) << pre_shift) + h;
+#if NTT_STREAM_B_STORE
+        fe_store_stream(dst + (k2 * k_stride + t), scale ? fe_mul_tw(v, s) : v);
+#else
         dst[k2 * k_stride + t] = scale ? fe_mul_tw(v, s) : v;            // uniform base + 32-bit lane offset (at most 2^24 points)
+#endif
     }
 };
 
+// Streaming hints on the arrays a pass touches exactly once (fe_store_stream / fe_load_stream, fe.h): the staging array between the passes
+// (written by the first, read by the second) and the finished extension (read next by the leaf hashing).  Measured on one lease, four
+// alternating rounds of the 2^20 proof (tools/ab_multi.sh, round 5): none 35.63 ms, first-pass stores 35.30, + second-pass stores 35.16,
+// + second-pass loads 35.15 (first passes 11.84 -> 11.41 ms).  FETCH_SIZE of the first passes does not move (10.3 -> 10.1 GB raw per proof):
+// what they re-read is not pushed out by their own output, it is the four-step table and the coefficient tiles in 64-byte row segments.
+#ifndef NTT_STREAM_STORE
+#define NTT_STREAM_STORE 1
+#endif
+#ifndef NTT_STREAM_B_STORE
+#define NTT_STREAM_B_STORE 1
+#endif
+#ifndef NTT_STREAM_B_LOAD
+#define NTT_STREAM_B_LOAD 1
+#endif
 extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
 
 // Both passes are persistent over `tiles_per_block` adjacent tiles.  PREFETCH instances (WPE = 4 waves per SIMD, 128 registers): the
@@ -217,9 +235,14 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
             static_for<0, RB>([&](auto q_) {
                 constexpr int q = decltype(q_)::value;
 #if NTT_TW4_PAIRS
-                if (ok[q]) dst[off[q]] = (a.debug & 2u) ? v[q] : fe_mul_tw(v[q], w[q]);
+                const fe out_q = (a.debug & 2u) ? v[q] : fe_mul_tw(v[q], w[q]);
 #else
-                if (ok[q]) dst[off[q]] = (a.debug & 2u) ? v[q] : fe_mul(v[q], w[q]);
+                const fe out_q = (a.debug & 2u) ? v[q] : fe_mul(v[q], w[q]);
+#endif
+#if NTT_STREAM_STORE
+                if (ok[q]) fe_store_stream(dst + off[q], out_q);          // the staging array: read next by the second pass, not by this one
+#else
+                if (ok[q]) dst[off[q]] = out_q;
 #endif
             });
         }
@@ -252,10 +275,15 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_b(NttArgs a, const fe* 
 #define NTT_ROW_B(idx) (colfast_b ? ((idx) & (T - 1)) : ((idx) >> log_n2))
 #define NTT_M2_B(idx) (colfast_b ? ((idx) >> log_t) : ((idx) & (n2 - 1)))
     // PRE (DIF pre-stage, see NttArgs): u_0 = y[m] + y[m + n2], u_1 = (y[m] - y[m + n2]) * w_{2 n2}^m
+#if NTT_STREAM_B_LOAD
+#define NTT_LOAD_B(p) fe_load_stream(p)
+#else
+#define NTT_LOAD_B(p) (*(p))
+#endif
 #define NTT_FETCH_B1(e, var) if constexpr ((e) < EPT) { uint32_t idx = lane + (e) * THREADS; idx = idx < count ? idx : 0u; \
         if constexpr (PRE != 0) { const uint32_t m_ = NTT_M2_B(idx); const fe* p_ = srct + NTT_ROW_B(idx) * row_stride + m_; const fe x0_ = p_[0], x1_ = p_[n2]; \
                                   var = hh ? fe_mul_tw(fe_sub(x0_, x1_), a.pre_tw[m_]) : fe_add(x0_, x1_); } \
-        else var = srct[NTT_ROW_B(idx) * row_stride + NTT_M2_B(idx)]; }
+        else var = NTT_LOAD_B(srct + (NTT_ROW_B(idx) * row_stride + NTT_M2_B(idx))); }
 #define NTT_FETCH_B(tile) { const fe* __restrict__ srct = src + (size_t)((tile) * T) * a.src_row_stride; NTT_EACH(NTT_FETCH_B1) }
     const uint32_t row_stride = (uint32_t)a.src_row_stride;
     const uint32_t tile0 = group * a.tiles_per_block;

@@ -118,7 +118,9 @@ def load_hooks():
     """The test / bench build as a SECOND handle beside the product library (bench.py: the calibration kernels live only there)."""
     global _hooks_lib
     if _hooks_lib is None:
-        _hooks_lib = load() if os.path.realpath(LIB_PATH) == os.path.realpath(HOOKS_LIB) or os.environ.get("DISTAFF_HIP_LIB") else _open(HOOKS_LIB)
+        bound = load()
+        has = getattr(bound, "dst_test_hooks", None)
+        _hooks_lib = bound if (has is not None and has() == 1) else _open(HOOKS_LIB)       # the bound library is itself a test build (tests, the CPU emulation)
     return _hooks_lib
 
 

@@ -6,7 +6,7 @@ ROUNDS=${1:-3}; shift
 VARS="$@"; [ -z "$VARS" ] && VARS=$(ls gpurun_tmp_libs 2>/dev/null)
 mkdir -p gpurun_out; : > gpurun_out/ab_multi.txt
 one() {   # name, env
-    env $2 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-upload-leg --no-verify 2>&1 | grep "^{" | python -c "
+    env $2 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-upload-leg --no-verify --allow-lib-override 2>&1 | grep "^{" | python -c "
 import json, sys
 b = json.loads(sys.stdin.read()); k = b['kernels']
 air = sum(v['ms_per_step'] for n, v in k.items() if n.startswith('air_kernel'))

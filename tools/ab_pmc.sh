@@ -6,7 +6,7 @@ R=$PWD
 for e in "$@"; do
     for ctr in FETCH_SIZE WRITE_SIZE; do
         rm -rf /tmp/abp; mkdir -p /tmp/abp
-        (cd /tmp && env ${e:-X_=1} rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/abp -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-upload-leg --no-verify > /tmp/abp/log 2>&1)
+        (cd /tmp && env ${e:-X_=1} rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d /tmp/abp -o p -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-upload-leg --no-verify --allow-lib-override > /tmp/abp/log 2>&1)
         python - "$e" $ctr <<'PY'
 import csv, glob, sys, collections, re
 f = glob.glob('/tmp/abp/**/p_counter_collection.csv', recursive=True)

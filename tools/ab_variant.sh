@@ -9,7 +9,7 @@ src=/tmp/ab_variant_$name
 rm -rf "$root/gpurun_tmp_libs/$name" "$src"
 mkdir -p "$root/gpurun_tmp_libs/$name/distaff_amd" "$src"
 (cd "$root" && tar -c --exclude='.pytest_cache' distaff_amd/csrc include) | tar -x -C "$src"
-make -C "$src/distaff_amd/csrc" -j8 CXXFLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable -Wno-unused-value $flags" > /dev/null 2> "$src/build.err" || { tail -20 "$src/build.err"; exit 1; }
+make -C "$src/distaff_amd/csrc" -j8 CXXFLAGS="-O3 -std=c++17 -fPIC -fvisibility=hidden --offload-arch=gfx950 -Wno-unused-function -Wno-unused-variable -Wno-unused-value $flags" > /dev/null 2> "$src/build.err" || { tail -20 "$src/build.err"; exit 1; }
 cp "$src/distaff_amd/libdistaff_hip.so" "$root/gpurun_tmp_libs/$name/distaff_amd/"
 echo "$flags" > "$root/gpurun_tmp_libs/$name/FLAGS"
 echo "variant $name built with: $flags"
