@@ -26,7 +26,10 @@ def pytest_sessionstart(session):
         import subprocess
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "distaff_amd", "csrc"), "-j8"])
     import distaff_amd
-    distaff_amd.use_test_hooks()
+    if os.environ.get("DISTAFF_PRODUCT_ONLY") == "1":       # tests/test_product_library.py re-runs a selection of the parity tests on the product library itself
+        os.environ.pop("DISTAFF_TEST_HOOKS", None)
+    else:
+        distaff_amd.use_test_hooks()
 
 
 @pytest.fixture(scope="session")

@@ -6,6 +6,16 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+def test_which_library_is_bound():
+    """the parity tests run on the test build (tests/conftest.py) -- or, when tests/test_product_library.py re-runs a selection with
+    DISTAFF_PRODUCT_ONLY=1, on the product library"""
+    import os
+    import distaff_amd as D
+    if os.environ.get("DISTAFF_HIP_LIB"):
+        return
+    assert D.load().dst_test_hooks() == (0 if os.environ.get("DISTAFF_PRODUCT_ONLY") == "1" else 1)
+
+
 def _ctx(D, trace, **kw):
     log_n = trace.length.bit_length() - 1
     return D.Context(log_n, trace.width, trace.ctx_depth, trace.loop_depth, **kw)
@@ -303,6 +313,24 @@ def test_whole_instruction_set_and_flow_blocks(oracle, monkeypatch, name, instan
     trace, num_outputs = _isa_traces(oracle)[name]
     assert trace.trace_hash() == trace.program_hash
     _check_all_phases(oracle, D, trace, num_outputs=num_outputs, grinding=8)
+
+
+def test_loops_and_macros_at_2_13_and_2_15(oracle):
+    """The same at sizes where every kernel runs its multi-workgroup form: the Collatz example from 27 (111 iterations of a `while` loop with
+    a nested if / else and isodd.128: 2^15 rows, 26 registers, loop depth 1, context depth 2 -- examples/collatz.rs) and 100 range checks
+    (`read rc.63 add`: binacc x 63, eq, 2^13 rows -- examples/range.rs); every intermediate of every phase against the oracle."""
+    import random
+    import distaff_amd as D
+    O = oracle
+    t = O.Trace("begin pad read dup push.1 ne while.true swap push.1 add swap dup isodd.128 if.true push.3 mul push.1 add else push.2 div end "
+                "dup push.1 ne end swap end", [], [27])
+    assert (t.length, t.loop_depth, t.ctx_depth) == (1 << 15, 1, 2) and t.outputs(1) == [111]
+    _check_all_phases(O, D, t, num_outputs=1, grinding=8)
+    rnd = random.Random(3)
+    values = [rnd.randrange(1 << 64) for _ in range(100)]
+    t = O.Trace("begin " + "read rc.63 add " * 100 + "end", [0], values)
+    assert t.length == 1 << 13 and t.outputs(1) == [sum(v < (1 << 63) for v in values)]
+    _check_all_phases(O, D, t, num_outputs=1, grinding=8)
 
 
 def test_isa_traces_cover_every_operation(oracle):

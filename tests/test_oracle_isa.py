@@ -603,6 +603,8 @@ def test_example_collatz(oracle):                                               
     if t.length <= 4096:
         prove_and_verify(O, t, 1, [7])
     assert O.Trace(src, [], [1]).outputs(1) == [0]                        # loop not entered
+    t = O.Trace(src, [], [27])                                            # the classic long one: 111 steps, 2^15 rows
+    assert t.outputs(1) == [_collatz_steps(27)] == [111] and (t.length, t.loop_depth) == (1 << 15, 1) and t.trace_hash() == t.program_hash
 
 
 def test_example_range(oracle):                                                                   # examples/range.rs:4-71
