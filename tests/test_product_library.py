@@ -114,7 +114,7 @@ def test_parity_selection_on_the_product_library_itself():
     """The phase-by-phase parity tests bind the test build (same sources, more switches).  A selection of them -- those that need no test-only
     switch -- is run here against distaff_amd/libdistaff_hip.so itself: every intermediate of every phase and the proof bytes, Fibonacci
     traces, other program shapes, traces of the whole instruction set with loops, the sharded prover with thread-ranks."""
-    selection = ["test_fibonacci_all_phases", "test_other_program_shapes", "test_program_shapes_with_stack_depth_5_to_8", "test_blowup_16_and_64",
+    selection = ["test_which_library_is_bound", "test_fibonacci_all_phases", "test_other_program_shapes", "test_program_shapes_with_stack_depth_5_to_8", "test_blowup_16_and_64",
                  "test_tiny_traces_of_32_and_16_rows", "test_thread_rank_transport_issue_order_and_peer_access", "test_loops_and_macros_at_2_13_and_2_15",
                  "test_whole_instruction_set_and_flow_blocks and not generic"]
     env = dict(os.environ, DISTAFF_PRODUCT_ONLY="1")
