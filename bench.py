@@ -37,12 +37,18 @@ def phase_algorithmic_bytes(n, W, B):
     }
 
 
+HOST_ONLY_SOURCES = ("api.hip", "shard.hip", "comm.hip", "comm.h", "host_util.h", "host_proof.h", "host_vm.h")        # no device code: an edit there does not change what a counter summary measured
+
+
 def csrc_digest():
-    """digest of the kernel sources (same rule as __graft_entry__._sources_digest): ties a rocprofv3 summary to the code it measured"""
+    """digest of the KERNEL sources (same rule as __graft_entry__._sources_digest): ties a rocprofv3 summary to the code it measured.  Every
+    file of distaff_amd/csrc that can contribute device code; the host-side translation units and headers are left out."""
     import glob
     import hashlib
     h = hashlib.sha256()
     for f in sorted(glob.glob(os.path.join(ROOT, "distaff_amd", "csrc", "*.h")) + glob.glob(os.path.join(ROOT, "distaff_amd", "csrc", "*.hip"))):
+        if os.path.basename(f) in HOST_ONLY_SOURCES:
+            continue
         h.update(os.path.basename(f).encode()); h.update(open(f, "rb").read())
     return h.hexdigest()[:16]
 

@@ -45,7 +45,7 @@ struct dst_comm {
             if (i == seen_streams.size()) seen_streams.push_back(s);
             tag = (uint8_t)i;
         }
-        trace.push_back(CollRec{kind, tag, (uint64_t)bytes});
+        if (trace.size() < 65536) trace.push_back(CollRec{kind, tag, (uint64_t)bytes});      // a record for tests / diagnosis, not a log: bounded
     }
     // what dst_comm_describe reports
     virtual int transport_kind() const = 0;                      // DST_COMM_RCCL / DST_COMM_LOCAL / DST_COMM_CALLBACKS
