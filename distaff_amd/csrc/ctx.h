@@ -59,7 +59,7 @@ static const dst_switch_def DST_SWITCHES[] = {
     {"DISTAFF_NTT_WAVES",          false, "4|8",             "force the 512- or 1024-lane instances of the LDS passes"},
     {"DISTAFF_NTT_FIXED",          false, "0",               "use the any-shape instances where a shape-compiled one exists"},
     {"DISTAFF_NTT_DIF",            false, "0|1|2",           "first pass of an extension: coset DIT (0), pre-scale + DIF (1), DIT with last-stage twiddles from global memory (2)"},
-    {"DISTAFF_NTT_DEBUG",          false, "bits",            "1: print the occupancy of every launch shape once; 2: skip the four-step twiddle (timing ablation, wrong results)"},
+    {"DISTAFF_NTT_DEBUG",          false, "1",               "print the occupancy of every transform launch shape once"},
     {"DISTAFF_LDE_BATCH",          false, "cols,cosets",     "registers x cosets per transform launch"},
     {"DISTAFF_FOLD8_DFT",          false, "0",               "8n-coefficient extensions without the fused fold + 8-point step"},
     {"DISTAFF_TRACE_BUFFER",       false, "1",               "give the trace its own buffer instead of coset 0 of the extension"},

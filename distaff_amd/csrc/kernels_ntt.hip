@@ -43,7 +43,7 @@ struct NttArgs {
     uint32_t j0;               // global index of the first local coset
     uint32_t has_scale;        // 1: multiply the result by `scale` (1/n of inverse transforms)
     uint32_t tiles_per_block;  // adjacent tiles one workgroup walks through
-    uint32_t debug;            // DISTAFF_NTT_DEBUG ablation bits (timing experiments only): 2 no four-step twiddle
+    uint32_t debug;            // DISTAFF_NTT_DEBUG (test build): 1 = report the occupancy of every launch shape once
     // pass B addressing (two-pass plans: row stride n2, frequency stride n1, no batch); three-pass plans run the last pass once per
     // middle frequency k2 (batch index = low bits of the tile-group index): source rows (k1, k2, .) and destination k1 + n1 * (k2 + n2' * k3)
     size_t src_row_stride, dst_k_stride, src_batch_stride, dst_batch_stride;
@@ -212,11 +212,7 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
         // (OutB); here that does not pay: in the 128-register instances the four-step twiddles (and the last-stage pairs from global memory)
         // live in the last round spill (13.15 / 13.3 against 13.05 ms), in the spill-free fixed-shape instance it is within the noise
         // (18.85 against 18.95 ms of extension, with the twiddle requested before or after the butterfly).
-#if defined(NTT_RB8)
-        constexpr int RB = WPE > 4 ? NTT_RB8 : THREADS == 512 ? 2 : 4;
-#else
         constexpr int RB = WPE > 4 ? 1 : THREADS == 512 ? 2 : 4;
-#endif
         fe* __restrict__ dst = dst0 + tile * T;          // uniform bases, 32-bit lane offsets
         const tw4_t* __restrict__ tw = tw4 + tile * T;
         for (uint32_t base = 0; base < count; base += RB * THREADS) {
@@ -235,9 +231,9 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
             static_for<0, RB>([&](auto q_) {
                 constexpr int q = decltype(q_)::value;
 #if NTT_TW4_PAIRS
-                const fe out_q = (a.debug & 2u) ? v[q] : fe_mul_tw(v[q], w[q]);
+                const fe out_q = fe_mul_tw(v[q], w[q]);
 #else
-                const fe out_q = (a.debug & 2u) ? v[q] : fe_mul(v[q], w[q]);
+                const fe out_q = fe_mul(v[q], w[q]);
 #endif
 #if NTT_STREAM_STORE
                 if (ok[q]) fe_store_stream(dst + off[q], out_q);          // the staging array: read next by the second pass, not by this one
@@ -300,11 +296,7 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_b(NttArgs a, const fe* 
         __syncthreads();
         if (PREFETCH && it + 1 < a.tiles_per_block) NTT_FETCH_B(tile0 + it + 1)
         const OutB out{dst + k1_0, (uint32_t)a.dst_k_stride, log_n2, a.has_scale != 0, a.scale, (uint32_t)PRE, hh};
-#if defined(NTT_TW_GLOBAL_B)
-        const fe_tw* Wuse = a.stage_tw;          // experiment: stage twiddles through the vector cache instead of LDS
-#else
         const fe_tw* Wuse = TW;
-#endif
         if constexpr (LOG_LEN != 0) lds_ntt_dif_fixed<THREADS, LOG_LEN, LOG_T, OutB>(L, Wuse, out);
         else lds_ntt_dif<THREADS, OutB>(L, Wuse, log_n2, log_t, 1u, log_n2 + 1u, out);
     }

@@ -64,13 +64,7 @@ __device__ __forceinline__ void lds_wave_sync() {
 // isolation: 11 % of their time).  XOR-ing bits 3..5 and 6..8 of the index into its low three bits spreads strides 4, 16 and 64 over
 // the banks and leaves unit stride alone.  The workgroup fills the table through the same map.
 __device__ __forceinline__ uint32_t dif_tw_slot(uint32_t e) {
-#if defined(NTT_LAB_TW0)
-    return e & 1u;                       // timing ablation (wrong results): every lane reads one of two twiddles -- what do the twiddle reads cost?
-#elif defined(NTT_LAB_PLAIN_TW) || defined(NTT_TW_GLOBAL_B)
-    return e;
-#else
     return e ^ ((e >> 3) & 7u) ^ ((e >> 6) & 7u);
-#endif
 }
 
 // The same transform for a tile shape known at compile time: the rounds are separate code with literal strides.  The lane index goes
@@ -119,12 +113,7 @@ __device__ __forceinline__ void lds_dif_round(fe* L, const fe_tw* W, uint32_t lo
         fe a0, a1, a2, a3;
         fe_addsub(x0, x2, a0, a2);
         fe_addsub(x1, x3, a1, a3);
-#if defined(NTT_LAB_TWREG)              // timing ablation (wrong results): ONE twiddle read per round, the rest from registers -- what do the twiddle reads cost?
-        const fe_tw lab_tw = W[0];
-#define NTT_TW_AT(idx) lab_tw
-#else
 #define NTT_TW_AT(idx) W[dif_tw_slot(idx)]
-#endif
         if (hd != 1) a2 = fe_mul_tw(a2, NTT_TW_AT(pos << (s - 1)));          // hd == 1: pos == 0 in every lane
         a3 = fe_mul_tw(a3, NTT_TW_AT((pos + hd) << (s - 1)));
         // stage s + 1: (a0, a1) and (a2, a3) with w_d^pos
