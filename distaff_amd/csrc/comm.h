@@ -25,8 +25,9 @@ struct dst_comm {
     virtual bool stream_ordered() const { return false; }
     int all_gather(const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream) { note('G', bytes_per_rank, stream); return all_gather_impl(send, recv, bytes_per_rank, stream); }   // recv = [world][bytes]
     int all_to_all(const void* send, void* recv, size_t chunk_bytes, hipStream_t stream) { note('A', chunk_bytes, stream); return all_to_all_impl(send, recv, chunk_bytes, stream); }           // chunk g of send -> rank g; chunk r of recv <- rank r
-    // small host values (status words, lengths, opening blobs)
-    int all_gather_host(const void* send, void* recv, size_t bytes_per_rank) { note('H', bytes_per_rank, nullptr); return all_gather_host_impl(send, recv, bytes_per_rank); }
+    // small host values (status words, lengths, opening blobs); complete on return.  `stream`: the caller's stream -- a transport that moves
+    // the values through the device (RCCL) queues them THERE, so that a communicator sees its collectives on the streams of the prover only
+    int all_gather_host(const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream) { note('H', bytes_per_rank, nullptr); return all_gather_host_impl(send, recv, bytes_per_rank, stream); }
 
     // Issue-order record (dst_comm_trace; DISTAFF_SHARD_DEBUG=1 switches it on at creation): one entry per collective -- kind, bytes per
     // rank, and which of the streams this communicator has seen it was queued on (index by first appearance; '-' = host values).  RCCL
@@ -53,5 +54,5 @@ struct dst_comm {
 protected:
     virtual int all_gather_impl(const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream) = 0;
     virtual int all_to_all_impl(const void* send, void* recv, size_t chunk_bytes, hipStream_t stream) = 0;
-    virtual int all_gather_host_impl(const void* send, void* recv, size_t bytes_per_rank) = 0;
+    virtual int all_gather_host_impl(const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream) = 0;
 };

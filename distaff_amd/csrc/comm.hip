@@ -92,7 +92,8 @@ struct RcclComm : dst_comm {
         if ((r = api->GroupEnd()) != ncclSuccess) return fail(r, "ncclGroupEnd");
         return DST_OK;
     }
-    int all_gather_host_impl(const void* send, void* recv, size_t bytes) override {
+    int all_gather_host_impl(const void* send, void* recv, size_t bytes, hipStream_t stream) override {
+        hipStream_t own_stream = stream ? stream : this->own_stream;       // the prover's stream; a caller without one gets the communicator's own
         const size_t need = bytes * (world + 1);
         if (need > staging_bytes) {
             if (staging) hipFree(staging);
@@ -179,7 +180,7 @@ struct LocalComm : dst_comm {
     int all_to_all_impl(const void* send, void* recv, size_t chunk, hipStream_t stream) override {
         return exchange(send, stream, false, [&](uint32_t p, const void* src) { return hipMemcpyAsync((uint8_t*)recv + (size_t)p * chunk, (const uint8_t*)src + (size_t)rank * chunk, chunk, hipMemcpyDefault, stream); });
     }
-    int all_gather_host_impl(const void* send, void* recv, size_t bytes) override {
+    int all_gather_host_impl(const void* send, void* recv, size_t bytes, hipStream_t) override {
         return exchange(send, nullptr, true, [&](uint32_t p, const void* src) { memcpy((uint8_t*)recv + (size_t)p * bytes, src, bytes); return hipSuccess; });
     }
 };
@@ -197,7 +198,7 @@ struct CallbackComm : dst_comm {
     int transport_kind() const override { return DST_COMM_CALLBACKS; }
     int all_gather_impl(const void* send, void* recv, size_t bytes, hipStream_t stream) override { return call(0, send, recv, bytes, stream); }
     int all_to_all_impl(const void* send, void* recv, size_t chunk, hipStream_t stream) override { return call(1, send, recv, chunk, stream); }
-    int all_gather_host_impl(const void* send, void* recv, size_t bytes) override { return call(2, send, recv, bytes, nullptr); }
+    int all_gather_host_impl(const void* send, void* recv, size_t bytes, hipStream_t) override { return call(2, send, recv, bytes, nullptr); }
 };
 }  // namespace
 

@@ -1084,7 +1084,7 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
     {
         struct LenRec { uint64_t len; int64_t rc; } rec{(uint64_t)mine, S.rc};
         std::vector<LenRec> all(G);
-        if (!S.coll(S.timed([&] { return comm->all_gather_host(&rec, all.data(), sizeof(LenRec)); }), "openings")) return S.agreed;
+        if (!S.coll(S.timed([&] { return comm->all_gather_host(&rec, all.data(), sizeof(LenRec), c->stream); }), "openings")) return S.agreed;
         for (size_t g = 0; g < G; g++) {
             if (all[g].rc != DST_OK && S.agreed == DST_OK) { S.agreed = (int)all[g].rc; if (S.rc == DST_OK) c->err = "before the openings: rank " + std::to_string(g) + " reported error " + std::to_string(all[g].rc); }
             lens[g] = all[g].len;            // every rank derives the same plan, so this equals what dst_shard_open computed locally
@@ -1096,7 +1096,7 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
     std::vector<uint8_t> blob(width + 8, 0), all(( width + 8) * G);
     S.local([&] { return dst_shard_open(c, positions.data(), (uint32_t)positions.size(), blob.data(), width, &mine, nullptr); });
     { const int64_t rc64 = S.rc; memcpy(blob.data() + width, &rc64, 8); }                    // the status rides behind the blob
-    if (!S.coll(S.timed([&] { return comm->all_gather_host(blob.data(), all.data(), width + 8); }), "openings")) return S.agreed;
+    if (!S.coll(S.timed([&] { return comm->all_gather_host(blob.data(), all.data(), width + 8, c->stream); }), "openings")) return S.agreed;
     for (size_t g = 0; g < G && S.agreed == DST_OK; g++) {
         int64_t rc64; memcpy(&rc64, all.data() + g * (width + 8) + width, 8);
         if (rc64 != DST_OK) { S.agreed = (int)rc64; if (S.rc == DST_OK) c->err = "openings: rank " + std::to_string(g) + " reported error " + std::to_string(rc64); }
