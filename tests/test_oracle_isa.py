@@ -29,205 +29,21 @@ def inv(x):
 # ---------------------------------------------------------------------------------------------------------------------------------
 # assembler: src/programs/assembly/tests.rs
 # ---------------------------------------------------------------------------------------------------------------------------------
-ASSEMBLY_CASES = [
-    # single_block :4-16
-    ("begin push.1 push.2 add end",
-     """begin noop noop noop noop noop noop noop
-        push(1) noop noop noop noop noop noop noop
-        push(2) add noop noop noop noop noop noop
-        noop noop noop noop noop noop noop end"""),
-    # sequence_of_blocks :18-33
-    ("begin block push.1 push.2 add end block push.3 push.4 add end end",
-     """begin noop noop noop noop noop noop noop
-        noop noop noop noop noop noop noop block
-        push(1) noop noop noop noop noop noop noop
-        push(2) add noop noop noop noop noop end
-        block push(3) noop noop noop noop noop noop
-        noop push(4) add noop noop noop noop noop
-        end end"""),
-    # sequence_of_blocks_with_prefix :35-50
-    ("begin read read add block push.1 push.2 add end block push.3 push.4 sub end end",
-     """begin read read add noop noop noop noop
-        noop noop noop noop noop noop noop block
-        push(1) noop noop noop noop noop noop noop
-        push(2) add noop noop noop noop noop end
-        block push(3) noop noop noop noop noop noop
-        noop push(4) neg add noop noop noop noop
-        end end"""),
-    # sequence_of_blocks_with_prefix_and_suffix :52-71
-    ("begin read read add block push.1 push.2 add end block push.3 push.4 sub end hash.2 end",
-     """begin read read add noop noop noop noop
-        noop noop noop noop noop noop noop block
-        push(1) noop noop noop noop noop noop noop
-        push(2) add noop noop noop noop noop end
-        block push(3) noop noop noop noop noop noop
-        noop push(4) neg add noop noop noop noop
-        end pad2 pad2 noop noop noop noop noop
-        noop noop noop noop noop noop noop noop
-        noop rescr rescr rescr rescr rescr rescr rescr
-        rescr rescr rescr drop4 noop noop noop noop
-        end"""),
-    # single_if_else :76-103
-    ("begin push.3 push.5 read if.true add dup mul else mul dup add end end",
-     """begin noop noop noop noop noop noop noop
-        push(3) noop noop noop noop noop noop noop
-        push(5) read noop noop noop noop noop noop
-        noop noop noop noop noop noop noop if
-        assert add dup mul noop noop noop noop
-        noop noop noop noop noop noop noop else
-        not assert mul dup add noop noop noop
-        noop noop noop noop noop noop noop end
-        end"""),
-    # single_if_else_with_suffix :105-141
-    ("begin push.3 push.5 read if.true add dup mul else mul dup add end rc.16 end",
-     """begin
-            noop noop noop noop noop noop noop
-            push(3) noop noop noop noop noop noop noop
-            push(5) read noop noop noop noop noop noop
-            noop noop noop noop noop noop noop
-            if
-                assert add dup mul noop noop noop noop
-                noop noop noop noop noop noop noop
-            else
-                not assert mul dup add noop noop noop
-                noop noop noop noop noop noop noop
-            end
-            pad2 noop noop noop noop noop noop noop
-            push(1) swap dup binacc.16 binacc binacc binacc binacc
-            binacc binacc binacc binacc binacc binacc binacc binacc
-            binacc binacc binacc dup drop4 read::eq eq
-        end"""),
-    # nested_if_else :143-183
-    ("begin push.3 push.5 read if.true add dup mul eq if.true not push.6 mul end else mul dup add end end",
-     """begin noop noop noop noop noop noop noop
-        push(3) noop noop noop noop noop noop noop
-        push(5) read noop noop noop noop noop noop
-        noop noop noop noop noop noop noop
-        if
-            assert add dup mul read::eq eq noop noop
-            noop noop noop noop noop noop noop
-            if
-                assert not noop noop noop noop noop noop
-                push(6) mul noop noop noop noop noop
-            else
-                not assert noop noop noop noop noop noop
-                noop noop noop noop noop noop noop
-            end
-        else
-            not assert mul dup add noop noop noop
-            noop noop noop noop noop noop noop
-        end
-    end"""),
-    # single_loop :188-213
-    ("begin push.3 push.5 read while.true add dup mul read.ab end end",
-     """begin noop noop noop noop noop noop noop
-        push(3) noop noop noop noop noop noop noop
-        push(5) read noop noop noop noop noop noop
-        noop noop noop noop noop noop noop
-        while
-            assert add dup mul read2 noop noop noop
-            noop noop noop noop noop noop noop
-        end
-    end"""),
-    # loop_with_suffix_and_nested_if_else :215-255
-    ("begin push.3 push.5 read while.true add dup mul read.ab if.true push.6 sub end push.7 add end end",
-     """begin noop noop noop noop noop noop noop
-        push(3) noop noop noop noop noop noop noop
-        push(5) read noop noop noop noop noop noop
-        noop noop noop noop noop noop noop
-        while
-            assert add dup mul read2 noop noop noop
-            noop noop noop noop noop noop noop
-            if
-                assert noop noop noop noop noop noop noop
-                push(6) neg add noop noop noop noop
-            else
-                not assert noop noop noop noop noop noop
-                noop noop noop noop noop noop noop
-            end
-            push(7) add noop noop noop noop noop noop
-            noop noop noop noop noop noop noop
-        end
-    end"""),
-    # repeat_2_spans :260-284
-    ("begin read read add read eq repeat.2 push.3 add end end",
-     """begin
-        read read add read read::eq eq noop
-        noop noop noop noop noop noop noop
-        block
-            push(3) add noop noop noop noop noop noop
-            noop noop noop noop noop noop noop noop
-            push(3) add noop noop noop noop noop noop
-            noop noop noop noop noop noop noop
-        end
-    end"""),
-    # repeat_5_spans :286-316
-    ("begin read read add read eq repeat.5 push.3 add end end",
-     "begin read read add read read::eq eq noop noop noop noop noop noop noop noop block "
-     + ("push(3) add" + " noop" * 14 + " ") * 4 + "push(3) add" + " noop" * 13 + " end end"),
-    # repeat_2_blocks :318-359
-    ("begin read read add read eq repeat.2 read if.true push.3 add mul end end end",
-     """begin
-        read read add read read::eq eq noop
-        noop noop noop noop noop noop noop
-        block
-            read noop noop noop noop noop noop noop
-            noop noop noop noop noop noop noop
-            if
-                assert noop noop noop noop noop noop noop
-                push(3) add mul noop noop noop noop
-            else
-                not assert noop noop noop noop noop noop
-                noop noop noop noop noop noop noop
-            end
-            read noop noop noop noop noop noop noop
-            noop noop noop noop noop noop noop
-            if
-                assert noop noop noop noop noop noop noop
-                push(3) add mul noop noop noop noop
-            else
-                not assert noop noop noop noop noop noop
-                noop noop noop noop noop noop noop
-            end
-        end
-    end"""),
-    # repeat_2_blocks_with_suffix :361-402
-    ("begin read read add read eq repeat.2 read if.true push.3 add mul end sub inv end end",
-     """begin
-        read read add read read::eq eq noop
-        noop noop noop noop noop noop noop
-        block
-            read noop noop noop noop noop noop noop
-            noop noop noop noop noop noop noop
-            if
-                assert noop noop noop noop noop noop noop
-                push(3) add mul noop noop noop noop
-            else
-                not assert noop noop noop noop noop noop
-                noop noop noop noop noop noop noop
-            end
-            neg add inv noop noop noop noop noop
-            noop noop noop noop noop noop noop noop
-            read noop noop noop noop noop noop noop
-            noop noop noop noop noop noop noop
-            if
-                assert noop noop noop noop noop noop noop
-                push(3) add mul noop noop noop noop
-            else
-                not assert noop noop noop noop noop noop
-                noop noop noop noop noop noop noop
-            end
-            neg add inv noop noop noop noop noop
-            noop noop noop noop noop noop noop
-        end
-    end"""),
-]
+def _assembly_cases():
+    """the reference's assembler fixtures (src/programs/assembly/tests.rs:1-402: all 13 tests), kept as data in tests/golden/"""
+    import json
+    import os
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "assembly_debug_strings.json")
+    return json.load(open(path))["cases"]
+
+
+ASSEMBLY_CASES = _assembly_cases()
 
 
 @pytest.mark.parametrize("case", range(len(ASSEMBLY_CASES)))
 def test_assembler_debug_strings(oracle, case):
-    source, expected = ASSEMBLY_CASES[case]
-    assert oracle.program_debug(source) == norm(expected)
+    c = ASSEMBLY_CASES[case]
+    assert oracle.program_debug(c["source"]) == c["debug"], c["reference_test"]
 
 
 def test_assembler_macros(oracle):
