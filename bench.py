@@ -65,7 +65,7 @@ def cpu_baseline(log_n, blowup=32, queries=50):
             "sample": "one full prove() of a 2^%d-step Fibonacci trace (same program and ProofOptions), %.1f s, oracle/liboracle.so -O3, 1 of %d host cores"
                       % (log_n, dt, os.cpu_count() or 1),
             "prove_ms": dt * 1e3, "phase_ms": [round(x, 1) for x in p.phase_ms], "reference_published": REFERENCE_PUBLISHED,
-            "same_size_note": "a 2^%d sample beside a 2^%d headline: the CPU's cost per cell grows with n (log n transforms, caches), so this rate flatters the CPU at the headline size" % (log_n, int(os.environ.get("BENCH_LOG_N", "20")))}
+            "same_size_note": "a 2^%d sample beside a 2^%d headline: the CPU's cost per cell grows with n (log n transforms, caches), so this rate flatters the CPU at the headline size; the same-size leg (--cpu-log-n 20, 227.6 s = 9.2e4 cells/s) is committed as profiles/r5_bench_cpu_2_20.json" % (log_n, int(os.environ.get("BENCH_LOG_N", "20")))}
 
 
 PMC_WORKLOAD = {"tag": ""}        # which committed counter summary belongs to the workload of this run: "" = default (config 3), "config4_", "config5_", "config2_"
@@ -153,6 +153,8 @@ def box_fingerprint(cal, mad_peak, mulmod_peak):
     except Exception as e:                                           # noqa: BLE001
         box["device_error"] = str(e)
     try:
+        if cal is None:
+            raise RuntimeError("no calibration build")
         t16, t176, t176c = cal.bench_code(16), cal.bench_code(176), cal.bench_code(177)
         box["code_probe"] = {"ms_16KiB": round(t16, 4), "ms_176KiB": round(t176, 4), "per_instruction_ratio": round((t176 / 176.0) / (t16 / 16.0), 3),
                              "ms_176KiB_convoy": round(t176c, 4), "convoy_per_instruction_ratio": round((t176c / 176.0) / (t16 / 16.0), 3),
@@ -609,9 +611,16 @@ def run(args):
     # on this device, against the multiply-adds the kernels execute: NTT launches count theirs (18 per table-pair multiplication), the
     # constraint kernels are priced with the static instruction counts of the current build (distaff_amd/_build_info.json)
     mad_iters = 2048
-    cal = D.Calibration(device)                                      # calibration kernels: test / bench build (libdistaff_hip_hooks.so), beside the measured product library
-    mad_ms = cal.bench_mad(1 << 21, mad_iters)
-    mad_peak = (1 << 21) * mad_iters * 32 / (mad_ms * 1e-3)
+    # calibration kernels: test / bench build (libdistaff_hip_hooks.so), opened beside the measured product library.  The line must not
+    # be lost when that build is missing or its kernels fail: the peaks then fall back to the figures measured on this pool and say so.
+    calibration_note = None
+    try:
+        cal = D.Calibration(device)
+        mad_ms = cal.bench_mad(1 << 21, mad_iters)
+        mad_peak = (1 << 21) * mad_iters * 32 / (mad_ms * 1e-3)
+    except Exception as e:                                           # noqa: BLE001
+        cal, mad_ms, mad_peak = None, float("nan"), 2.7e13
+        calibration_note = "calibration kernels unavailable (%s: %s): mad_peak / mulmod_peak are the pool's usual figures, not measured in this run" % (type(e).__name__, e)
     air_isa = {}
     try:
         air_isa = json.load(open(os.path.join(ROOT, "distaff_amd", "_build_info.json"))).get("air_isa", {})
@@ -642,8 +651,12 @@ def run(args):
     except Exception as e:                                           # noqa: BLE001  (never lose the bench line over a summary file)
         alu["valu_issue"] = {"error": str(e)}
     # ALU ceiling: dependent-chain modular multiplications per second measured on this device with the same fe_mul
-    mm_ms = cal.bench_mulmod(1 << 21, 512)
-    mulmod_peak = (1 << 21) * 512 * 4 / (mm_ms * 1e-3)
+    try:
+        mm_ms = cal.bench_mulmod(1 << 21, 512)
+        mulmod_peak = (1 << 21) * 512 * 4 / (mm_ms * 1e-3)
+    except Exception as e:                                           # noqa: BLE001
+        mulmod_peak = 5.0e11
+        calibration_note = calibration_note or "mulmod calibration failed (%s): the pool's usual figure" % e
     if args.workload == "commit":
         workload = ("BASELINE config 2: LDE (iNTT + coset NTTs) + BLAKE3 row hashing + Merkle tree of %d uniform random columns (splitmix64, SURVEY.md 8(d)) of 2^%d steps, "
                     "blowup %d: TraceTable::extend + build_merkle_tree (prover.rs:22-35) only" % (W_FIB, log_n, blowup))
@@ -662,7 +675,7 @@ def run(args):
         "prover_ms": ms_per_step,
         "phase_ms": None if transport.startswith("torch") else {k: round(v / args.steps, 3) for k, v in zip(phase_names, phase_sum) if args.workload == "prove" or k in ("lde", "trace_merkle")},
         "proof_bytes": len(proof),
-        "library": lib_ident,
+        "library": dict(lib_ident, calibration_note=calibration_note),
         "shard_stage_ms_rank0": {k: round(v / args.steps, 3) for k, v in stage_sum.items()} or None,
         "roofline": roofline,
         "roofline_transform": roofline_transform,
@@ -704,7 +717,8 @@ def run(args):
         else:
             out["cpu_baseline"] = cpu_baseline(args.cpu_log_n, blowup, args.queries)
     print(json.dumps(out), flush=True)
-    cal.close()
+    if cal is not None:
+        cal.close()
     ctx.close()
     if dist is not None:
         dist.barrier()
