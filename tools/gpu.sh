@@ -5,5 +5,7 @@ set -e
 root=$(cd "$(dirname "$0")/.." && pwd)
 make -C "$root/distaff_amd/csrc" -j8 2>&1 | grep -E " error|Error " && exit 1
 make -C "$root/oracle" > /dev/null
+# the build stamp (git head, kernel table) travels with the snapshot: profile scripts on the box read it
+(cd "$root" && python -c "import __graft_entry__ as g; g._build_info()" > /dev/null 2>&1) || echo "[gpu.sh] warning: _build_info() failed (kernel gate?)"
 t=$1; shift
 exec /usr/local/graft/bin/gpurun --timeout "$t" -- "$@"
