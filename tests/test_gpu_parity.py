@@ -721,7 +721,7 @@ def _accepts_and_rejects(O, proof, program_hash, result):
     assert not ok
 
 
-def _sampled_parity(O, D, log_n, log_blowup=5, num_queries=50, points=32, horner_rows=32, deep_registers=20, seed=1):
+def _sampled_parity(O, D, log_n, log_blowup=5, num_queries=50, points=32, horner_rows=32, deep_registers=20, seed=1, trace=None, num_outputs=1):
     """Oracle POINT computations against intermediates of a full-size proof (sizes at which the oracle's whole-domain loops take hours):
       * trace polynomials: Horner at trace-domain points = the trace (interpolation), at LDE points = sampled LDE rows (trace_table.rs:143-169);
       * the reference evaluator on sampled row pairs of the 8n-point domain = the transition combination the constraint kernels
@@ -732,13 +732,20 @@ def _sampled_parity(O, D, log_n, log_blowup=5, num_queries=50, points=32, horner
         rebuilt with Python integers from those rows, = the composition LDE;
       * every FRI layer: sampled rows hashed by the oracle's BLAKE3 = the leaf, folded by the oracle's quartic interpolation /
         evaluation at x = prng(root) (fri/prover.rs:25-49, quartic.rs:20-60) = the entry of the next layer.
-    Challenges are the library's own Fiat-Shamir draws (pinned against the oracle's PRNG in test_host_logic)."""
+    Challenges are the library's own Fiat-Shamir draws (pinned against the oracle's PRNG in test_host_logic).
+    `trace`: any oracle.Trace instead of the Fibonacci trace of 2^log_n steps (other register counts, context / loop / stack depths)."""
     P = O.P
-    cols, program_hash, result = _fib(log_n)
-    n, B, W = 1 << log_n, 1 << log_blowup, 20
+    if trace is None:
+        cols, program_hash, result = _fib(log_n)
+        W, ctx_depth, loop_depth, stack_depth, inputs, outputs = 20, 1, 0, 4, [1, 0], [result]
+    else:
+        cols, log_n = trace.columns, trace.length.bit_length() - 1
+        W, ctx_depth, loop_depth, stack_depth = trace.width, trace.ctx_depth, trace.loop_depth, trace.stack_depth
+        inputs, outputs = trace.public_inputs, trace.outputs(num_outputs)
+    n, B = 1 << log_n, 1 << log_blowup
     N = n * B
     rng = np.random.default_rng(seed)
-    ctx = D.Context(log_n, W, 1, 0, log_blowup=log_blowup, num_queries=num_queries)
+    ctx = D.Context(log_n, W, ctx_depth, loop_depth, log_blowup=log_blowup, num_queries=num_queries)
     ctx.upload(cols)
     ints = lambda a: [int(lo) | (int(hi) << 64) for lo, hi in np.asarray(a, dtype=np.uint64).reshape(-1, 2)]      # noqa: E731
     elems = lambda b: ints(np.frombuffer(b, dtype=np.uint64))                                                     # noqa: E731
@@ -748,7 +755,7 @@ def _sampled_parity(O, D, log_n, log_blowup=5, num_queries=50, points=32, horner
     # ---- steps 1-2
     root = ctx.commit_trace()
     polys = ctx.read_elements("polys").reshape(W, n, 2)
-    for c, k in ((0, 0), (4, 1), (19, n - 1), (int(rng.integers(W)), int(rng.integers(n)))):
+    for c, k in ((0, 0), (4, 1), (W - 1, n - 1), (int(rng.integers(W)), int(rng.integers(n)))):
         assert O.poly_eval(polys[c], O.exp(g_n, k)) == ints(cols[c, k])[0], ("interpolation", c, k)
     steps = [0, 8, 3, 8 * n - 8, 8 * n - 1, 8 * n - 5, 8 * 17 + 5] + [int(v) for v in rng.integers(0, 8 * n, size=max(points - 7, 0))]
     steps = steps[:max(points, 7)]
@@ -767,14 +774,14 @@ def _sampled_parity(O, D, log_n, log_blowup=5, num_queries=50, points=32, horner
 
     # ---- steps 3-5
     coeffs = D.prng_vector(root, 344)
-    croot = ctx.eval_constraints([1, 0], [result], coeffs)
+    croot = ctx.eval_constraints(inputs, outputs, coeffs)
     tv = elems(ctx.shard_read(11, 0, [(s_ % 8) * n + s_ // 8 for s_ in steps]))
     cv = elems(ctx.shard_read(3, 0, [cm(p_) for p_ in pos]))
     op_count, ph = ints(cols[0, n - 1])[0], [ints(cols[1, n - 1])[0], ints(cols[2, n - 1])[0]]
     x_last = pow(g_n, n - 1, P)
     for i, s_ in enumerate(steps):
         x = O.exp(g_8n, s_)
-        t, bi, bf, ok = O.evaluate_at(n, 1, 0, 4, coeffs, ph, op_count, [1, 0], [result], s_, x, ints(rows_cur[i]), ints(rows_nxt[i]))
+        t, bi, bf, ok = O.evaluate_at(n, ctx_depth, loop_depth, stack_depth, coeffs, ph, op_count, inputs, outputs, s_, x, ints(rows_cur[i]), ints(rows_nxt[i]))
         assert ok and t == tv[i], ("transition combination", s_)
         if s_ % 8:                                                     # off the trace domain the divisors are invertible
             c_x = (bi * pow(x - 1, -1, P) + bf * pow(x - x_last, -1, P) + t * (x - x_last) % P * pow(pow(x, n, P) - 1, -1, P)) % P
@@ -836,6 +843,25 @@ def test_sampled_oracle_parity_small(oracle, log_n, log_blowup):
     pins the sampling arithmetic itself, and runs on the CPU-emulated build"""
     import distaff_amd as D
     _sampled_parity(oracle, D, log_n, log_blowup=log_blowup, points=24, horner_rows=48)
+
+
+def test_sampled_oracle_parity_on_a_long_loop_trace(oracle):
+    """The same sampled checks on a trace that is NOT the Fibonacci shape, at a size where the oracle's whole-domain loops take minutes: the
+    Collatz example from 837 799 (524 iterations of a `while` loop with a nested if / else, isodd.128, eq: 2^17 rows, 26 registers, loop
+    depth 1, context depth 2 -- the any-shape constraint instances, 7-block leaves, 26-register transform batches), and the complete
+    proof accepted by the oracle's verifier."""
+    import distaff_amd as D
+    O = oracle
+    t = O.Trace("begin pad read dup push.1 ne while.true swap push.1 add swap dup isodd.128 if.true push.3 mul push.1 add else push.2 div end "
+                "dup push.1 ne end swap end", [], [837799])
+    assert (t.length, t.width, t.loop_depth, t.ctx_depth) == (1 << 17, 26, 1, 2) and t.outputs(1) == [524]
+    _sampled_parity(O, D, None, points=24, horner_rows=8, deep_registers=26, trace=t)
+    ctx = _ctx(D, t)
+    ctx.upload(t.columns)
+    proof = ctx.prove(t.public_inputs, t.outputs(1))
+    assert O.verify(proof, t.program_hash, t.public_inputs, t.outputs(1)) == (True, "")
+    assert O.verify(proof, t.program_hash, t.public_inputs, [523])[0] is False
+    ctx.close()
 
 
 def test_config3_sampled_oracle_parity_at_full_size(oracle):
