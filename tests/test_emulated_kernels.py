@@ -84,7 +84,11 @@ def emulated_library():
 def _run(emulated_library, args, timeout=900):
     env = dict(os.environ, DISTAFF_HIP_LIB=emulated_library, DISTAFF_HIP_RUNTIME="none", DISTAFF_EMU_THREADS="2",
                DISTAFF_BENCH_ENTRY=os.path.join(EMU_DIR, "bench_harness.py"))           # the tests that launch bench.py go through the CPU stand-ins
-    return subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", "-m", "gpu"] + args,
+    # the selected tests are independent: four pytest-xdist workers (each launch of the emulated runtime uses two host threads) when the
+    # plugin is there, otherwise in sequence
+    import importlib.util
+    workers = ["-n", "4"] if importlib.util.find_spec("xdist") is not None and (os.cpu_count() or 1) >= 8 and len(args) > 8 else []
+    return subprocess.run([sys.executable, "-m", "pytest", "-q", "-x", "-p", "no:cacheprovider", "-m", "gpu"] + workers + args,
                           cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout)
 
 
