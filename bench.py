@@ -261,7 +261,25 @@ def cpu_baseline_commit(cols, blowup):
             "reference_published": REFERENCE_PUBLISHED}
 
 
-_STATE = {"rank": 0, "stage": "start", "args": None}
+_STATE = {"rank": 0, "stage": "start", "args": None, "stdout_fd": None}
+
+
+def claim_stdout():
+    """stdout carries the ONE JSON line and nothing else: libraries print there too (RCCL writes its version banner to stdout through C
+    stdio, flushed when the process exits -- i.e. AFTER the line), so file descriptor 1 is pointed at stderr for the rest of the run and the
+    line is written to the saved descriptor."""
+    if _STATE["stdout_fd"] is None:
+        sys.stdout.flush()
+        _STATE["stdout_fd"] = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(line):
+    sys.stdout.flush(); sys.stderr.flush()
+    if _STATE["stdout_fd"] is None:
+        print(line, flush=True)
+    else:
+        os.write(_STATE["stdout_fd"], (line + "\n").encode())
 
 
 def error_line(message):
@@ -269,8 +287,8 @@ def error_line(message):
     or a bare traceback"""
     a = _STATE["args"]
     if _STATE["rank"] == 0:
-        print(json.dumps({"metric": "trace_cells_per_sec", "value": None, "unit": "trace-cells/s", "n_gpus": getattr(a, "gpus", None), "steps": getattr(a, "steps", None),
-                          "warmup": getattr(a, "warmup", None), "error": str(message)[-2000:], "stage": _STATE["stage"]}), flush=True)
+        emit(json.dumps({"metric": "trace_cells_per_sec", "value": None, "unit": "trace-cells/s", "n_gpus": getattr(a, "gpus", None), "steps": getattr(a, "steps", None),
+                         "warmup": getattr(a, "warmup", None), "error": str(message)[-2000:], "stage": _STATE["stage"]}))
 
 
 def start_watchdog(seconds):
@@ -336,6 +354,7 @@ def main():
         args.log_n = int(os.environ.get("BENCH_LOG_N", "16" if args.workload == "commit" else "20"))
     _STATE["args"] = args
     _STATE["rank"] = int(os.environ.get("RANK", "0"))
+    claim_stdout()
     # stall limit: with several ranks a stage that makes no progress for minutes is a collective that will never return
     watchdog = start_watchdog(int(os.environ.get("BENCH_TIMEOUT_S", "1500" if args.gpus == 1 else "420")))
     try:
@@ -716,7 +735,7 @@ def run(args):
             out["proof_verified"] = "trace root equals the oracle's (same columns, CPU leg of this run)"
         else:
             out["cpu_baseline"] = cpu_baseline(args.cpu_log_n, blowup, args.queries)
-    print(json.dumps(out), flush=True)
+    emit(json.dumps(out))
     if cal is not None:
         cal.close()
     ctx.close()
