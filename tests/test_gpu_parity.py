@@ -333,6 +333,28 @@ def test_loops_and_macros_at_2_13_and_2_15(oracle):
     _check_all_phases(O, D, t, num_outputs=1, grinding=8)
 
 
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_prover_on_loop_and_macro_traces(oracle, world):
+    """dst_prove_sharded (thread-ranks) on traces that are not the Fibonacci shape: loop registers, context depth 2, stacks deeper than 8 --
+    the constraint evaluation runs per rank on its own cosets, the last trace state travels with rank 0's status record; every rank must
+    return the oracle's proof."""
+    import distaff_amd as D
+    O = oracle
+    traces = _isa_traces(O)
+    for name in ("while_5_iterations", "nested_loops", "example_comparison", "example_merkle", "cmp_128"):
+        t, num_outputs = traces[name]
+        op = O.Prover.from_trace(t, num_outputs, grinding=8)
+        expected = op.prove()
+        ctxs = []
+        for r in range(world):
+            ctx = D.Context(t.length.bit_length() - 1, t.width, t.ctx_depth, t.loop_depth, rank=r, world=world, grinding=8)
+            ctx.upload(t.columns)
+            ctxs.append(ctx)
+        assert D.prove_sharded_local(ctxs, t.public_inputs, op.outputs) == expected, name
+        for ctx in ctxs:
+            ctx.close()
+
+
 def test_isa_traces_cover_every_operation(oracle):
     """the set above executes all 32 user operations and all 8 flow operations, with loop_depth 0, 1 and 2 and ctx_depth up to 3"""
     users, flows, loop_depths = set(), set(), set()
