@@ -66,6 +66,9 @@ int main(int argc, char** argv) {
         dst_ctx* ctx = make_ctx(log_n, rank, world, (int)rank, cols);
         dst_comm* comm = NULL;
         if (dst_comm_init(id, rank, world, (int)rank, &comm) != DST_OK) { fprintf(stderr, "rank %u: dst_comm_init: %s\n", rank, dst_comm_last_error(NULL)); return 1; }
+        dst_comm_info info;                                    /* what RCCL itself says about the communicator it built */
+        if (dst_comm_describe(comm, &info) == DST_OK)
+            fprintf(stderr, "rank %u: RCCL %u connected %u ranks, this rank is %u on device %d\n", rank, info.rccl_version, info.rccl_ranks, info.rccl_rank, (int)info.device);
         rc = dst_prove_sharded(ctx, comm, &pub, proof, cap, &len);
         if (rc != DST_OK) { fprintf(stderr, "rank %u: dst_prove_sharded: %d %s\n", rank, rc, dst_last_error(ctx)); return 1; }
         dst_comm_destroy(comm);
