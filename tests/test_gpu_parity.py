@@ -1290,6 +1290,24 @@ def test_gpu_proofs_match_golden_digests():
         assert len(proof) == c["proof_bytes"] and D.blake3(proof).hex() == c["proof_blake3"], c
 
 
+def test_gpu_proofs_of_loop_and_macro_traces_match_golden_digests():
+    """Committed fixtures of traces with a `while` loop, a taken else-branch and the lt / isodd macros (tests/golden/isa_traces.npz, made by
+    the oracle's VM) and the digests of the oracle's proofs for them: no oracle run involved on the GPU box."""
+    import json
+    import os
+    import distaff_amd as D
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    traces = np.load(os.path.join(here, "isa_traces.npz"))
+    for c in json.load(open(os.path.join(here, "isa_proof_digests.json")))["cases"]:
+        cols = traces[c["name"]]
+        assert cols.shape == (c["width"], c["length"], 2) and D.blake3(np.ascontiguousarray(cols).tobytes()).hex() == c["columns_blake3"]
+        ctx = D.Context(c["length"].bit_length() - 1, c["width"], c["ctx_depth"], c["loop_depth"], grinding=c["grinding_factor"])
+        ctx.upload(cols)
+        proof = ctx.prove([int(v) for v in c["public_inputs"]], [int(v) for v in c["outputs"]])
+        ctx.close()
+        assert len(proof) == c["proof_bytes"] and D.blake3(proof).hex() == c["proof_blake3"], c["name"]
+
+
 _GLOO_WORKER = r'''
 import os, sys
 sys.path.insert(0, %r)

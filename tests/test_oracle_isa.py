@@ -462,3 +462,22 @@ def test_example_merkle(oracle):                                                
         assert t.outputs(4) == expected
         if depth == 3:
             prove_and_verify(O, t, 4, expected)
+
+
+def test_committed_isa_fixtures_are_what_the_oracle_produces(oracle):
+    """tests/golden/isa_traces.npz / isa_proof_digests.json (the GPU test that uses them runs without the oracle) against a fresh run of the
+    script that made them: a change of the oracle's VM or prover shows up here."""
+    import importlib.util
+    import json
+    import os
+    import numpy as np
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    spec = importlib.util.spec_from_file_location("make_isa_golden", os.path.join(here, "make_isa_golden.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    arrays, cases = mod.build()
+    committed = json.load(open(os.path.join(here, "isa_proof_digests.json")))["cases"]
+    assert cases == committed
+    stored = np.load(os.path.join(here, "isa_traces.npz"))
+    for name, cols in arrays.items():
+        assert (stored[name] == cols).all(), name
