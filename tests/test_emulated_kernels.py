@@ -68,6 +68,7 @@ SELECTION = [
     "test_prove_sharded_with_collectives_on_their_own_stream[2]",
     "test_isa_traces_cover_every_operation",
     "test_sharded_prover_on_loop_and_macro_traces[2]",
+    "test_gpu_proofs_of_loop_and_macro_traces_match_golden_digests",
 ] + ["test_whole_instruction_set_and_flow_blocks[%s-%s]" % (name, instance) for name, instance in (
     ("stack_manipulation", ""), ("choose2", "generic"), ("cswap2", ""), ("math_inv_neg_not", ""), ("bool_and_or", "generic"), ("read_read2", ""), ("eq", ""),
     ("rescr_double_hash", ""), ("cmp_128", ""), ("binacc_128", "generic"), ("if_true", "generic"), ("if_false", ""), ("while_skipped", ""),
