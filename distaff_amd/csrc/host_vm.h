@@ -14,28 +14,93 @@
 namespace dsth {
 
 // ---- host field (u128) -------------------------------------------------------------------------------------------------------
-static const u128 HF_C = ((u128)45 << 40) - 1;      // 2^128 mod p
+// p = 2^128 - C with C = 45 * 2^40 - 1 (46 bits): a 256-bit product hi:lo is folded as lo + hi * C, twice.
+static const uint64_t HF_C = ((uint64_t)45 << 40) - 1;      // 2^128 mod p
 inline u128 hf_add(u128 a, u128 b) { u128 z = FIELD_P - b; return a < z ? FIELD_P - z + a : a - z; }
 inline u128 hf_sub(u128 a, u128 b) { return a < b ? FIELD_P - b + a : a - b; }
-inline u128 hf_mul(u128 a, u128 b) {
-    u128 hi, lo;
-    mul_wide(a, b, hi, lo);
-    while (hi) { u128 h2, l2; mul_wide(hi, HF_C, h2, l2); u128 s = lo + l2; hi = h2 + (s < lo); lo = s; }
-    return lo >= FIELD_P ? lo - FIELD_P : lo;
+// hf_fold_lazy: any hi:lo -> a value < 2^128 congruent to it (not necessarily < p); hf_fold: the canonical value
+inline u128 hf_fold_lazy(u128 hi, u128 lo) {
+    u128 t0 = (u128)(uint64_t)hi * HF_C, t1 = (u128)(uint64_t)(hi >> 64) * HF_C;       // hi * C = t0 + t1 * 2^64 < 2^174
+    u128 s = lo + t0;
+    uint64_t top = (uint64_t)(t1 >> 64) + (s < lo);
+    u128 s2 = s + (t1 << 64);
+    top += s2 < s;                                                                       // < 2^47: what went past 2^128
+    u128 f = (u128)top * HF_C;                                                           // < 2^93
+    u128 r = s2 + f;
+    if (r < s2) r += HF_C;                                                               // wrapped once more: r < 2^93 before the add
+    return r;
 }
-inline u128 hf_pow(u128 b, u128 e) { if (!b) return 0; u128 r = 1; while (e) { if (e & 1) r = hf_mul(r, b); e >>= 1; b = hf_mul(b, b); } return r; }
+inline u128 hf_fold(u128 hi, u128 lo) { u128 r = hf_fold_lazy(hi, lo); return r >= FIELD_P ? r - FIELD_P : r; }
+template <bool LAZY = false>
+inline u128 hf_mul(u128 a, u128 b) {                                                     // LAZY: operands and result anywhere below 2^128
+    uint64_t a0 = (uint64_t)a, a1 = (uint64_t)(a >> 64), b0 = (uint64_t)b, b1 = (uint64_t)(b >> 64);
+    u128 p00 = (u128)a0 * b0, p01 = (u128)a0 * b1, p10 = (u128)a1 * b0, p11 = (u128)a1 * b1;
+    u128 mid = (p00 >> 64) + (uint64_t)p01 + (uint64_t)p10;
+    u128 hi = p11 + (p01 >> 64) + (p10 >> 64) + (mid >> 64), lo = (u128)(uint64_t)p00 | (mid << 64);
+    return LAZY ? hf_fold_lazy(hi, lo) : hf_fold(hi, lo);
+}
+template <bool LAZY = false>
+inline u128 hf_sqr(u128 a) {                                                             // three multiplies instead of four
+    uint64_t a0 = (uint64_t)a, a1 = (uint64_t)(a >> 64);
+    u128 p00 = (u128)a0 * a0, p01 = (u128)a0 * a1, p11 = (u128)a1 * a1;
+    u128 mid = (p00 >> 64) + 2 * (u128)(uint64_t)p01;
+    u128 hi = p11 + 2 * (p01 >> 64) + (mid >> 64), lo = (u128)(uint64_t)p00 | (mid << 64);
+    return LAZY ? hf_fold_lazy(hi, lo) : hf_fold(hi, lo);
+}
+inline u128 hf_pow(u128 b, u128 e) { if (!b) return 0; u128 r = 1; while (e) { if (e & 1) r = hf_mul(r, b); e >>= 1; b = hf_sqr(b); } return r; }
 inline u128 limbs(const uint32_t v[4]) { return (u128)v[0] | ((u128)v[1] << 32) | ((u128)v[2] << 64) | ((u128)v[3] << 96); }
 static const u128 HF_INV_ALPHA = (((u128)0xAAAAAAAAAAAAAAAAull) << 64) | 0xAAAA8CAAAAAAAAABull;     // utils/sponge.rs:70
 
+// x -> x^INV_ALPHA (the inverse of cubing) on the four state elements at once.  The steps of a trace form one dependency chain through
+// this function, so its latency is the cost of the generator: the four lanes advance in lock-step (four independent multiplies in flight)
+// along an addition chain for the exponent's bit pattern -- INV_ALPHA = (10)^40 10001100 (10)^20 10101011 in binary: with
+// a_k = x^((10)^k), a_2k = a_k^(4^k) * a_k gives a_40 and a_20 in 9 multiplies; 143 squarings + 13 multiplies per lane against the
+// 127 + 64 of square-and-multiply.
+struct Lanes { u128 v[4]; };
+inline void l_sqr(Lanes& r, int n) { for (int k = 0; k < n; k++) for (int l = 0; l < 4; l++) r.v[l] = hf_sqr<true>(r.v[l]); }
+inline void l_mul(Lanes& r, const Lanes& b) { for (int l = 0; l < 4; l++) r.v[l] = hf_mul<true>(r.v[l], b.v[l]); }
+inline void inv_alpha4(u128 s[4]) {
+    Lanes x, a1, a2, a4, a8, a16, a20, r;
+    for (int l = 0; l < 4; l++) x.v[l] = s[l];
+    a1 = x;    l_sqr(a1, 1);                             // x^(10b)
+    a2 = a1;   l_sqr(a2, 2);   l_mul(a2, a1);            // (10)^2
+    a4 = a2;   l_sqr(a4, 4);   l_mul(a4, a2);            // (10)^4
+    a8 = a4;   l_sqr(a8, 8);   l_mul(a8, a4);            // (10)^8
+    a16 = a8;  l_sqr(a16, 16); l_mul(a16, a8);           // (10)^16
+    a20 = a16; l_sqr(a20, 8);  l_mul(a20, a4);           // (10)^20
+    r = a16;   l_sqr(r, 32);   l_mul(r, a16);            // (10)^32
+    l_sqr(r, 16); l_mul(r, a8);                          // (10)^40
+    l_sqr(r, 1); l_mul(r, x);                            // 1
+    l_sqr(r, 4); l_mul(r, x);                            // 0001
+    l_sqr(r, 1); l_mul(r, x);                            // 1
+    l_sqr(r, 2);                                         // 00
+    l_sqr(r, 40); l_mul(r, a20);                         // (10)^20
+    l_sqr(r, 8); l_mul(r, a4); l_mul(r, x);              // 10101011 = (10)^4 + 1
+    for (int l = 0; l < 4; l++) s[l] = r.v[l] >= FIELD_P ? r.v[l] - FIELD_P : r.v[l];          // the chain ran on values below 2^128: canonical now
+}
+
 // one round of the program-hash accumulator (src/utils/sponge.rs:13-30)
+struct SpongeTables {                                     // the constants as u128, converted once
+    u128 ark[8][16], mds[16];
+    SpongeTables() {
+        for (int i = 0; i < 8; i++) for (int j = 0; j < 16; j++) ark[i][j] = limbs(SPONGE_ARK[i][j]);
+        for (int i = 0; i < 16; i++) mds[i] = limbs(SPONGE_MDS[i]);
+    }
+};
+inline const SpongeTables& sponge_tables() { static const SpongeTables t; return t; }
+inline void sponge_mds(const SpongeTables& T, const u128 s[4], u128 r[4]) {
+    for (int i = 0; i < 4; i++) { u128 acc = 0; for (int j = 0; j < 4; j++) acc = hf_add(acc, hf_mul(T.mds[i * 4 + j], s[j])); r[i] = acc; }
+}
 inline void sponge_round(u128 s[4], u128 op_code, u128 op_value, size_t step) {
+    const SpongeTables& T = sponge_tables();
     size_t idx = step % 16;
-    for (int i = 0; i < 4; i++) { u128 t = hf_add(s[i], limbs(SPONGE_ARK[i][idx])); s[i] = hf_mul(hf_mul(t, t), t); }
+    for (int i = 0; i < 4; i++) { u128 t = hf_add(s[i], T.ark[i][idx]); s[i] = hf_mul(hf_sqr(t), t); }
     u128 r[4];
-    for (int i = 0; i < 4; i++) { u128 acc = 0; for (int j = 0; j < 4; j++) acc = hf_add(acc, hf_mul(limbs(SPONGE_MDS[i * 4 + j]), s[j])); r[i] = acc; }
+    sponge_mds(T, s, r);
     r[0] = hf_add(r[0], op_code); r[1] = hf_add(r[1], op_value);
-    for (int i = 0; i < 4; i++) s[i] = hf_pow(hf_add(r[i], limbs(SPONGE_ARK[4 + i][idx])), HF_INV_ALPHA);
-    for (int i = 0; i < 4; i++) { u128 acc = 0; for (int j = 0; j < 4; j++) acc = hf_add(acc, hf_mul(limbs(SPONGE_MDS[i * 4 + j]), s[j])); r[i] = acc; }
+    for (int i = 0; i < 4; i++) s[i] = hf_add(r[i], T.ark[4 + i][idx]);
+    inv_alpha4(s);
+    sponge_mds(T, s, r);
     for (int i = 0; i < 4; i++) s[i] = r[i];
 }
 
