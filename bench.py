@@ -65,7 +65,27 @@ def cpu_baseline(log_n, blowup=32, queries=50):
             "sample": "one full prove() of a 2^%d-step Fibonacci trace (same program and ProofOptions), %.1f s, oracle/liboracle.so -O3, 1 of %d host cores"
                       % (log_n, dt, os.cpu_count() or 1),
             "prove_ms": dt * 1e3, "phase_ms": [round(x, 1) for x in p.phase_ms], "reference_published": REFERENCE_PUBLISHED,
-            "same_size_note": "a 2^%d sample beside a 2^%d headline: the CPU's cost per cell grows with n (log n transforms, caches), so this rate flatters the CPU at the headline size; the same-size leg (--cpu-log-n 20, 227.6 s = 9.2e4 cells/s) is committed as profiles/r5_bench_cpu_2_20.json" % (log_n, int(os.environ.get("BENCH_LOG_N", "20")))}
+            "same_size_reference": same_size_cpu_leg(),
+            "same_size_note": "a 2^%d sample beside a 2^%d headline: the CPU's cost per cell grows with n (log n transforms, caches), so this rate flatters the CPU at the headline size; "
+                              "same_size_reference quotes the committed leg at the headline size (one full prove() at 2^20 takes minutes: run once per round with --cpu-log-n 20, not in the driver's bench)" % (log_n, int(os.environ.get("BENCH_LOG_N", "20")))}
+
+
+def same_size_cpu_leg():
+    """The CPU leg at the HEADLINE size, from the newest committed builder run (profiles/r<N>_bench_cpu_2_20.json: `bench.py --cpu-log-n 20`, one
+    full oracle prove() of the 2^20-step trace on one host core of a GPU box of this pool) -- quoted, not re-measured: it takes four minutes."""
+    import glob
+    import re
+    pat = re.compile(r"r(\d+)_bench_cpu_2_20\.json")
+    files = sorted((int(pat.fullmatch(os.path.basename(f)).group(1)), f) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_bench_cpu_2_20.json")) if pat.fullmatch(os.path.basename(f)))
+    if not files:
+        return None
+    try:
+        line = [l for l in open(files[-1][1]).read().splitlines() if l.startswith("{")][-1]
+        cb = json.loads(line)["cpu_baseline"]
+        return {"source": "profiles/" + os.path.basename(files[-1][1]), "log_n": 20, "value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                "prove_s": round(cb["prove_ms"] / 1e3, 1), "phase_ms": cb.get("phase_ms"), "sample": cb.get("sample")}
+    except Exception as e:                                           # noqa: BLE001  (never lose the bench line over a committed file)
+        return {"source": "profiles/" + os.path.basename(files[-1][1]), "error": str(e)}
 
 
 PMC_WORKLOAD = {"tag": ""}        # which committed counter summary belongs to the workload of this run: "" = default (config 3), "config4_", "config5_", "config2_"
@@ -81,45 +101,85 @@ def pmc_workload_tag(workload, log_n, blowup, queries, world):
     return {(20, 32, 50): "", (22, 32, 50): "config4_", (24, 16, 100): "config5_"}.get((log_n, blowup, queries))
 
 
-def pmc_row(kernel):
-    """Row of `kernel` in the newest committed PMC summary of this run's workload (profiles/r<N>_[config<k>_]pmc_per_kernel.csv) -- or
-    (None, reason) when there is none, when it carries no stamp, or when its stamp (digest of distaff_amd/csrc at the time of the rocprofv3
-    passes) differs from the sources of this run.  Kernel names are compared without blanks and with template booleans as 0 / 1 (the
-    library's event names print them so)."""
+def _pmc_summary():
+    """(rows, source) of the newest committed PMC summary of this run's workload (profiles/r<N>_[config<k>_]pmc_per_kernel.csv, newest = largest
+    round NUMBER) -- or (None, reason) when there is none, when it carries no stamp, or when its stamp (digest of distaff_amd/csrc at the time
+    of the rocprofv3 passes) differs from the sources of this run."""
     import csv
     import glob
     import re
     if PMC_WORKLOAD["tag"] is None:
         return None, "no counter passes exist for this workload"
-    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_kernel.csv"))
-                   if re.fullmatch(r"r\d+_%spmc_per_kernel\.csv" % PMC_WORKLOAD["tag"], os.path.basename(f)))
+    pat = re.compile(r"r(\d+)_%spmc_per_kernel\.csv" % re.escape(PMC_WORKLOAD["tag"]))
+    files = sorted((int(pat.fullmatch(os.path.basename(f)).group(1)), f) for f in glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_per_kernel.csv"))
+                   if pat.fullmatch(os.path.basename(f)))
     if not files:
         return None, "no PMC summary of this workload under profiles/"
-    meta_path = files[-1].replace("_pmc_per_kernel.csv", "_meta.json")
+    newest = files[-1][1]
+    meta_path = newest.replace("_pmc_per_kernel.csv", "_meta.json")
     if not os.path.exists(meta_path):
-        return None, os.path.basename(files[-1]) + " carries no stamp"
+        return None, os.path.basename(newest) + " carries no stamp"
     meta = json.load(open(meta_path))
     if meta.get("csrc_sha16") != csrc_digest():
-        return None, "%s was taken on kernel sources %s, this run is %s: refused" % (os.path.basename(files[-1]), meta.get("csrc_sha16"), csrc_digest())
-
-    def norm(name):
-        import re
-        name = name.replace("void ", "").replace(" ", "").replace("false", "0").replace("true", "1")
-        return re.sub(r"(\d+)u\b", r"\1", re.sub(r"\(unsignedint\)(\d+)", r"\1", name))       # unsigned template arguments: 240u / (unsigned int)240
-    with open(files[-1], newline="") as fh:
-        for row in csv.DictReader(fh):
-            if norm(row["kernel"]).startswith(norm(kernel)):
-                return row, "%s (git %s)" % (os.path.basename(files[-1]), str(meta.get("git_head"))[:10])
-    return None, "kernel not in " + os.path.basename(files[-1])
+        return None, "%s was taken on kernel sources %s, this run is %s: refused" % (os.path.basename(newest), meta.get("csrc_sha16"), csrc_digest())
+    with open(newest, newline="") as fh:
+        return list(csv.DictReader(fh)), "%s (git %s)" % (os.path.basename(newest), str(meta.get("git_head"))[:10])
 
 
-VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4        # wave-instructions per second: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz
+def _pmc_norm(name):
+    import re
+    name = name.replace("void ", "").replace(" ", "").replace("false", "0").replace("true", "1")
+    return re.sub(r"(\d+)u\b", r"\1", re.sub(r"\(unsignedint\)(\d+)", r"\1", name))       # unsigned template arguments: 240u / (unsigned int)240
+
+
+def pmc_rows(kernel):
+    """EVERY row of the summary whose kernel name starts with `kernel` (names compared without blanks, template booleans as 0 / 1: the
+    library's event names print them so).  The library names a launch by its function, not by its template instance, so one event name can
+    cover several instances (lincomb_kernel<2> and <4>, the pass kernels of different tile shapes): a per-launch figure of the NAME is the
+    call-weighted mean over its instances -- taking the first matching row priced every launch as the most frequent instance and produced
+    issue fractions above 1."""
+    rows, source = _pmc_summary()
+    if rows is None:
+        return [], source
+    hit = [r for r in rows if _pmc_norm(r["kernel"]).startswith(_pmc_norm(kernel))]
+    # "ntt_pass_a" must not swallow a longer function name that merely starts with it: the next character is '<', '(' or the end
+    hit = [r for r in hit if _pmc_norm(r["kernel"])[len(_pmc_norm(kernel)):][:1] in ("", "<", "(")] or hit
+    return hit, (source if hit else "kernel not in " + source.split(" ")[0])
+
+
+def pmc_row(kernel):
+    """One row for `kernel`: the call-weighted mean of the numeric columns over its template instances (see pmc_rows)."""
+    rows, source = pmc_rows(kernel)
+    if not rows:
+        return None, source
+    if len(rows) == 1:
+        return rows[0], source
+    calls = [float(r.get("calls") or 1) for r in rows]
+    out = {"kernel": kernel, "calls": str(int(sum(calls))), "instances": len(rows)}
+    for key in rows[0]:
+        if key in ("kernel", "calls"):
+            continue
+        try:
+            out[key] = repr(sum(c * float(r[key]) for c, r in zip(calls, rows)) / sum(calls))
+        except (TypeError, ValueError):
+            pass
+    for key in ("fetch_bytes_per_launch_raw", "fetch_bytes_per_launch_x2", "write_bytes_per_launch_raw"):
+        if key in out:
+            out[key] = str(int(float(out[key])))
+    return out, source + " (%d template instances, call-weighted)" % len(rows)
+
+
+# wave-instructions per second: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 4 cycles at 2.4 GHz.  The 4 cycles are MEASURED for the
+# integer instructions this path is made of (profiles/r6_issue_slots.txt: v_add_co / v_addc_co with SGPR carries, v_cndmask on an SGPR mask,
+# v_xor / v_alignbit each reach 0.95 - 0.99 of one wave-instruction per 4 cycles and SIMD; v_mad_u64_u32 takes 1.41 such slots); the guide's
+# 2-cycle figure is for v_fma_f32 and does not apply to them.
+VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4
 
 
 def valu_issue(stats, proof_ms, steps):
     """Share of the VALU issue slots the kernels of one proof fill: SQ_INSTS_VALU per launch (committed, stamped PMC summary) x the
     launches of this run, against 1024 SIMDs x 2.4 GHz / 4 cycles.  `stats`: {kernel: {"launches", "ms"}} over `steps` proofs."""
-    per_kernel, total, missing = {}, 0.0, []
+    per_kernel, total, missing, refused = {}, 0.0, [], []
     for name, st in stats.items():
         row, _ = pmc_row(name)
         if row is None or not row.get("SQ_INSTS_VALU"):
@@ -129,13 +189,17 @@ def valu_issue(stats, proof_ms, steps):
         insts = float(row["SQ_INSTS_VALU"]) * st["launches"]
         total += insts
         if st["ms"] / steps >= 0.5:
-            per_kernel[name] = round(insts / (st["ms"] * 1e-3) / VALU_ISSUE_PEAK, 4)
+            frac = insts / (st["ms"] * 1e-3) / VALU_ISSUE_PEAK
+            # a fraction above 1 is an accounting error (instruction counts of another launch mix than this run's), never a measurement
+            per_kernel[name] = round(frac, 4) if frac <= 1.02 else None
+            if frac > 1.02:
+                refused.append("%s: %.3f" % (name, frac))
     if total == 0:
         return None
     return {"unit": "wave64 VALU instructions/s", "peak": VALU_ISSUE_PEAK, "proof_achieved": total / steps / (proof_ms * 1e-3),
             "proof_frac": round(total / steps / (proof_ms * 1e-3) / VALU_ISSUE_PEAK, 4), "kernel_frac": per_kernel,
-            "not_counted": missing, "note": "instruction counts per launch from the stamped rocprofv3 summary, launch times of this run; "
-            "the SQ_INSTS_VALU of a kernel name is the average over its launches of a proof, so kernels whose launches differ in size are exact for the whole proof only"}
+            "not_counted": missing, "refused_above_1": refused, "note": "instruction counts per launch from the stamped rocprofv3 summary, launch times of this run; "
+            "the SQ_INSTS_VALU of a kernel name is the call-weighted average over its template instances and launches of a proof (pmc_rows), so kernels whose launches differ in size are exact for the whole proof only"}
 
 
 
@@ -189,6 +253,7 @@ def kernel_rooflines(stats, steps, default_workload, top=5):
         valu = None
         if row is not None and row.get("SQ_INSTS_VALU"):
             valu = round(float(row["SQ_INSTS_VALU"]) / (per_launch_ms * 1e-3) / VALU_ISSUE_PEAK, 4)
+            valu = valu if valu <= 1.02 else None
         rows.append({"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "traffic_over_algorithmic": None if traffic is None else round(traffic / per_launch_bytes, 2), "traffic_source": source,
                      "valu_issue_frac": valu, "ms_per_step": round(st["ms"] / steps, 3), "launches_per_step": st["launches"] / steps,
@@ -545,6 +610,7 @@ def run(args):
     t0 = time.perf_counter()
     phase_sum = [0.0] * 9
     stage_sum = {}
+    exchange_sum = {}
     step_ms = []
     for _ in range(args.steps):
         ts = time.perf_counter()
@@ -556,6 +622,9 @@ def run(args):
         if stage_of is not None:
             for k, v in stage_of().items():
                 stage_sum[k] = stage_sum.get(k, 0.0) + v
+        if c_orchestration:
+            for k, v in ctx.shard_exchange_ms().items():
+                exchange_sum[k] = exchange_sum.get(k, 0.0) + v
     barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
@@ -696,6 +765,8 @@ def run(args):
         "proof_bytes": len(proof),
         "library": dict(lib_ident, calibration_note=calibration_note),
         "shard_stage_ms_rank0": {k: round(v / args.steps, 3) for k, v in stage_sum.items()} or None,
+        # enqueue -> completion of rank 0's collectives per kind and proof, from events on the streams they were queued on (dst_shard_exchange_ms)
+        "exchange_ms_rank0": {k: round(v / args.steps, 3) for k, v in exchange_sum.items()} or None,
         "roofline": roofline,
         "roofline_transform": roofline_transform,
         "rooflines": rooflines,

@@ -101,6 +101,8 @@ static void free_all(dst_ctx* c) {
     if (c->d_status) hipFree(c->d_status);
     if (c->h_stage) hipHostFree(c->h_stage);
     for (hipEvent_t e : c->ph_ev) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : c->sh_ev) if (e) hipEventDestroy(e);
+    for (auto& ce : c->coll_ev) { hipEventDestroy(ce.e0); hipEventDestroy(ce.e1); }
     if (c->stream) hipStreamDestroy(c->stream);
 }
 
@@ -673,7 +675,7 @@ static int compose_impl(dst_ctx* c, const uint8_t* draws_bytes, uint8_t* trace_a
     HIP_TRY(c, hipMemcpyAsync(c->h_stage + HS_DEEP + HS_DEEP_HALF, d_tz2, W * 16, hipMemcpyDeviceToHost, c->stream));
     c->deep_pending = true;
     if (wait) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        CTX_SYNC(c, "the DEEP composition");
         HIP_TRY(c, hipGetLastError());
         finish_deep_values(c);
         memcpy(trace_at_z1, c->deep_z1.data(), W * 16);

@@ -2,7 +2,9 @@
 #include <dlfcn.h>
 #include <functional>
 #include <condition_variable>
+#include <chrono>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include "comm.h"
 
@@ -11,7 +13,7 @@
 namespace {
 typedef struct ncclComm* ncclComm_t;
 typedef struct { char internal[128]; } ncclUniqueId;
-enum { ncclSuccess = 0, ncclUint8 = 1 };
+enum { ncclSuccess = 0, ncclInProgress = 7, ncclUint8 = 1 };
 struct RcclApi {
     void* handle = nullptr;
     int (*GetUniqueId)(ncclUniqueId*) = nullptr;
@@ -26,6 +28,8 @@ struct RcclApi {
     int (*CommCuDevice)(ncclComm_t, int*) = nullptr;
     int (*CommUserRank)(ncclComm_t, int*) = nullptr;
     int (*GetVersion)(int*) = nullptr;
+    int (*CommAbort)(ncclComm_t) = nullptr;
+    int (*CommGetAsyncError)(ncclComm_t, int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     std::string error;
 };
@@ -47,10 +51,15 @@ RcclApi* rccl_api() {
         api.GroupStart = (int (*)())sym("ncclGroupStart");
         api.GroupEnd = (int (*)())sym("ncclGroupEnd");
         api.GetErrorString = (const char* (*)(int))sym("ncclGetErrorString");
-        api.CommCount = (int (*)(ncclComm_t, int*))sym("ncclCommCount");
-        api.CommCuDevice = (int (*)(ncclComm_t, int*))sym("ncclCommCuDevice");
-        api.CommUserRank = (int (*)(ncclComm_t, int*))sym("ncclCommUserRank");
-        api.GetVersion = (int (*)(int*))sym("ncclGetVersion");
+        // containment: without these two a stalled collective could not be ended, so they are required like the collectives themselves
+        api.CommAbort = (int (*)(ncclComm_t))sym("ncclCommAbort");
+        api.CommGetAsyncError = (int (*)(ncclComm_t, int*))sym("ncclCommGetAsyncError");
+        // diagnostics only (dst_comm_describe): a librccl without one of them keeps the transport, the field stays 0
+        auto opt = [&](const char* s) { return dlsym(api.handle, s); };
+        api.CommCount = (int (*)(ncclComm_t, int*))opt("ncclCommCount");
+        api.CommCuDevice = (int (*)(ncclComm_t, int*))opt("ncclCommCuDevice");
+        api.CommUserRank = (int (*)(ncclComm_t, int*))opt("ncclCommUserRank");
+        api.GetVersion = (int (*)(int*))opt("ncclGetVersion");
     });
     return &api;
 }
@@ -61,7 +70,7 @@ struct RcclComm : dst_comm {
     int device = 0;
     hipStream_t own_stream = nullptr;      // host-value gathers
     uint8_t* staging = nullptr; size_t staging_bytes = 0;
-    int fail(int r, const char* what) { err = std::string(what) + ": " + (api && api->GetErrorString ? api->GetErrorString(r) : "RCCL error"); return DST_ERR_HIP; }
+    int fail(int r, const char* what) { err = std::string(what) + ": " + (api && api->GetErrorString ? api->GetErrorString(r) : "RCCL error"); return DST_ERR_COMM; }
     ~RcclComm() override {
         if (comm && api) api->CommDestroy(comm);
         if (staging) hipFree(staging);
@@ -72,11 +81,21 @@ struct RcclComm : dst_comm {
     void fill_info(dst_comm_info* o) const override {
         int v = 0;
         // what RCCL itself says about this communicator: the number of ranks it connected, this rank's index and device
-        if (api->CommCount(comm, &v) == ncclSuccess) o->rccl_ranks = (uint32_t)v;
-        if (api->CommUserRank(comm, &v) == ncclSuccess) o->rccl_rank = (uint32_t)v;
-        if (api->CommCuDevice(comm, &v) == ncclSuccess) o->device = v;
         if (api->GetVersion && api->GetVersion(&v) == ncclSuccess) o->rccl_version = (uint32_t)v;
+        if (!comm) return;                                  // aborted
+        if (api->CommCount && api->CommCount(comm, &v) == ncclSuccess) o->rccl_ranks = (uint32_t)v;
+        if (api->CommUserRank && api->CommUserRank(comm, &v) == ncclSuccess) o->rccl_rank = (uint32_t)v;
+        if (api->CommCuDevice && api->CommCuDevice(comm, &v) == ncclSuccess) o->device = v;
     }
+    // what RCCL's own watchdog knows (a peer process that died, a failed transport): looked at while the host polls a stream
+    int poll_async() override {
+        int state = ncclSuccess;
+        if (!comm || api->CommGetAsyncError(comm, &state) != ncclSuccess || state == ncclSuccess || state == ncclInProgress) return DST_OK;
+        err = std::string("RCCL reported an asynchronous error: ") + (api->GetErrorString ? api->GetErrorString(state) : "?");
+        return DST_ERR_COMM;
+    }
+    // ncclCommAbort ends the communicator's kernels wherever they wait and frees it: the streams drain, nothing of this rank is left behind
+    void abort_impl() override { if (comm) { api->CommAbort(comm); comm = nullptr; } }
     int all_gather_impl(const void* send, void* recv, size_t bytes, hipStream_t stream) override {
         int r = api->AllGather(send, recv, bytes, ncclUint8, comm, stream);          // in place when send == recv + rank * bytes
         if (r != ncclSuccess) return fail(r, "ncclAllGather");
@@ -103,10 +122,8 @@ struct RcclComm : dst_comm {
         if (hipMemcpyAsync(staging, send, bytes, hipMemcpyHostToDevice, own_stream) != hipSuccess) { err = "all_gather_host: upload failed"; return DST_ERR_HIP; }
         int r = api->AllGather(staging, staging + bytes, bytes, ncclUint8, comm, own_stream);
         if (r != ncclSuccess) return fail(r, "ncclAllGather");
-        if (hipMemcpyAsync(recv, staging + bytes, bytes * world, hipMemcpyDeviceToHost, own_stream) != hipSuccess || hipStreamSynchronize(own_stream) != hipSuccess) {
-            err = "all_gather_host: download failed"; return DST_ERR_HIP;
-        }
-        return DST_OK;
+        if (hipMemcpyAsync(recv, staging + bytes, bytes * world, hipMemcpyDeviceToHost, own_stream) != hipSuccess) { err = "all_gather_host: download failed"; return DST_ERR_HIP; }
+        return wait_stream(own_stream, "the all-gather of host values");
     }
 };
 
@@ -119,14 +136,21 @@ struct LocalShared {
     std::vector<int> device;                          // device of every rank's thread (-1 until its first device collective)
     uint32_t refs;
     explicit LocalShared(uint32_t w) : world(w), ptr(w, nullptr), device(w, -1), refs(w) {}
-    bool barrier() {                                   // false: another rank gave up (dst_comm_destroy while peers wait)
+    // false: another rank gave up (dst_comm_destroy / abort while peers wait) or did not arrive within `limit_s` seconds (<= 0: no limit);
+    // *timed_out tells the two apart.  Whoever times out marks the group aborted: every peer leaves its barrier with an error too.
+    bool barrier(double limit_s, bool* timed_out) {
         std::unique_lock<std::mutex> lk(mu);
+        *timed_out = false;
         if (aborted) return false;
         const uint64_t gen = generation;
         if (++arrived == world) { arrived = 0; generation++; cv.notify_all(); return true; }
-        cv.wait(lk, [&] { return generation != gen || aborted; });
-        return !aborted;
+        auto done = [&] { return generation != gen || aborted; };
+        if (limit_s > 0) {
+            if (!cv.wait_for(lk, std::chrono::duration<double>(limit_s), done)) { *timed_out = true; aborted = true; cv.notify_all(); return false; }
+        } else cv.wait(lk, done);
+        return generation != gen;                      // the generation moved on: the barrier completed (even if someone aborted right after)
     }
+    void abort() { { std::lock_guard<std::mutex> lk(mu); aborted = true; } cv.notify_all(); }
 };
 struct LocalComm : dst_comm {
     LocalShared* sh = nullptr;
@@ -136,7 +160,13 @@ struct LocalComm : dst_comm {
         sh->cv.notify_all();
         if (last) delete sh;
     }
-    int broken() { err = "local communicator: a peer rank left the collective"; return DST_ERR_STATE; }
+    int broken(bool timed_out) {
+        dead = true;
+        err = timed_out ? "local communicator: a peer rank did not reach " + last_collective() + " within " + std::to_string(timeout_s) + " s; the group was aborted"
+                        : "local communicator: a peer rank left the group (aborted or destroyed) at " + last_collective();
+        return DST_ERR_COMM;
+    }
+    void abort_impl() override { sh->abort(); }
     int transport_kind() const override { return DST_COMM_LOCAL; }
     int my_device = -1;
     bool peers_checked = false;
@@ -159,16 +189,18 @@ struct LocalComm : dst_comm {
         }
     }
     int exchange(const void* send, hipStream_t stream, bool host, const std::function<hipError_t(uint32_t peer, const void* peer_send)>& take) {
-        if (!host && hipStreamSynchronize(stream) != hipSuccess) { err = "local collective: stream synchronisation failed"; return DST_ERR_HIP; }
+        // any failure of this rank ends the group: its peers are waiting in the barriers below
+        if (!host) { const int w = wait_stream(stream, "the work queued before a collective of the in-process transport"); if (w) { const std::string why = err; abort(why); return w; } }
         if (!host && my_device < 0) { if (hipGetDevice(&my_device) != hipSuccess) my_device = -1; sh->device[rank] = my_device; }
         sh->ptr[rank] = send;
-        if (!sh->barrier()) return broken();
+        bool late = false;
+        if (!sh->barrier(timeout_s, &late)) return broken(late);
         if (!host && !peers_checked && my_device >= 0) enable_peer_access();      // every rank has published its device before the barrier
         hipError_t e = hipSuccess;
         for (uint32_t p = 0; p < world && e == hipSuccess; p++) e = take(p, sh->ptr[p]);
-        if (!host && e == hipSuccess) e = hipStreamSynchronize(stream);
-        if (!sh->barrier()) return broken();           // every rank has read every send buffer
-        if (e != hipSuccess) { err = std::string("local collective: ") + hipGetErrorString(e); return DST_ERR_HIP; }
+        if (e != hipSuccess) { abort(std::string("local collective: ") + hipGetErrorString(e)); return DST_ERR_HIP; }
+        if (!host) { const int w = wait_stream(stream, "the copies of a collective of the in-process transport"); if (w) { const std::string why = err; abort(why); return w; } }
+        if (!sh->barrier(timeout_s, &late)) return broken(late);           // every rank has read every send buffer
         return DST_OK;
     }
     int all_gather_impl(const void* send, void* recv, size_t bytes, hipStream_t stream) override {
@@ -189,10 +221,12 @@ struct LocalComm : dst_comm {
 typedef int (*dst_comm_fn)(void* user, int kind, const void* send, void* recv, size_t bytes);
 struct CallbackComm : dst_comm {
     dst_comm_fn fn = nullptr; void* user = nullptr;
+    // The host's channel is the host's to bound (a torch.distributed group has its timeout, MPI its own): a callback that reports failure --
+    // a peer that stopped answering included -- kills this communicator, and the rank returns DST_ERR_COMM from dst_prove_sharded.
     int call(int kind, const void* send, void* recv, size_t bytes, hipStream_t stream) {
-        if (kind != 2 && hipStreamSynchronize(stream) != hipSuccess) { err = "callback collective: stream synchronisation failed"; return DST_ERR_HIP; }
+        if (kind != 2) { const int w = wait_stream(stream, "the work queued before a callback collective"); if (w) return w; }
         const int r = fn(user, kind, send, recv, bytes);
-        if (r) { err = "the host's collective callback returned " + std::to_string(r); return DST_ERR_STATE; }
+        if (r) { dead = true; err = "the host's collective callback returned " + std::to_string(r) + " at " + last_collective(); return DST_ERR_COMM; }
         return DST_OK;
     }
     int transport_kind() const override { return DST_COMM_CALLBACKS; }
@@ -202,6 +236,71 @@ struct CallbackComm : dst_comm {
 };
 }  // namespace
 
+#if defined(DISTAFF_TEST_HOOKS) && defined(__HIPCC__)
+// one wavefront that holds its stream until the host releases it (or 30 s have passed: the device is never left hanging)
+__global__ void comm_stall_kernel(uint32_t* release, unsigned long long max_ticks) {
+    const unsigned long long t0 = wall_clock64();                  // constant-rate counter (100 MHz)
+    while (__hip_atomic_load(release, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) == 0u && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(64);
+}
+void dst_comm::test_stall(hipStream_t stream) {
+    if (stall_at < 0 || (int64_t)issued != stall_at) return;
+    if (!stall_flag) { if (hipHostMalloc((void**)&stall_flag, 64, hipHostMallocDefault) != hipSuccess) { stall_flag = nullptr; return; } *stall_flag = 0u; }
+    hipLaunchKernelGGL(comm_stall_kernel, dim3(1), dim3(64), 0, stream, stall_flag, 30ull * 100000000ull);
+}
+// "k" (every rank of the process) or "k@r" (rank r only: thread-ranks share the environment)
+static int64_t comm_stall_env(uint32_t rank) {
+    const char* e = getenv("DISTAFF_TEST_STALL_COLLECTIVE");
+    if (!e || !e[0]) return -1;
+    const char* at = strchr(e, '@');
+    if (at && (uint32_t)atoll(at + 1) != rank) return -1;
+    return atoll(e);
+}
+#else
+void dst_comm::test_stall(hipStream_t) {}
+static int64_t comm_stall_env(uint32_t) { return -1; }
+#endif
+
+std::string dst_comm::last_collective() const {
+    if (!issued) return "the first collective (none issued yet)";
+    const char* k = last_kind == 'G' ? "all-gather" : last_kind == 'A' ? "all-to-all" : "all-gather of host values";
+    return "collective #" + std::to_string(issued - 1) + " (" + k + ", " + std::to_string(last_bytes) + " bytes per rank)";
+}
+
+// Bounded wait for everything queued on `stream` so far.  hipStreamSynchronize cannot be interrupted; the host polls instead (the runtime's
+// own wait spins too), and every 64 queries looks at the transport's asynchronous error state and at the clock.
+int dst_comm::wait_stream(hipStream_t stream, const char* what) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 1;; spins++) {
+        const hipError_t e = hipStreamQuery(stream);
+        if (e == hipSuccess) return DST_OK;
+        (void)hipGetLastError();                           // "not ready" is not an error of this call site
+        if (e != hipErrorNotReady) { err = std::string("waiting for ") + what + ": " + hipGetErrorString(e); return DST_ERR_HIP; }
+        if (spins & 63u) continue;
+        if (poll_async() != DST_OK) { const std::string why = err + " (while waiting for " + what + ", last issued: " + last_collective() + ")"; abort(why); return DST_ERR_COMM; }
+        const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (timeout_s > 0 && waited > timeout_s) {
+            char lim[32]; snprintf(lim, sizeof lim, "%.1f", timeout_s);
+            abort(std::string("no completion within ") + lim + " s while waiting for " + what + "; last issued: " + last_collective() + "; the communicator was aborted");
+            // the abort ends the transport's kernels: give the stream a moment to drain so that the caller's buffers are quiet when it returns
+            for (int i = 0; i < 2000 && hipStreamQuery(stream) == hipErrorNotReady; i++) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+            (void)hipGetLastError();
+            return DST_ERR_COMM;
+        }
+        if (waited > 0.002) std::this_thread::yield();      // a long wait (a peer is behind): let the host's other threads run
+    }
+}
+
+int ctx_sync(dst_ctx* c, const char* what) {
+    if (c->wait_comm) {
+        const int r = c->wait_comm->wait_stream(c->stream, what);
+        if (r) c->err = std::string("waiting for ") + what + ": " + c->wait_comm->err;
+        return r;
+    }
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return DST_OK;
+}
+
+static double comm_timeout_env() { const char* e = getenv("DISTAFF_COMM_TIMEOUT_S"); if (!e || !e[0]) return 60.0; char* end = nullptr; const double v = strtod(e, &end); return end == e ? 60.0 : v; }
 static bool shard_debug_env() { const char* e = getenv("DISTAFF_SHARD_DEBUG"); return e && e[0] && e[0] != '0'; }
 static thread_local std::string g_comm_error;      // errors before a communicator exists, per calling thread (ranks may be threads)
 
@@ -231,7 +330,7 @@ int dst_comm_init(const uint8_t id[128], uint32_t rank, uint32_t world, int devi
     int r = api->CommInitRank(&c->comm, (int)world, u, (int)rank);
     if (r != ncclSuccess) { g_comm_error = std::string("ncclCommInitRank: ") + api->GetErrorString(r); c->comm = nullptr; delete c; return DST_ERR_HIP; }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { g_comm_error = "dst_comm_init: stream creation failed"; delete c; return DST_ERR_HIP; }
-    c->tracing = shard_debug_env();
+    c->tracing = shard_debug_env(); c->timeout_s = comm_timeout_env(); c->stall_at = comm_stall_env(c->rank);
     *out = c;
     return DST_OK;
 }
@@ -239,7 +338,7 @@ int dst_comm_init(const uint8_t id[128], uint32_t rank, uint32_t world, int devi
 int dst_comm_init_local(uint32_t world, dst_comm** out) {
     if (!out || world == 0 || world > 64) { g_comm_error = "dst_comm_init_local: bad arguments"; return DST_ERR_ARG; }
     LocalShared* sh = new LocalShared(world);
-    for (uint32_t r = 0; r < world; r++) { LocalComm* c = new LocalComm(); c->rank = r; c->world = world; c->sh = sh; c->tracing = shard_debug_env(); out[r] = c; }
+    for (uint32_t r = 0; r < world; r++) { LocalComm* c = new LocalComm(); c->rank = r; c->world = world; c->sh = sh; c->tracing = shard_debug_env(); c->timeout_s = comm_timeout_env(); c->stall_at = comm_stall_env(c->rank); out[r] = c; }
     return DST_OK;
 }
 
@@ -247,12 +346,18 @@ int dst_comm_init_callbacks(uint32_t rank, uint32_t world, dst_comm_fn fn, void*
     if (!out || !fn || world == 0 || rank >= world) { g_comm_error = "dst_comm_init_callbacks: bad arguments"; return DST_ERR_ARG; }
     CallbackComm* c = new CallbackComm();
     c->rank = rank; c->world = world; c->fn = fn; c->user = user;
-    c->tracing = shard_debug_env();
+    c->tracing = shard_debug_env(); c->timeout_s = comm_timeout_env(); c->stall_at = comm_stall_env(c->rank);
     *out = c;
     return DST_OK;
 }
 
 void dst_comm_destroy(dst_comm* comm) { delete comm; }
+
+// limit of every host wait behind a collective of this communicator, seconds (default 60, or DISTAFF_COMM_TIMEOUT_S at creation); <= 0: none
+int dst_comm_set_timeout(dst_comm* comm, double seconds) { if (!comm) return DST_ERR_ARG; comm->timeout_s = seconds; return DST_OK; }
+// Gives the communicator up from the host's side (a watchdog that learnt of a dead peer, a shutdown): RCCL's kernels end, in-process peers
+// leave their barriers, every later collective of this handle returns DST_ERR_COMM.  The handle still has to be destroyed.
+int dst_comm_abort(dst_comm* comm) { if (!comm) return DST_ERR_ARG; comm->abort("the host aborted the communicator (dst_comm_abort)"); return DST_OK; }
 
 int dst_comm_describe(const dst_comm* comm, dst_comm_info* out) {
     if (!comm || !out) return DST_ERR_ARG;

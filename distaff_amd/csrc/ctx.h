@@ -249,6 +249,14 @@ struct dst_ctx {
     double phase_ms[9] = {0};
     double shard_ms[2] = {0, 0};           // dst_prove_sharded: host milliseconds inside the transport's calls / waiting for tree roots
     uint32_t shard_trees = 0;              // tree exchanges of the last sharded proof
+    // dst_prove_sharded: the communicator whose collectives may sit on this context's streams.  While it is set, every host wait of the
+    // prover is the communicator's bounded poll (ctx_sync below, comm.h) instead of hipStreamSynchronize
+    struct dst_comm* wait_comm = nullptr;
+    hipEvent_t sh_ev[8] = {nullptr};       // phase boundaries of dst_prove_sharded on the stream (created on first use)
+    struct CollEv { hipEvent_t e0, e1; int kind; };
+    std::vector<CollEv> coll_ev;           // events around the collectives of the last sharded proof (the first coll_used of them)
+    size_t coll_used = 0;
+    double exchange_ms[8] = {0};           // dst_shard_exchange_ms
 
     // optional per-kernel timing with HIP events recorded on `stream` (dst_set_profiling / dst_kernel_stats)
     int profile = 0;                       // dst_set_profiling: 0 off, 1 every kernel launch, 2 only the heavy kernels (NTT passes, constraint kernel, leaf hashing)
@@ -283,6 +291,10 @@ struct KScope {
             return DST_ERR_HIP;                                                                     \
         }                                                                                           \
     } while (0)
+
+// host wait for the context's stream: bounded while a communicator is attached (comm.hip), hipStreamSynchronize otherwise
+int ctx_sync(dst_ctx* c, const char* what);
+#define CTX_SYNC(ctx, what) do { const int _r = ctx_sync((ctx), (what)); if (_r) return _r; } while (0)
 
 // ---- kernel launchers (kernels_*.hip) ------------------------------------------------------------------------------------
 // NTT / LDE

@@ -53,28 +53,34 @@ static const u128 HF_INV_ALPHA = (((u128)0xAAAAAAAAAAAAAAAAull) << 64) | 0xAAAA8
 
 // x -> x^INV_ALPHA (the inverse of cubing) on the four state elements at once.  The steps of a trace form one dependency chain through
 // this function, so its latency is the cost of the generator: the four lanes advance in lock-step (four independent multiplies in flight)
-// along an addition chain for the exponent's bit pattern -- INV_ALPHA = (10)^40 10001100 (10)^20 10101011 in binary: with
-// a_k = x^((10)^k), a_2k = a_k^(4^k) * a_k gives a_40 and a_20 in 9 multiplies; 143 squarings + 13 multiplies per lane against the
-// 127 + 64 of square-and-multiply.
+// along an addition chain for the exponent's bit pattern -- INV_ALPHA = (10)^40 10001100 (10)^16 10101011 in binary (128 bits): with
+// a_k = x^((10)^k), a_2k = a_k^(4^k) * a_k gives a_16 and a_40 in 6 multiplies; 127 squarings + 12 multiplies per lane against the
+// 127 + 64 of square-and-multiply.  (Round 5's chain ended in (10)^20 10101011 -- a 136-bit exponent that happens to be congruent to
+// INV_ALPHA modulo p - 1, so its results were the same; tests/test_host_logic.py now asserts the exponent the chain implements.)
 struct Lanes { u128 v[4]; };
-inline void l_sqr(Lanes& r, int n) { for (int k = 0; k < n; k++) for (int l = 0; l < 4; l++) r.v[l] = hf_sqr<true>(r.v[l]); }
-inline void l_mul(Lanes& r, const Lanes& b) { for (int l = 0; l < 4; l++) r.v[l] = hf_mul<true>(r.v[l], b.v[l]); }
+#if defined(HF_COUNT_OPS)          // tests/hostfield: the chain's operation counts pin the exponent it implements (127 squarings: below 2^128)
+static int hf_count_sqr = 0, hf_count_mul = 0;
+#define HF_COUNT(c, k) ((c) += (k))
+#else
+#define HF_COUNT(c, k) ((void)0)
+#endif
+inline void l_sqr(Lanes& r, int n) { HF_COUNT(hf_count_sqr, n); for (int k = 0; k < n; k++) for (int l = 0; l < 4; l++) r.v[l] = hf_sqr<true>(r.v[l]); }
+inline void l_mul(Lanes& r, const Lanes& b) { HF_COUNT(hf_count_mul, 1); for (int l = 0; l < 4; l++) r.v[l] = hf_mul<true>(r.v[l], b.v[l]); }
 inline void inv_alpha4(u128 s[4]) {
-    Lanes x, a1, a2, a4, a8, a16, a20, r;
+    Lanes x, a1, a2, a4, a8, a16, r;
     for (int l = 0; l < 4; l++) x.v[l] = s[l];
     a1 = x;    l_sqr(a1, 1);                             // x^(10b)
     a2 = a1;   l_sqr(a2, 2);   l_mul(a2, a1);            // (10)^2
     a4 = a2;   l_sqr(a4, 4);   l_mul(a4, a2);            // (10)^4
     a8 = a4;   l_sqr(a8, 8);   l_mul(a8, a4);            // (10)^8
     a16 = a8;  l_sqr(a16, 16); l_mul(a16, a8);           // (10)^16
-    a20 = a16; l_sqr(a20, 8);  l_mul(a20, a4);           // (10)^20
     r = a16;   l_sqr(r, 32);   l_mul(r, a16);            // (10)^32
     l_sqr(r, 16); l_mul(r, a8);                          // (10)^40
     l_sqr(r, 1); l_mul(r, x);                            // 1
     l_sqr(r, 4); l_mul(r, x);                            // 0001
     l_sqr(r, 1); l_mul(r, x);                            // 1
     l_sqr(r, 2);                                         // 00
-    l_sqr(r, 40); l_mul(r, a20);                         // (10)^20
+    l_sqr(r, 32); l_mul(r, a16);                         // (10)^16
     l_sqr(r, 8); l_mul(r, a4); l_mul(r, x);              // 10101011 = (10)^4 + 1
     for (int l = 0; l < 4; l++) s[l] = r.v[l] >= FIELD_P ? r.v[l] - FIELD_P : r.v[l];          // the chain ran on values below 2^128: canonical now
 }

@@ -609,7 +609,7 @@ int k_fri_tail(dst_ctx* c, int first, uint8_t* roots_out) {
     a.fold.alpha = fe_zero(); a.fold.iota = c->iota; a.fold.quarter = c->four_inv;
     { KScope ks_(c, "fri_tail_kernel", 0.0); hipLaunchKernelGGL(fri_tail_kernel, dim3(1), dim3(FRI_TAIL_THREADS), 0, c->stream, a); }
     HIP_TRY(c, hipMemcpyAsync(roots_out, a.roots, (size_t)count * 32, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    CTX_SYNC(c, "the last FRI layers");
     HIP_TRY(c, hipGetLastError());
     return DST_OK;
 }
@@ -642,7 +642,7 @@ int k_pow(dst_ctx* c, const uint8_t seed[32], uint32_t grinding, uint64_t* nonce
         { KScope ks_(c, "pow_kernel", 0.0); hipLaunchKernelGGL(pow_kernel, dim3((unsigned)(batch / PT)), dim3(PT), 0, c->stream, (const uint32_t*)d_seed, base, grinding, d_best); }
         unsigned long long best = 0;
         HIP_TRY(c, hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        CTX_SYNC(c, "the proof-of-work search");
         if (best != ~0ull) { *nonce = best; return DST_OK; }
         if (base > ((uint64_t)1 << 40)) { c->err = "proof-of-work search exhausted"; return DST_ERR_ARG; }
     }

@@ -169,6 +169,7 @@ static int shard_combine_parts(dst_ctx* c, int parts) {
             k_add(c, c->cpoly, ip, D);
             k_add(c, c->cpoly, fp, D);
         }
+        if (c->wait_comm && c->sh_ev[4]) (void)hipEventRecord(c->sh_ev[4], c->stream);      // dst_prove_sharded: end of the combination (phase 3 | 4)
         k_lde_fold8(c, c->cpoly, c->cevals);
         if (c->Bc >= 4) {                                   // with two cosets per rank the leaves themselves are the boundary (see dst_shard_export)
             k_constraint_level1(c);
@@ -273,11 +274,11 @@ int dst_shard_import(dst_ctx* c, uint32_t what, uint32_t arg, const void* src, i
         c->ceval_inverted = false;                                  // dst_prove_sharded sets it after importing arrays it has inverse-transformed
         const size_t Q = c->Bc / (c->B / 8), blk = Q * c->n;        // gathered [G][V][Q][n] -> ceval [3][8][n], V = 3 (i, f, t) or 1 (t)
         const size_t V = dst_internal_boundary_by_evaluation(c) ? 3 : 1;
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        CTX_SYNC(c, "an imported tree");
         for (size_t g = 0; g < G; g++)
             for (size_t v = 0; v < V; v++)
                 HIP_TRY(c, hipMemcpyAsync(c->ceval + ((V == 3 ? v : 2) * 8 + g * Q) * c->n, (const fe*)c->gather_buf + (g * V + v) * blk, blk * 16, hipMemcpyDeviceToDevice, c->stream));
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        CTX_SYNC(c, "an imported tree");
         return DST_OK;
     }
     digest* upper = nullptr; size_t nb = 0;
@@ -290,7 +291,7 @@ int dst_shard_import(dst_ctx* c, uint32_t what, uint32_t arg, const void* src, i
     k_upper_tree(c, (const digest*)c->gather_buf, upper, nb, (uint32_t)G);
     uint8_t root[32];
     HIP_TRY(c, hipMemcpyAsync(root, upper + 1, 32, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    CTX_SYNC(c, "the imported constraint evaluations");
     HIP_TRY(c, hipGetLastError());
     if (what == SH_TRACE_TREE) memcpy(c->trace_root, root, 32);
     else if (what == SH_CONSTRAINT_TREE) memcpy(c->constraint_root, root, 32);
@@ -400,7 +401,7 @@ static int fri_replicated_tail(dst_ctx* c, const void* gathered, int src_is_devi
         if (rt) return rt;
         for (int i = d; i < L; i++) c->fri_roots[i].assign(rs.begin() + 32 * (i - d), rs.begin() + 32 * (i - d + 1));
     } else {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        CTX_SYNC(c, "the gathered FRI layer");
         HIP_TRY(c, hipGetLastError());
     }
     for (int i = d0; i < d; i++) c->fri_roots[i].assign(h_roots + 32 * (i - d0), h_roots + 32 * (i - d0 + 1));
@@ -601,7 +602,7 @@ static int gather_requests(dst_ctx* c, const OpenPlan& p, int me, bool everythin
     uint8_t* d_out = c->d_stage + idx_bytes;
     k_gather_pieces(c, (const uint64_t*)c->d_stage, addr.size(), d_out);
     if (total) HIP_TRY(c, hipMemcpyAsync(blob.data(), d_out, total, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    CTX_SYNC(c, "the openings");
     HIP_TRY(c, hipGetLastError());
     return DST_OK;
 }
@@ -696,6 +697,11 @@ int dst_shard_stage_ms(const dst_ctx* c, double out[3]) {
     return DST_OK;
 }
 
+int dst_shard_exchange_ms(const dst_ctx* c, double out[8]) {
+    if (!c || !out) return DST_ERR_ARG;
+    for (int i = 0; i < 8; i++) out[i] = c->exchange_ms[i];
+    return DST_OK;
+}
 int dst_shard_info(dst_ctx* c, uint64_t* op_count, uint32_t* num_fri_layers, uint32_t* stack_depth) {
     if (!c) return DST_ERR_ARG;
     if (op_count) *op_count = c->op_count;
@@ -739,6 +745,32 @@ struct Sharded {
     void local(const std::function<int()>& f) { if (rc == DST_OK) { rc = f(); } }           // (this file's functions sit in an extern "C" block: no member templates)
     // host time inside the transport's calls (an enqueue on a stream-ordered transport, the whole exchange on a blocking one)
     int timed(const std::function<int()>& f) { const double t = wall_ms_shard(); const int r = f(); c->shard_ms[0] += wall_ms_shard() - t; return r; }
+    // ... and, for a collective on device buffers, two events around it on the stream it is queued on: enqueue -> completion as the device
+    // saw it (on RCCL that includes the wait for the slowest peer), read once after the proof's last wait (dst_shard_exchange_ms).
+    // kind: index into dst_ctx::exchange_ms (0 coefficients, 1 tree all-to-all, 2 tree all-gather, 3 constraint evaluations, 4 FRI tail)
+    int coll_on(int kind, hipStream_t stream, const std::function<int()>& f) {
+        dst_ctx::CollEv* ev = nullptr;
+        if (c->coll_used < c->coll_ev.size()) ev = &c->coll_ev[c->coll_used];
+        else if (c->coll_ev.size() < 256) {
+            dst_ctx::CollEv n{nullptr, nullptr, 0};
+            if (hipEventCreate(&n.e0) == hipSuccess && hipEventCreate(&n.e1) == hipSuccess) { c->coll_ev.push_back(n); ev = &c->coll_ev.back(); }
+            else { if (n.e0) hipEventDestroy(n.e0); (void)hipGetLastError(); }
+        }
+        c->exchange_ms[6] += 1;
+        if (ev && hipEventRecord(ev->e0, stream) != hipSuccess) { (void)hipGetLastError(); ev = nullptr; }
+        const int r = timed(f);
+        if (ev && hipEventRecord(ev->e1, stream) == hipSuccess) { ev->kind = kind; c->coll_used++; }
+        return r;
+    }
+    // all-gather of host values: complete on return, host wall time
+    int coll_host(const std::function<int()>& f) { const double t = wall_ms_shard(); const int r = timed(f); c->exchange_ms[5] += wall_ms_shard() - t; c->exchange_ms[6] += 1; return r; }
+    void read_collective_events() {
+        for (size_t i = 0; i < c->coll_used; i++) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, c->coll_ev[i].e0, c->coll_ev[i].e1) == hipSuccess) { c->exchange_ms[c->coll_ev[i].kind] += ms; c->exchange_ms[7] += 1; }
+            else (void)hipGetLastError();
+        }
+    }
     void fail(int code, const std::string& msg) { if (rc == DST_OK) { rc = code; c->err = msg; } }
     // collective errors are not rank-local: the transport failed for everyone (or will hang for everyone)
     bool coll(int r, const char* what) { if (r != DST_OK) { if (rc == DST_OK) { rc = r; c->err = std::string(what) + ": " + comm->err; } agreed = agreed ? agreed : r; return false; } return true; }
@@ -798,19 +830,19 @@ void tree_exchange(Sharded& S, uint32_t what, uint32_t arg, uint8_t root[32], co
     if (!staged) S.fail(DST_ERR_HIP, "tree_exchange: staging of the status record failed");
     if (krange) {
         const size_t chunk = K / G;                              // boundary nodes per (sender, owner) pair
-        if (!S.coll(S.timed([&] { return comm->all_to_all(src, c->gather_buf, chunk * 32, c->stream); }), "tree_exchange")) return;
+        if (!S.coll(S.coll_on(1, c->stream, [&] { return comm->all_to_all(src, c->gather_buf, chunk * 32, c->stream); }), "tree_exchange")) return;
         digest* mid = upper + 2 * G;                             // this rank's subtree heap: mid[1] = its root, mid[K + kl*G + r] = boundary node of rank r at k = g*K/G + kl
         S.local([&]() -> int {
             k_upper_tree(c, (const digest*)c->gather_buf, mid, chunk, (uint32_t)G);
             HIP_TRY(c, hipMemcpyAsync(&recs[comm->rank].root, mid + 1, sizeof(digest), hipMemcpyDeviceToDevice, c->stream));
             return DST_OK;
         });
-        if (!S.coll(S.timed([&] { return comm->all_gather(recs + comm->rank, recs, sizeof(TreeRec), c->stream); }), "tree_exchange")) return;
+        if (!S.coll(S.coll_on(2, c->stream, [&] { return comm->all_gather(recs + comm->rank, recs, sizeof(TreeRec), c->stream); }), "tree_exchange")) return;
         S.local([&] { k_digests_from_records(c, recs, sizeof(TreeRec), upper + G, G); k_merkle_upper(c, upper, G); return DST_OK; });      // the top log2(G) levels, on every rank
     } else {
-        if (!S.coll(S.timed([&] { return comm->all_gather(src, c->gather_buf, K * 32, c->stream); }), "tree_exchange")) return;
+        if (!S.coll(S.coll_on(2, c->stream, [&] { return comm->all_gather(src, c->gather_buf, K * 32, c->stream); }), "tree_exchange")) return;
         S.local([&] { k_upper_tree(c, (const digest*)c->gather_buf, upper, K, (uint32_t)G); return DST_OK; });
-        if (!S.coll(S.timed([&] { return comm->all_gather(recs + comm->rank, recs, sizeof(TreeRec), c->stream); }), "tree_exchange")) return;
+        if (!S.coll(S.coll_on(2, c->stream, [&] { return comm->all_gather(recs + comm->rank, recs, sizeof(TreeRec), c->stream); }), "tree_exchange")) return;
     }
     if (defer_slot) {
         bool okd = hipMemcpyAsync(defer_slot, recs, G * sizeof(TreeRec), hipMemcpyDeviceToHost, c->stream) == hipSuccess;
@@ -822,9 +854,12 @@ void tree_exchange(Sharded& S, uint32_t what, uint32_t arg, uint8_t root[32], co
     std::vector<uint8_t> host(G * sizeof(TreeRec) + 32);
     bool ok = hipMemcpyAsync(host.data(), recs, G * sizeof(TreeRec), hipMemcpyDeviceToHost, c->stream) == hipSuccess;
     ok = ok && hipMemcpyAsync(host.data() + G * sizeof(TreeRec), upper + 1, 32, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
-    ok = ok && hipStreamSynchronize(c->stream) == hipSuccess && hipGetLastError() == hipSuccess;
-    c->shard_ms[1] += wall_ms_shard() - t_wait;                 // the host waits here for everything queued before the root: kernels and exchanges
-    if (!ok) { S.fail(DST_ERR_HIP, "tree_exchange: root read-back failed"); S.agreed = S.agreed ? S.agreed : DST_ERR_HIP; return; }
+    // the host waits here for everything queued before the root, kernels and exchanges: a bounded poll (a peer that never joined the
+    // exchange would otherwise hold this rank for ever); on expiry the communicator is aborted and the rank returns DST_ERR_COMM
+    const int rw = ok ? ctx_sync(c, what == SH_TRACE_TREE ? "the root of the trace tree" : what == SH_CONSTRAINT_TREE ? "the root of the constraint tree" : "the root of a FRI tree") : DST_ERR_HIP;
+    ok = ok && rw == DST_OK && hipGetLastError() == hipSuccess;
+    c->shard_ms[1] += wall_ms_shard() - t_wait;
+    if (!ok) { const int code = rw ? rw : DST_ERR_HIP; S.fail(code, rw ? c->err : std::string("tree_exchange: root read-back failed")); S.agreed = S.agreed ? S.agreed : code; return; }
     tree_exchange_finish(S, what, arg, host.data(), payload_out, first_bad);
     if (root) memcpy(root, host.data() + G * sizeof(TreeRec), 32);
 }
@@ -876,6 +911,7 @@ void commit_trace_columns(Sharded& S) {
         S.local([&]() -> int {
             k_intt_columns(c, c->trace, c->trace_stride, c->polys, W);
             k_lde_columns(c, c->polys, c->lde, W);
+            if (c->sh_ev[1]) (void)hipEventRecord(c->sh_ev[1], c->stream);        // end of the extension (phase 0 | 1)
             k_trace_leaves(c);
             k_merkle_levels_to(c, c->trace_leaves, c->trace_nodes, c->Bc * n, n);
             return DST_OK;
@@ -891,16 +927,17 @@ void commit_trace_columns(Sharded& S) {
             return DST_OK;
         });
         if (use_side) {
-            if (!S.coll(S.timed([&] { return comm->all_gather(c->polys + col * n, c->polys + k * G * n, n * sizeof(fe), c->comm_stream); }), "coefficient all-gather")) return;
+            if (!S.coll(S.coll_on(0, c->comm_stream, [&] { return comm->all_gather(c->polys + col * n, c->polys + k * G * n, n * sizeof(fe), c->comm_stream); }), "coefficient all-gather")) return;
             S.local([&]() -> int { HIP_TRY(c, hipEventRecord(c->comm_events[2 * k + 1], c->comm_stream)); return DST_OK; });
         }
     }
     for (size_t k = 0; k < rounds; k++) {
         const size_t first = k * G, cnt = first + G <= W ? G : W - first;
         if (use_side) S.local([&]() -> int { HIP_TRY(c, hipStreamWaitEvent(c->stream, c->comm_events[2 * k + 1], 0)); return DST_OK; });
-        else if (!S.coll(S.timed([&] { return comm->all_gather(c->polys + (first + comm->rank) * n, c->polys + first * n, n * sizeof(fe), c->stream); }), "coefficient all-gather")) return;
+        else if (!S.coll(S.coll_on(0, c->stream, [&] { return comm->all_gather(c->polys + (first + comm->rank) * n, c->polys + first * n, n * sizeof(fe), c->stream); }), "coefficient all-gather")) return;
         S.local([&]() -> int { k_lde_columns(c, c->polys + first * n, c->lde + first * c->Bc * n, cnt); return DST_OK; });
     }
+    if (c->sh_ev[1]) (void)hipEventRecord(c->sh_ev[1], c->stream);        // end of the extension (phase 0 | 1)
     S.local([&]() -> int {
         k_trace_leaves(c);
         k_merkle_levels_to(c, c->trace_leaves, c->trace_nodes, c->Bc * n, n);
@@ -912,27 +949,38 @@ void commit_trace_columns(Sharded& S) {
 int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t* proof_out, size_t cap, size_t* proof_len) {
     if (!c || !comm) return DST_ERR_ARG;                      // nothing to agree through: the caller's bug, peers are its to stop
     Sharded S{c, comm};
-    // rank-local pre-flight failures must not leave the peers waiting in the first collective: they travel with the first status record
     // A communicator of another shape than the context's cannot take part at all: the exchange sizes follow comm->world, the buffers
-    // prm.world (in-place all-gathers would run past them).  Returned before the first collective; the caller built both handles.
+    // prm.world (in-place all-gathers would run past them).  Returned before the first collective; the caller built both handles, and its
+    // peers leave their first wait after the communicator's limit (dst_comm_set_timeout) instead of hanging.
     if (comm->world != c->prm.world || comm->rank != c->prm.rank) { c->err = "dst_prove_sharded: the communicator's rank / world differ from the context's"; return DST_ERR_ARG; }
     if (comm->world > 8) return DST_ERR_ARG;                  // contexts cannot be created for more
-    // without its device or its exchange buffers (allocated at context creation; only a failed allocation there leaves them missing)
-    // a rank has nothing to hand to a collective: also returned before the first one
-    if (hipSetDevice(c->device) != hipSuccess) { c->err = "dst_prove_sharded: hipSetDevice failed"; return DST_ERR_HIP; }
-    { const int rb = ensure_shard_buffers(c); if (rb) return rb; }
+    // Rank-local pre-flight failures travel with the first status record like every later one: the rank keeps issuing its collectives.
+    if (hipSetDevice(c->device) != hipSuccess) { (void)hipGetLastError(); S.fail(DST_ERR_HIP, "dst_prove_sharded: hipSetDevice failed"); }
+    // The exchange buffers exist from context creation when world > 1 (dst_ctx_create fails otherwise); a one-rank context gets them here.
+    // A rank WITHOUT them has nothing to hand to a collective: it gives its communicator up (in-process peers wake at once, RCCL peers
+    // leave their first wait after the limit) -- unreachable through the public API, kept so that it cannot become a hang.
+    if (S.rc == DST_OK) { const int rb = ensure_shard_buffers(c); if (rb) S.fail(rb, c->err); }
+    if (!c->gather_buf || !c->d_status) { comm->abort("dst_prove_sharded: rank " + std::to_string(comm->rank) + " has no exchange buffers"); return S.rc ? S.rc : DST_ERR_HIP; }
     if (!pub || !proof_len) S.fail(DST_ERR_ARG, "dst_prove_sharded: null argument");
+    // from here on every host wait on this context's stream is the communicator's bounded poll (ctx_sync)
+    struct WaitScope { dst_ctx* c; ~WaitScope() { c->wait_comm = nullptr; } } wait_scope{c};
+    c->wait_comm = comm;
     const size_t G = comm->world;
     double t0 = wall_ms_shard();
     c->shard_ms[0] = c->shard_ms[1] = 0; c->shard_trees = 0;
+    for (double& x : c->exchange_ms) x = 0;
+    c->coll_used = 0;
     auto mark = [&](int i) { const double t = wall_ms_shard(); c->phase_ms[i] = t - t0; t0 = t; };
-    // steps 1-2.  Nothing waits for the extension on the host (the tree exchange is queued behind it): its share of the phase times
-    // comes from two events on the stream
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    const bool timed = hipEventCreate(&ev0) == hipSuccess && hipEventCreate(&ev1) == hipSuccess && hipEventRecord(ev0, c->stream) == hipSuccess;
-    commit_trace_columns(S);
-    if (timed) (void)hipEventRecord(ev1, c->stream);          // after the leaf hashing and the rank-local tree levels
-    if (S.agreed) { if (ev0) hipEventDestroy(ev0); if (ev1) hipEventDestroy(ev1); return S.agreed; }      // a collective itself failed
+    // Phase boundaries are events on the stream (the reference's nine timings, prover.rs:28,36,66,74,87,103,112,134,167): the host only
+    // ENQUEUES between two waits, so its own clock says nothing about where the device's time went.  sh_ev: 0 start, 1 end of the
+    // extension, 2 / 3 around the constraint evaluation, 4 end of the combination.
+    bool timed = true;
+    for (int i = 0; i < 5 && timed; i++) if (!c->sh_ev[i] && hipEventCreate(&c->sh_ev[i]) != hipSuccess) { (void)hipGetLastError(); c->sh_ev[i] = nullptr; timed = false; }
+    auto ev_ms = [&](int a, int b) -> double { float ms = 0; if (timed && hipEventElapsedTime(&ms, c->sh_ev[a], c->sh_ev[b]) == hipSuccess) return ms; (void)hipGetLastError(); return -1.0; };
+    // steps 1-2.  Nothing waits for the extension on the host (the tree exchange is queued behind it)
+    timed = timed && hipEventRecord(c->sh_ev[0], c->stream) == hipSuccess;
+    commit_trace_columns(S);                                    // records sh_ev[1] behind the last extension launch
+    if (S.agreed) return S.agreed;                              // a collective itself failed
     const double t_commit = t0;
     uint8_t trace_root[32], constraint_root[32];
     {
@@ -942,29 +990,28 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
         const fe* from[3] = {c->lde + (c->n - 1), c->lde + stride + (c->n - 1), c->lde + 2 * stride + (c->n - 1)};
         fe last[3];
         tree_exchange(S, SH_TRACE_TREE, 0, trace_root, from, last);
-        if (S.agreed) { if (ev0) hipEventDestroy(ev0); if (ev1) hipEventDestroy(ev1); return S.agreed; }
+        if (S.agreed) return S.agreed;
         c->op_count = (uint64_t)fe_to_u128(last[0]);
         c->program_hash[0] = last[1]; c->program_hash[1] = last[2];
         c->committed = true; c->constraints_done = c->composed = false;
     }
     {
-        // phase 0 = interpolation + extension, phase 1 = leaves, tree levels and the exchange: split the wall time of both at the point
-        // the device reached after the rank-local tree levels, less the leaf hashing that ran before it
-        float dev_ms = 0;
-        const double now = wall_ms_shard(), both = now - t_commit;
-        if (timed && hipEventElapsedTime(&dev_ms, ev0, ev1) == hipSuccess && dev_ms < both) { c->phase_ms[0] = dev_ms; c->phase_ms[1] = both - dev_ms; }
+        // phase 0 = interpolation + extension (the stream's own clock up to sh_ev[1]), phase 1 = leaves, tree levels, the exchange and the
+        // host's share: the rest of the wall time up to the root
+        const double now = wall_ms_shard(), both = now - t_commit, dev_ms = S.rc == DST_OK ? ev_ms(0, 1) : -1.0;
+        if (dev_ms >= 0 && dev_ms < both) { c->phase_ms[0] = dev_ms; c->phase_ms[1] = both - dev_ms; }
         else { c->phase_ms[0] = 0; c->phase_ms[1] = both; }
         t0 = now;
     }
-    if (ev0) hipEventDestroy(ev0);
-    if (ev1) hipEventDestroy(ev1);
     // step 3
     std::vector<fe> coef(344);
     prng_vector(trace_root, 344, coef.data());
     // the evaluation is queued; its verdict (first failing step of this rank's cosets, evaluator.rs:152-158) rides with the status records of the
     // constraint tree's exchange below instead of a host exchange and a wait of its own -- a trace that fails is reported one phase later
+    const double t_eval = t0;
+    if (timed) (void)hipEventRecord(c->sh_ev[2], c->stream);
     S.local([&] { return shard_eval_constraints(c, pub, (const uint8_t*)coef.data(), nullptr, true); });
-    mark(2);
+    if (timed) (void)hipEventRecord(c->sh_ev[3], c->stream);
     // steps 4-5: the transition evaluations of all ranks, then combination (replicated) and the constraint tree
     {
         size_t bytes = 0;
@@ -985,22 +1032,30 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
         const bool side = (comm->stream_ordered() || c->sw_flag("DISTAFF_SHARD_FORCE_OVERLAP")) && G > 1 && invert_first && S.rc == DST_OK && c->comm_stream && c->comm_events.size() >= 2 && !c->sw_flag("DISTAFF_SHARD_NO_OVERLAP");
         if (side) {
             S.local([&]() -> int { HIP_TRY(c, hipEventRecord(c->comm_events[0], c->stream)); HIP_TRY(c, hipStreamWaitEvent(c->comm_stream, c->comm_events[0], 0)); return DST_OK; });
-            if (!S.coll(S.timed([&] { return comm->all_gather(send, c->gather_buf, bytes, c->comm_stream); }), "constraint evaluations")) return S.agreed;
+            if (!S.coll(S.coll_on(3, c->comm_stream, [&] { return comm->all_gather(send, c->gather_buf, bytes, c->comm_stream); }), "constraint evaluations")) return S.agreed;
             S.local([&]() -> int { HIP_TRY(c, hipEventRecord(c->comm_events[1], c->comm_stream)); return DST_OK; });
             S.local([&] { part1_done = true; return shard_combine_parts(c, 1); });
             S.local([&]() -> int { HIP_TRY(c, hipStreamWaitEvent(c->stream, c->comm_events[1], 0)); return DST_OK; });
-        } else if (!S.coll(S.timed([&] { return comm->all_gather(send, c->gather_buf, bytes, c->stream); }), "constraint evaluations")) return S.agreed;        // the import below rewrites `ceval` only after the exchange
+        } else if (!S.coll(S.coll_on(3, c->stream, [&] { return comm->all_gather(send, c->gather_buf, bytes, c->stream); }), "constraint evaluations")) return S.agreed;        // the import below rewrites `ceval` only after the exchange
         S.local([&] { const int r = dst_shard_import(c, SH_CEVAL, 0, c->gather_buf, 1, nullptr); c->ceval_inverted = invert_first && r == DST_OK; return r; });
-        S.local([&] { return shard_combine_parts(c, part1_done ? 2 : 3); });
+        S.local([&] { return shard_combine_parts(c, part1_done ? 2 : 3); });       // records sh_ev[4] between the combination and the extension of its result
     }
-    mark(3);
     {
         int64_t first_bad = -1;
         tree_exchange(S, SH_CONSTRAINT_TREE, 0, constraint_root, nullptr, nullptr, c->d_u64, &first_bad);
         if (S.agreed) return S.agreed;
         if (first_bad >= 0) { c->err = "transition constraints were not satisfied at step " + std::to_string(first_bad); return DST_ERR_AIR; }
     }
-    mark(4);
+    {
+        // phases 2 (constraint evaluation), 3 (combination incl. the exchange of the evaluations), 4 (extension of the constraint polynomial,
+        // its tree, the tree exchange): the host queued all three without a wait, so they are split at the stream's events; what the host spent
+        // before the first and after the last event goes to the outer phases, as in dst_eval_constraints
+        const double now = wall_ms_shard(), total = now - t_eval;
+        const double e1 = S.rc == DST_OK ? ev_ms(2, 3) : -1.0, e2 = S.rc == DST_OK ? ev_ms(3, 4) : -1.0;
+        if (e1 >= 0 && e2 >= 0 && e1 + e2 <= total) { c->phase_ms[2] = e1; c->phase_ms[3] = e2; c->phase_ms[4] = total - e1 - e2; }
+        else { c->phase_ms[2] = 0; c->phase_ms[3] = 0; c->phase_ms[4] = total; }
+        t0 = now;
+    }
     // step 6
     std::vector<fe> draws(516);
     prng_vector(constraint_root, 516, draws.data());
@@ -1050,14 +1105,14 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
         // this rank's cosets of the layer (contiguous, coset-major) -> all cosets in the gather buffer -> natural order, then the rest
         // of the commit phase on every rank (the natural-order layer overwrites fri_e[d] only after the exchange has completed)
         uint8_t root[32];
-        if (!S.coll(S.timed([&] { return comm->all_gather(c->fri_e[d], c->gather_buf, bytes, c->stream); }), "FRI tail")) return S.agreed;
+        if (!S.coll(S.coll_on(4, c->stream, [&] { return comm->all_gather(c->fri_e[d], c->gather_buf, bytes, c->stream); }), "FRI tail")) return S.agreed;
         S.local([&] { c->fri_tail_pending = true; return fri_replicated_tail(c, c->gather_buf, 1, root); });
     }
     if (chained && rep_from > 0) {
         // the deferred records of the sharded layers: everything queued has completed once the stream is idle (a rank that failed locally
         // did not run the tail's own wait)
         const double t_wait = wall_ms_shard();
-        if (hipStreamSynchronize(c->stream) != hipSuccess) S.fail(DST_ERR_HIP, "dst_prove_sharded: stream synchronisation failed");
+        { const int rw = ctx_sync(c, "the FRI layers"); if (rw) { S.fail(rw, c->err); if (rw == DST_ERR_COMM) return rw; } }
         c->shard_ms[1] += wall_ms_shard() - t_wait;
         for (int d = 0; d < rep_from && !S.agreed; d++) tree_exchange_finish(S, SH_FRI_TREE, (uint32_t)d, slot_of(d), nullptr, nullptr);
         if (S.agreed) return S.agreed;
@@ -1084,7 +1139,7 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
     {
         struct LenRec { uint64_t len; int64_t rc; } rec{(uint64_t)mine, S.rc};
         std::vector<LenRec> all(G);
-        if (!S.coll(S.timed([&] { return comm->all_gather_host(&rec, all.data(), sizeof(LenRec), c->stream); }), "openings")) return S.agreed;
+        if (!S.coll(S.coll_host([&] { return comm->all_gather_host(&rec, all.data(), sizeof(LenRec), c->stream); }), "openings")) return S.agreed;
         for (size_t g = 0; g < G; g++) {
             if (all[g].rc != DST_OK && S.agreed == DST_OK) { S.agreed = (int)all[g].rc; if (S.rc == DST_OK) c->err = "before the openings: rank " + std::to_string(g) + " reported error " + std::to_string(all[g].rc); }
             lens[g] = all[g].len;            // every rank derives the same plan, so this equals what dst_shard_open computed locally
@@ -1096,7 +1151,7 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
     std::vector<uint8_t> blob(width + 8, 0), all(( width + 8) * G);
     S.local([&] { return dst_shard_open(c, positions.data(), (uint32_t)positions.size(), blob.data(), width, &mine, nullptr); });
     { const int64_t rc64 = S.rc; memcpy(blob.data() + width, &rc64, 8); }                    // the status rides behind the blob
-    if (!S.coll(S.timed([&] { return comm->all_gather_host(blob.data(), all.data(), width + 8, c->stream); }), "openings")) return S.agreed;
+    if (!S.coll(S.coll_host([&] { return comm->all_gather_host(blob.data(), all.data(), width + 8, c->stream); }), "openings")) return S.agreed;
     for (size_t g = 0; g < G && S.agreed == DST_OK; g++) {
         int64_t rc64; memcpy(&rc64, all.data() + g * (width + 8) + width, 8);
         if (rc64 != DST_OK) { S.agreed = (int)rc64; if (S.rc == DST_OK) c->err = "openings: rank " + std::to_string(g) + " reported error " + std::to_string(rc64); }
@@ -1107,6 +1162,7 @@ int dst_prove_sharded(dst_ctx* c, dst_comm* comm, const dst_public* pub, uint8_t
     // assembly is deterministic host work on identical inputs: it succeeds or fails on every rank alike
     const int rc = dst_shard_assemble(c, positions.data(), (uint32_t)positions.size(), nonce, packed.data(), lens.data(), proof_out, cap, proof_len);
     mark(8);
+    S.read_collective_events();                                 // everything queued has completed: the last exchange was waited for
     return rc;
 }
 

@@ -27,10 +27,21 @@ def use_test_hooks():
         LIB_PATH = HOOKS_LIB
 
 
+def use_product():
+    """Bind the product library whatever the environment said at import (an inherited DISTAFF_TEST_HOOKS=1) -- before the first load().
+    An explicit DISTAFF_HIP_LIB still wins: it names a library, not a build flavour."""
+    global LIB_PATH
+    if _lib is not None:
+        raise RuntimeError("use_product() must be called before the library is loaded")
+    os.environ.pop("DISTAFF_TEST_HOOKS", None)
+    if not os.environ.get("DISTAFF_HIP_LIB"):
+        LIB_PATH = PRODUCT_LIB
+
+
 def library_path():
     return LIB_PATH
 
-DST_OK, DST_ERR_ARG, DST_ERR_HIP, DST_ERR_AIR, DST_ERR_STATE = 0, -1, -2, -3, -4
+DST_OK, DST_ERR_ARG, DST_ERR_HIP, DST_ERR_AIR, DST_ERR_STATE, DST_ERR_COMM = 0, -1, -2, -3, -4, -5
 
 # ids of dst_read_buffer (distaff_amd/csrc/ctx.h)
 BUF = {"polys": 0, "lde": 1, "trace_leaves": 2, "trace_nodes": 3, "ceval_i": 4, "ceval_f": 5, "ceval_t": 6, "cpoly": 7, "cevals": 8,
@@ -43,7 +54,7 @@ EXPORTS = ["dst_ctx_create", "dst_ctx_destroy", "dst_last_error", "dst_phase_ms"
            "dst_shard_commit_trace", "dst_shard_eval_constraints", "dst_shard_combine", "dst_shard_fri_layer", "dst_shard_fri_fold",
            "dst_shard_export_size", "dst_shard_export", "dst_shard_import", "dst_shard_read", "dst_shard_fri_begin", "dst_shard_fri_end", "dst_shard_fri_roots", "dst_shard_open", "dst_shard_assemble", "dst_shard_info",
            "dst_comm_unique_id", "dst_comm_init", "dst_comm_init_local", "dst_comm_init_callbacks", "dst_comm_destroy", "dst_comm_last_error", "dst_comm_copy", "dst_prove_sharded", "dst_prove_sharded_local", "dst_shard_stage_ms",
-           "dst_comm_describe", "dst_comm_trace", "dst_test_hooks"]
+           "dst_comm_describe", "dst_comm_trace", "dst_test_hooks", "dst_comm_set_timeout", "dst_comm_abort", "dst_shard_exchange_ms"]
 
 
 class DistaffError(RuntimeError):
@@ -204,6 +215,21 @@ class Comm:
         d = {f: int(getattr(info, f)) for f, _ in CommInfo._fields_}
         d["transport"] = ("rccl", "local", "callbacks")[d["transport"]]
         return d
+
+    def set_timeout(self, seconds):
+        """dst_comm_set_timeout: limit of every host wait behind a collective of this communicator (default 60 s; <= 0: none).  On expiry
+        the rank aborts the communicator and prove_sharded raises DistaffError(DST_ERR_COMM)."""
+        if self.lib.dst_comm_set_timeout(self._h, ctypes.c_double(seconds)) != DST_OK:
+            raise DistaffError(DST_ERR_ARG, "dst_comm_set_timeout failed")
+
+    def abort(self):
+        """dst_comm_abort: gives the communicator up from the host's side; every later collective of this handle fails at once"""
+        self.lib.dst_comm_abort(self._h)
+
+    def last_error(self):
+        self.lib.dst_comm_last_error.restype = ctypes.c_char_p
+        self.lib.dst_comm_last_error.argtypes = [ctypes.c_void_p]
+        return self.lib.dst_comm_last_error(self._h).decode()
 
     def trace(self, enable=-1):
         """dst_comm_trace: the collectives this rank has issued so far as [(kind, bytes per rank, stream index or None)]; enable = 1 starts a
@@ -441,6 +467,13 @@ class Context:
         v = (ctypes.c_double * 3)()
         self._check(self.lib.dst_shard_stage_ms(self._h, v))
         return {"transport_calls": v[0], "root_waits": v[1], "tree_exchanges": int(v[2])}
+
+    def shard_exchange_ms(self):
+        """dst_shard_exchange_ms: enqueue -> completion of the collectives of the last prove_sharded, per kind, from events on their streams"""
+        v = (ctypes.c_double * 8)()
+        self._check(self.lib.dst_shard_exchange_ms(self._h, v))
+        return {"coefficients": v[0], "tree_all_to_all": v[1], "tree_all_gather": v[2], "constraint_evaluations": v[3], "fri_tail": v[4],
+                "host_values": v[5], "collectives": int(v[6]), "timed_by_events": int(v[7])}
 
     def commit_trace(self):
         root = ctypes.create_string_buffer(32)

@@ -38,6 +38,8 @@ extern "C" {
 #define DST_ERR_HIP (-2)      /* HIP runtime error (no device, out of memory, launch failure) */
 #define DST_ERR_AIR (-3)      /* transition constraints not satisfied by the trace (reference panic: evaluator.rs:155) */
 #define DST_ERR_STATE (-4)    /* phase called out of order */
+#define DST_ERR_COMM (-5)     /* a collective of dst_prove_sharded failed or did not complete within the communicator's limit (a peer that died or
+                                 never arrived); the communicator has been aborted and refuses further collectives -- destroy it, create a new one */
 
 typedef struct dst_ctx dst_ctx;
 
@@ -173,19 +175,21 @@ DST_API int dst_shard_info(dst_ctx* ctx, uint64_t* op_count, uint32_t* num_fri_l
 /* ---- inspection (tests and profiling): copies an internal device buffer to the host.  `what` ids are listed in
  * distaff_amd/csrc/ctx.h (DST_BUF_*).  Two-call protocol: out = NULL returns the size through *len. ------------------- */
 DST_API int dst_read_buffer(dst_ctx* ctx, uint32_t what, uint32_t arg, uint8_t* out, size_t cap, size_t* len);
-/* micro-benchmark hook used by bench.py's roofline section: runs `iters` dependent modular multiplications per lane
- * on `lanes` lanes and returns the elapsed milliseconds. */
 /* 1: this is the test / bench build (libdistaff_hip_hooks.so: calibration kernels, the alternative formulations behind the test-only
  * DISTAFF_* switches of INTEGRATION.md section 6); 0: the product library, which has neither */
 DST_API int dst_test_hooks(void);
+/* micro-benchmark hook used by bench.py's roofline section: runs `iters` dependent modular multiplications per lane
+ * on `lanes` lanes and returns the elapsed milliseconds.  (Test / bench build only: the product library returns DST_ERR_STATE.) */
 DST_API int dst_bench_mulmod(dst_ctx* ctx, uint64_t lanes, uint32_t iters, double* ms);
 /* peak of the 32x32+64 multiply-add (v_mad_u64_u32) on this device: `iters` iterations of 32 independent-enough mads per lane on
- * `lanes` lanes; returns the elapsed milliseconds (rate = lanes * iters * 32 / time).  The integer-multiplier roofline of the path. */
+ * `lanes` lanes; returns the elapsed milliseconds (rate = lanes * iters * 32 / time).  The integer-multiplier roofline of the path.
+ * (Test / bench build only: the product library returns DST_ERR_STATE.) */
 DST_API int dst_bench_mad(dst_ctx* ctx, uint64_t lanes, uint32_t iters, double* ms);
 /* box fingerprint: milliseconds for 2^23 lanes to run `code_kib` (16 or 176) KiB of straight-line multiply-adds once each.  The ratio
  * of the two times per instruction is 0.9 on a healthy device; a device on which code beyond the instruction cache is slow shows it here.
  * code_kib = 177: the 176 KiB kernel in its convoy form (256 lanes per workgroup, a workgroup barrier every 16 KiB: the wavefronts share
- * their instruction-cache lines) -- whether that form would help on the device at hand. */
+ * their instruction-cache lines) -- whether that form would help on the device at hand.
+ * (Test / bench build only: the product library returns DST_ERR_STATE.) */
 DST_API int dst_bench_code(dst_ctx* ctx, uint32_t code_kib, double* ms);
 /* element-wise device field arithmetic on caller data (tests): op 0 add, 1 sub, 2 mul, 3 mul (portable formulation), 4 inv(a), 5 a^b */
 DST_API int dst_field_op(dst_ctx* ctx, int op, const uint8_t* a, const uint8_t* b, uint8_t* out, size_t count);
@@ -219,6 +223,15 @@ DST_API int dst_comm_init_local(uint32_t world, dst_comm** out /* [world] */);
 typedef int (*dst_comm_fn)(void* user, int kind, const void* send, void* recv, size_t bytes);
 DST_API int dst_comm_init_callbacks(uint32_t rank, uint32_t world, dst_comm_fn fn, void* user, dst_comm** out);
 DST_API void dst_comm_destroy(dst_comm* comm);
+/* Containment.  The reference panics (src/lib.rs:32,49,56); dst_prove_sharded returns an error on every rank instead, also when a peer
+ * never arrives: every host wait behind a collective is a bounded poll of the stream (plus ncclCommGetAsyncError on the RCCL transport).
+ * After `seconds` without completion (default 60, DISTAFF_COMM_TIMEOUT_S at creation; <= 0: no limit) the rank aborts its communicator --
+ * ncclCommAbort on RCCL, which also ends the kernels stuck on the stream; the in-process transport wakes every peer out of its barrier --
+ * and returns DST_ERR_COMM; dst_comm_last_error then names the wait and the index, kind and size of the last collective this rank issued
+ * (with dst_comm_trace the whole issue order).  dst_comm_abort does the same from the host's side (a watchdog that learnt of a dead
+ * peer).  A callback transport's channel is the host's to bound: a callback that returns non-zero ends the rank the same way. */
+DST_API int dst_comm_set_timeout(dst_comm* comm, double seconds);
+DST_API int dst_comm_abort(dst_comm* comm);
 /* What a communicator is and what its transport says about itself.  For the RCCL transport rccl_ranks / rccl_rank / device come from
  * ncclCommCount / ncclCommUserRank / ncclCommCuDevice on the live communicator (the proof that RCCL connected `world` ranks);
  * for the in-process transport peers_other_device = ranks whose buffers live on another device than this rank's and peers_enabled = how many
@@ -244,6 +257,12 @@ DST_API int dst_prove_sharded(dst_ctx* ctx, dst_comm* comm, const dst_public* pu
  * whole exchange on a blocking transport), out[1] = milliseconds waiting for tree roots (the only host waits of the protocol), out[2] =
  * number of tree exchanges */
 DST_API int dst_shard_stage_ms(const dst_ctx* ctx, double out[3]);
+/* device-side view of the collectives of the last dst_prove_sharded on this rank: milliseconds from enqueue to completion (events around
+ * every collective on the stream it was queued on; on RCCL that includes the wait for the slowest peer), summed per kind --
+ * out[0] coefficient all-gathers, [1] tree all-to-alls (boundary nodes), [2] tree all-gathers (subtree roots + status records, or boundary
+ * nodes in the all-gather-only form), [3] the all-gather of the constraint evaluations, [4] the all-gather of the first replicated FRI
+ * layer, [5] all-gathers of host values (openings; host wall time), [6] number of collectives, [7] of which timed by events */
+DST_API int dst_shard_exchange_ms(const dst_ctx* ctx, double out[8]);
 DST_API int dst_prove_sharded_local(dst_ctx** ctxs, uint32_t world, const dst_public* pub, uint8_t* proof, size_t cap, size_t* len);
 
 #ifdef __cplusplus

@@ -25,9 +25,12 @@ def pytest_sessionstart(session):
     if not all(os.path.exists(p) for p in libs) and os.environ.get("DISTAFF_HIP_LIB") is None:
         import subprocess
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "distaff_amd", "csrc"), "-j8"])
+    product_only = os.environ.get("DISTAFF_PRODUCT_ONLY") == "1"       # tests/test_product_library.py re-runs a selection of the parity tests on the product library itself
+    if product_only:
+        os.environ.pop("DISTAFF_TEST_HOOKS", None)           # BEFORE the import: the package fixes the library it binds when it is imported
     import distaff_amd
-    if os.environ.get("DISTAFF_PRODUCT_ONLY") == "1":       # tests/test_product_library.py re-runs a selection of the parity tests on the product library itself
-        os.environ.pop("DISTAFF_TEST_HOOKS", None)
+    if product_only:
+        distaff_amd.use_product()
     else:
         distaff_amd.use_test_hooks()
 

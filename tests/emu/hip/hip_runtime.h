@@ -65,7 +65,7 @@ static inline unsigned atomicAdd(unsigned* p, unsigned v) { return emu_atomic_ad
 
 // ---- runtime API (the subset the library uses) --------------------------------------------------------------------------------
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100, hipErrorPeerAccessAlreadyEnabled = 704 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100, hipErrorNotReady = 600, hipErrorPeerAccessAlreadyEnabled = 704 };
 typedef struct emu_stream* hipStream_t;
 typedef struct emu_event* hipEvent_t;
 enum hipMemcpyKind { hipMemcpyHostToHost = 0, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
@@ -96,6 +96,7 @@ hipError_t hipStreamCreate(hipStream_t* s);
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t s);
 hipError_t hipStreamSynchronize(hipStream_t s);
+static inline hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }      /* every emulated operation is synchronous: a stream is always idle */
 hipError_t hipEventCreate(hipEvent_t* e);
 hipError_t hipEventDestroy(hipEvent_t e);
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t s = nullptr);

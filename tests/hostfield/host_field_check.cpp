@@ -2,6 +2,7 @@
 // hf_mul, hf_sqr, inv_alpha4, hf_pow) for edge and seeded random operands; tests/test_host_logic.py compares them with Python integers.
 #include <stdio.h>
 #include <stdlib.h>
+#define HF_COUNT_OPS 1
 #include "host_vm.h"
 using namespace dsth;
 static uint64_t state = 0x9E3779B97F4A7C15ull;
@@ -25,5 +26,6 @@ int main() {
         inv_alpha4(t);
         for (int l = 0; l < 4; l++) { printf("p "); pr(s[l]); printf(" "); pr(t[l]); printf(" "); pr(hf_pow(s[l], HF_INV_ALPHA)); printf("\n"); }
     }
+    { u128 one[4] = {2, 3, 5, 7}; hf_count_sqr = hf_count_mul = 0; inv_alpha4(one); printf("c %x %x\n", hf_count_sqr, hf_count_mul); }      // operations of ONE chain
     return 0;
 }

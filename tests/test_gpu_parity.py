@@ -1192,6 +1192,181 @@ def test_thread_rank_transport_issue_order_and_peer_access(oracle, world):
         cm.close()
 
 
+def _thread_ranks(ctxs, comms, inputs, outputs, skip=()):
+    """one Python thread per rank calling prove_sharded -> (proofs, {rank: DistaffError}, seconds per rank)"""
+    import threading
+    import time
+    import distaff_amd as D
+    world = len(ctxs)
+    proofs, errors, took = [None] * world, {}, [0.0] * world
+
+    def run(r):
+        t0 = time.time()
+        try:
+            proofs[r] = ctxs[r].prove_sharded(comms[r], inputs, outputs)
+        except D.DistaffError as e:
+            errors[r] = e
+        took[r] = time.time() - t0
+    threads = [threading.Thread(target=run, args=(r,)) for r in range(world) if r not in skip]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    return proofs, errors, took
+
+
+def test_prove_sharded_peer_that_never_arrives(oracle):
+    """Containment (the reference panics, lib.rs:32,49,56; the C-ABI promises an error code on every rank): a rank whose peer never enters
+    dst_prove_sharded does not wait for ever -- after the communicator's limit (dst_comm_set_timeout) it aborts the communicator and returns
+    DST_ERR_COMM, naming the collective it was stuck in; the dead communicator refuses further work at once; with fresh communicators the
+    SAME contexts prove."""
+    import time
+    import distaff_amd as D
+    O = oracle
+    t = O.fibonacci_trace(128)
+    op = O.Prover.from_trace(t, 1, grinding=8)
+    expected = op.prove()
+    ctxs = []
+    for r in range(2):
+        ctx = D.Context(7, t.width, t.ctx_depth, t.loop_depth, rank=r, world=2, grinding=8)
+        ctx.upload(t.columns)
+        ctxs.append(ctx)
+    comms = D.Comm.local(2)
+    for cm in comms:
+        cm.set_timeout(1.5)
+    proofs, errors, took = _thread_ranks(ctxs, comms, t.public_inputs, op.outputs, skip=(1,))        # rank 1 never calls
+    assert 0 in errors and errors[0].code == D.DST_ERR_COMM, errors
+    assert "did not reach collective #0 (all-gather" in str(errors[0]) and "within 1.5" in str(errors[0]), str(errors[0])
+    assert 1.0 < took[0] < 20.0, took
+    # the group is dead for every rank: the late peer is refused at once instead of waiting in a barrier nobody will complete
+    t0 = time.time()
+    with pytest.raises(D.DistaffError) as e:
+        ctxs[1].prove_sharded(comms[1], t.public_inputs, op.outputs)
+    assert e.value.code == D.DST_ERR_COMM and time.time() - t0 < 5.0, str(e.value)
+    with pytest.raises(D.DistaffError) as e:
+        ctxs[0].prove_sharded(comms[0], t.public_inputs, op.outputs)
+    assert e.value.code == D.DST_ERR_COMM and time.time() - t0 < 5.0
+    for cm in comms:
+        cm.close()
+    # a host-side abort (a watchdog that learnt of a dead peer) has the same effect
+    comms = D.Comm.local(2)
+    comms[0].abort()
+    proofs, errors, took = _thread_ranks(ctxs, comms, t.public_inputs, op.outputs)
+    assert set(errors) == {0, 1} and all(err.code == D.DST_ERR_COMM for err in errors.values()), errors
+    assert max(took) < 5.0
+    for cm in comms:
+        cm.close()
+    comms = D.Comm.local(2)
+    proofs, errors, took = _thread_ranks(ctxs, comms, t.public_inputs, op.outputs)
+    assert not errors and proofs[0] == expected and proofs[1] == expected
+    for cm in comms:
+        cm.close()
+    for ctx in ctxs:
+        ctx.close()
+
+
+@pytest.mark.parametrize("stall_at", [0, 3, 11])
+def test_prove_sharded_stalled_collective_is_aborted(oracle, monkeypatch, stall_at):
+    """What a collective whose peer never arrives does to a rank -- its stream stops -- reproduced on ONE GPU by the test build's fault
+    injection (DISTAFF_TEST_STALL_COLLECTIVE=k@r: before rank r's device collective number k a kernel is queued that holds the stream
+    until the communicator is aborted).  The rank's next host wait is a bounded poll: after the limit it aborts the communicator (which
+    releases the stream, as ncclCommAbort ends RCCL's kernels), returns DST_ERR_COMM and names the wait and the last collective it issued;
+    its peer, waiting for it in the exchange, is woken and returns DST_ERR_COMM as well.  With 2 ranks: collectives 0 - 9 = the coefficient
+    all-gathers, 10 = the all-to-all of the trace tree's boundary nodes, 11 = the all-gather of its root records."""
+    import distaff_amd as D
+    if not D.load().dst_test_hooks():
+        pytest.skip("fault injection exists in the test build only")
+    O = oracle
+    t = O.fibonacci_trace(128)
+    op = O.Prover.from_trace(t, 1, grinding=8)
+    expected = op.prove()
+    ctxs = []
+    for r in range(2):
+        ctx = D.Context(7, t.width, t.ctx_depth, t.loop_depth, rank=r, world=2, grinding=8)
+        ctx.upload(t.columns)
+        ctxs.append(ctx)
+    monkeypatch.setenv("DISTAFF_TEST_STALL_COLLECTIVE", "%d@1" % stall_at)
+    comms = D.Comm.local(2)
+    monkeypatch.delenv("DISTAFF_TEST_STALL_COLLECTIVE")
+    for cm in comms:
+        cm.set_timeout(2.0)
+    proofs, errors, took = _thread_ranks(ctxs, comms, t.public_inputs, op.outputs)
+    assert set(errors) == {0, 1} and all(e.code == D.DST_ERR_COMM for e in errors.values()), errors
+    msg = comms[1].last_error()
+    assert "no completion within 2.0 s" in msg and "the communicator was aborted" in msg, msg
+    assert ("collective #%d (%s" % (stall_at, "all-gather" if stall_at != 10 else "all-to-all")) in msg, msg
+    assert "left the group" in comms[0].last_error() or "did not reach" in comms[0].last_error(), comms[0].last_error()
+    assert 1.5 < max(took) < 25.0, took
+    for cm in comms:
+        cm.close()
+    comms = D.Comm.local(2)
+    proofs, errors, took = _thread_ranks(ctxs, comms, t.public_inputs, op.outputs)
+    assert not errors and proofs[0] == expected and proofs[1] == expected
+    for cm in comms:
+        cm.close()
+    for ctx in ctxs:
+        ctx.close()
+
+
+_STALLED_PEER_WORKER = r"""
+import datetime, json, os, sys, time
+sys.path.insert(0, %r)
+import torch.distributed as dist
+import distaff_amd as D
+dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=12))      # the HOST's channel carries its own limit
+rank, world = dist.get_rank(), dist.get_world_size()
+cols, program_hash, result = D.fibonacci_trace(10)
+ctx = D.Context(10, 20, 1, 0, device=0, rank=rank, world=world)
+ctx.upload(cols)
+if rank == 1:
+    os.environ["DISTAFF_TEST_STALL_COLLECTIVE"] = "12"                        # somewhere behind the trace tree
+comm = D.Comm.over_torch(dist)
+comm.set_timeout(3.0)
+t0 = time.time()
+out = {"rank": rank}
+try:
+    ctx.prove_sharded(comm, [1, 0], [result])
+    out["code"] = 0
+except D.DistaffError as e:
+    out["code"], out["message"] = e.code, str(e)
+out["seconds"] = time.time() - t0
+out["comm_error"] = comm.last_error()
+json.dump(out, open(os.path.join(sys.argv[1], "result_%%d.json" %% rank), "w"))
+if rank == 1:
+    time.sleep(20)                                                            # the stalled rank stops answering: rank 0 has only its own limits
+os._exit(0)                                                                   # no orderly shutdown of a broken group
+"""
+
+
+def test_stalled_peer_process_over_the_callback_transport(tmp_path):
+    """Two OS processes on GPU 0 over the callback transport (gloo carries the collectives): rank 1's stream stalls in the middle of the
+    proof (fault injection of the test build) and the process then stops answering.  Rank 1 returns DST_ERR_COMM after ITS communicator's
+    limit (3 s: bounded poll, abort); rank 0, inside the host's collective callback, returns DST_ERR_COMM when the host's channel gives up
+    (gloo's 12 s) -- nobody hangs, both name the collective."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+    import distaff_amd as D
+    if not D.load().dst_test_hooks():
+        pytest.skip("fault injection exists in the test build only")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    script = tmp_path / "worker.py"
+    script.write_text(_STALLED_PEER_WORKER % root)
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script), str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    res = [json.load(open(tmp_path / ("result_%d.json" % r))) for r in range(2)]
+    assert res[1]["code"] == D.DST_ERR_COMM and "no completion within 3.0 s" in res[1]["comm_error"] and "collective #12 (all-gather" in res[1]["comm_error"], (res, outs)
+    assert 2.5 < res[1]["seconds"] < 20.0, res
+    assert res[0]["code"] == D.DST_ERR_COMM and "callback returned" in res[0]["comm_error"] and "collective #12" in res[0]["comm_error"], (res, outs)
+    assert res[0]["seconds"] < 60.0, res
+
+
 def test_prove_sharded_reports_an_invalid_trace_on_every_rank(oracle):
     import distaff_amd as D
     O = oracle

@@ -35,6 +35,11 @@ def test_host_field_and_inverse_sbox_chain(tmp_path):
     for line in out.splitlines():
         f = line.split()
         v = [int(x, 16) for x in f[1:]]
+        if f[0] == "c":
+            # 127 squarings: the exponent the chain implements is below 2^128, and the only exponent below 2^128 that agrees with x^E on
+            # every x is E itself (E + (p - 1) > 2^128) -- round 5's chain had 143: a 136-bit exponent congruent to E modulo p - 1
+            assert v == [127, 12], v
+            continue
         if f[0] == "m":
             a, b, m, sq = v
             assert m == a * b % P and sq == a * a % P, (hex(a), hex(b))
@@ -42,7 +47,7 @@ def test_host_field_and_inverse_sbox_chain(tmp_path):
             x, chain, ladder = v
             assert chain == ladder == pow(x, E, P) and pow(chain, 3, P) == x, hex(x)
         seen[f[0]] += 1
-    assert seen == {"m": 256 + 4000, "p": 1600}
+    assert seen == {"m": 256 + 4000, "p": 1600} and any(l.startswith("c ") for l in out.splitlines())
 
 
 def test_library_fiat_shamir_helpers_equal_oracle(oracle):
