@@ -174,6 +174,18 @@ def pmc_row(kernel):
 # v_xor / v_alignbit each reach 0.95 - 0.99 of one wave-instruction per 4 cycles and SIMD; v_mad_u64_u32 takes 1.41 such slots); the guide's
 # 2-cycle figure is for v_fma_f32 and does not apply to them.
 VALU_ISSUE_PEAK = 256 * 4 * 2.4e9 / 4
+NOMINAL_SCLK_MHZ = 2400.0
+# bytes a memory-side read request carries per 64 B that FETCH_SIZE tallies, per kernel (profiles/r6_fetch_factor.txt): wide streaming reads travel
+# as 128-byte requests tallied at 64 (x 2, the guide's figure); the first transform pass reads 64-byte row segments only, tallied in full (x 1)
+FETCH_FACTOR = {"ntt_pass_a": 1.0, "ntt_pass_mid": 1.0}
+
+
+def counter_traffic(name, row):
+    """HBM-side bytes per launch from the committed counter row of kernel `name`: FETCH_SIZE x its calibrated factor + WRITE_SIZE"""
+    if row is None or not row.get("fetch_bytes_per_launch_raw") or not row.get("write_bytes_per_launch_raw"):
+        return None, None
+    factor = FETCH_FACTOR.get(name.split("<")[0], 2.0)
+    return int(float(row["fetch_bytes_per_launch_raw"]) * factor) + int(float(row["write_bytes_per_launch_raw"])), factor
 
 
 def valu_issue(stats, proof_ms, steps):
@@ -209,6 +221,13 @@ def box_fingerprint(cal, mad_peak, mulmod_peak):
     import subprocess
     import torch
     box = {"mad_peak": mad_peak, "mulmod_peak": mulmod_peak}
+    try:
+        # the shader clock this box sustains under the path's arithmetic (four fe_mul chains per lane on every SIMD; s_memtime against s_memrealtime)
+        box["sclk_under_load_MHz"] = round(cal.bench_clock(1 << 20, 512), 1) if cal is not None else None
+        box["sclk_nominal_MHz"] = NOMINAL_SCLK_MHZ
+    except Exception as e:                                           # noqa: BLE001
+        box["sclk_under_load_MHz"] = None
+        box["sclk_error"] = str(e)
     try:
         props = torch.cuda.get_device_properties(torch.cuda.current_device())
         box["device"] = props.name
@@ -247,15 +266,14 @@ def kernel_rooflines(stats, steps, default_workload, top=5):
         per_launch_bytes = st["bytes"] / st["launches"]
         achieved = per_launch_bytes / (per_launch_ms * 1e-3) / 1e9
         row, source = pmc_row(name) if default_workload else (None, "no counter passes exist for this workload")
-        traffic = None
-        if row is not None and row.get("fetch_bytes_per_launch_x2") and row.get("write_bytes_per_launch_raw"):
-            traffic = int(row["fetch_bytes_per_launch_x2"]) + int(row["write_bytes_per_launch_raw"])
+        traffic, fetch_factor = counter_traffic(name, row)
         valu = None
         if row is not None and row.get("SQ_INSTS_VALU"):
             valu = round(float(row["SQ_INSTS_VALU"]) / (per_launch_ms * 1e-3) / VALU_ISSUE_PEAK, 4)
             valu = valu if valu <= 1.02 else None
         rows.append({"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "traffic_over_algorithmic": None if traffic is None else round(traffic / per_launch_bytes, 2), "traffic_source": source,
+                     "traffic_fetch_factor": fetch_factor,
                      "valu_issue_frac": valu, "ms_per_step": round(st["ms"] / steps, 3), "launches_per_step": st["launches"] / steps,
                      "avg_launch_ms": round(per_launch_ms, 4), "algorithmic_bytes_per_launch": per_launch_bytes})
     return rows
@@ -751,6 +769,17 @@ def run(args):
     else:
         workload = ("Fibonacci program (src/examples/fibonacci.rs), 2^%d-step trace, W=20 registers, full stark::prove with %sProofOptions (blowup %d, %d queries, grinding 20, blake3)"
                     % (log_n, "default " if (blowup, args.queries) == (32, 50) else "", blowup, args.queries))
+    box = box_fingerprint(cal, mad_peak, mulmod_peak)
+    vi = alu.get("valu_issue")
+    if isinstance(vi, dict) and vi.get("proof_frac") is not None and box.get("sclk_under_load_MHz"):
+        # the slots the device OFFERS shrink with the clock the power management grants under this arithmetic (profiles/r6_power_clock.md):
+        # the same instruction counts against 1024 SIMDs x measured clock / 4 cycles.  Above 1 is possible: ~7 % of the instructions are
+        # full-rate kinds that take half a slot (profiles/r6_issue_slots.txt).
+        scale = NOMINAL_SCLK_MHZ / box["sclk_under_load_MHz"]
+        vi["proof_frac_at_measured_clock"] = round(vi["proof_frac"] * scale, 4)
+        vi["kernel_frac_at_measured_clock"] = {k: (None if v is None else round(v * scale, 4)) for k, v in vi["kernel_frac"].items()}
+        vi["measured_clock_note"] = ("sclk_under_load_MHz = %.0f of %.0f nominal, from the calibration kernel of the test build (field multiplications on every SIMD); "
+                                     "the transform passes themselves were measured at 1870 / 1980 MHz (profiles/r6_pass_stamps.md)" % (box["sclk_under_load_MHz"], NOMINAL_SCLK_MHZ))
     out = {
         "metric": "trace_cells_per_sec", "value": value, "unit": "trace-cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
@@ -771,7 +800,7 @@ def run(args):
         "roofline_transform": roofline_transform,
         "rooflines": rooflines,
         "step_ms": {"min": round(min(step_ms), 3), "median": round(float(np.median(step_ms)), 3), "max": round(max(step_ms), 3), "all": [round(x, 3) for x in step_ms]},
-        "box": box_fingerprint(cal, mad_peak, mulmod_peak),
+        "box": box,
         "alu_roofline": dict(alu, mulmod_peak_measured=mulmod_peak, mulmod_kernel="mulmod_bench_kernel: general fe_mul, 4 dependent chains per lane (21 mads + 50 other VALU instructions each)"),
         "phase_hbm": phase_hbm,
         "prover_ms_incl_upload": incl_upload_ms,

@@ -983,6 +983,11 @@ int dst_bench_code(dst_ctx* c, uint32_t code_kib, double* ms) {
     HIP_TRY(c, hipSetDevice(c->device));
     return k_bench_code(c, code_kib, ms);
 }
+int dst_bench_clock(dst_ctx* c, uint64_t lanes, uint32_t iters, double* mhz) {
+    if (!c || !mhz) return DST_ERR_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    return k_bench_clock(c, lanes, iters, mhz);
+}
 int dst_bench_mad(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms) {
     if (!c || !ms) return DST_ERR_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
@@ -993,6 +998,7 @@ static int no_hooks(dst_ctx* c) { if (c) c->err = "calibration kernels are part 
 int dst_bench_mulmod(dst_ctx* c, uint64_t, uint32_t, double*) { return no_hooks(c); }
 int dst_bench_code(dst_ctx* c, uint32_t, double*) { return no_hooks(c); }
 int dst_bench_mad(dst_ctx* c, uint64_t, uint32_t, double*) { return no_hooks(c); }
+int dst_bench_clock(dst_ctx* c, uint64_t, uint32_t, double*) { return no_hooks(c); }
 #endif
 // 1 when this is the test / bench build
 int dst_test_hooks(void) { return DST_TEST_HOOKS; }

@@ -43,12 +43,14 @@ typedef fe tw4_t;
 // They are read ONCE per context, when it is created (dst_ctx_create -> dst_ctx::sw), never per call.  `product` switches are operational
 // choices every build honours; the others select alternative formulations that exist for the tests to compare with the default ones and are
 // honoured only by the test / bench build (libdistaff_hip_hooks.so, -DDISTAFF_TEST_HOOKS): the product library does not even read them.
-// (DISTAFF_SHARD_DEBUG is also looked at by dst_comm_init*, which has no context: once, when the communicator is created.)
+// (DISTAFF_SHARD_DEBUG is also looked at by dst_comm_init*, which has no context: once, when the communicator is created; DISTAFF_COMM_TIMEOUT_S
+// and the test build's DISTAFF_TEST_STALL_COLLECTIVE are communicator settings read at the same moment and nowhere else.)
 struct dst_switch_def { const char* name; bool product; const char* values; const char* what; };
 static const dst_switch_def DST_SWITCHES[] = {
     {"DISTAFF_SHARD_DEBUG",        true,  "1",               "stderr line per tree exchange on rank 0; communicators record the order of their collectives (dst_comm_trace)"},
     {"DISTAFF_SHARD_TREE_GATHER",  true,  "1",               "sharded Merkle trees: all-gather of all boundary nodes + upper levels repeated on every rank (BASELINE north_star's all-gather-only form) instead of the k-range all-to-all"},
     {"DISTAFF_SHARD_NO_OVERLAP",   true,  "1",               "sharded prover: every collective on the context's main stream (no second stream / events) also on a stream-ordered transport"},
+    {"DISTAFF_COMM_TIMEOUT_S",     true,  "seconds",         "communicators: limit of every host wait behind a collective (default 60; <= 0: none); on expiry the rank aborts the communicator and returns DST_ERR_COMM (dst_comm_set_timeout changes it per handle)"},
     {"DISTAFF_TMP_REGS",           true,  "4..W",            "registers per transform launch = size of the staging array (default: as many as 12 GiB hold, at most W)"},
     {"DISTAFF_AIR",                false, "small|deep|generic", "force a more general constraint-kernel instance set than the trace shape needs (generic = per-operation formulation)"},
     {"DISTAFF_BOUNDARY",           false, "eval",            "boundary combinations by evaluation on the 8n domain (the reference's route) instead of coefficient form"},
@@ -70,6 +72,7 @@ static const dst_switch_def DST_SWITCHES[] = {
     {"DISTAFF_FRI_CHAIN",          false, "0",               "FRI commit phase with a root read-back and a host draw per layer"},
     {"DISTAFF_FRI_REPLICATE_LOG",  false, "k",               "sharded prover: replicate FRI layers from 2^k elements on (default 2^17)"},
     {"DISTAFF_SHARD_FORCE_OVERLAP", false, "1",              "sharded prover: the two-stream choreography of a stream-ordered transport over a blocking one"},
+    {"DISTAFF_TEST_STALL_COLLECTIVE", false, "k|k@r",        "communicators: fault injection -- before device collective number k (of rank r only) a kernel holds the stream until the communicator is aborted"},
 };
 // Layout of the page-locked staging area dst_ctx::h_stage (HS_TOTAL bytes): every small upload / read-back that must be QUEUED rather than
 // waited for has its own region, so that the lifetime of the host side of an asynchronous copy is explicit (a pageable source would be
@@ -349,6 +352,7 @@ void k_gather_rows(dst_ctx* c, const uint64_t* positions_dev, size_t count, fe* 
 void k_gather_pieces(dst_ctx* c, const uint64_t* addr_dev, size_t count, void* dst);          // dst[t] = the 16 bytes at device address addr[t]
 int k_bench_mulmod(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms);
 int k_bench_mad(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms);
+int k_bench_clock(dst_ctx* c, uint64_t lanes, uint32_t iters, double* mhz);          // shader clock (MHz) sustained under four fe_mul chains per lane on `lanes` lanes
 int k_bench_code(dst_ctx* c, uint32_t code_kib, double* ms);      // kernels_probe.hip
 // coset-sharded (multi-GPU) helpers
 void k_merkle_local_levels(dst_ctx* c, digest* nodes, size_t count, size_t stop_count);

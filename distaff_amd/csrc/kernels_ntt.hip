@@ -126,6 +126,41 @@ struct OutB {                                          // natural-order store X[
 #ifndef NTT_STREAM_B_LOAD
 #define NTT_STREAM_B_LOAD 1
 #endif
+// Laboratory switches of the first pass (tools/r6_lde_lab.sh; WRONG results on purpose, never defined in a build that ships): each takes one
+// of the pass's three global streams out of the memory system while every instruction stays -- the bound of anything that could be done
+// about that stream.  NTT_LAB_SRC_SMALL=1: the coefficient loads of every workgroup fall into a 64 KiB window (cache hits); =2: only those
+// of the odd-half workgroups of a register pre-stage pass (the upper bound of SHARING the loads between the halves);
+// NTT_LAB_TW4_SMALL: the four-step twiddles come from a 64 KiB window per coset; NTT_LAB_DST_DENSE: a tile is stored as one contiguous
+// 64 KiB block instead of 64-byte row segments a row stride apart.
+// (the window is indexed by (row, column) of the tile, so every row still carries different data: a window indexed by the masked ARRAY offset
+// would make the columns periodic, their spectra sparse -- and the kernels measurably faster for that alone, their time depends on the data)
+#if defined(NTT_LAB_SRC_SMALL)
+#define NTT_LAB_SRC(row, t, off) ((((NTT_LAB_SRC_SMALL) == 1) || hh) ? ((((row) & 1023u) << 2) + ((t) & 3u)) : (off))
+#else
+#define NTT_LAB_SRC(row, t, off) (off)
+#endif
+#if defined(NTT_LAB_TW4_SMALL)
+#define NTT_LAB_TW(row, t, off) ((((row) & 1023u) << 2) + ((t) & 3u))
+#else
+#define NTT_LAB_TW(row, t, off) (off)
+#endif
+#if defined(NTT_LAB_STAMPS)
+// [pass 0/1][workgroup slot 256][wave 16][tile 2][stamp 16]: written by lane 0 of every wave of the workgroups blockIdx.x = 61 * slot
+#define NTT_LAB_WG_STRIDE 61u
+__device__ unsigned long long ntt_lab_buf[2 * 256 * 16 * 2 * 16];
+extern "C" __attribute__((visibility("default"))) int dst_lab_stamps(unsigned long long* out, size_t count, int clear) {
+    if (count > sizeof(ntt_lab_buf) / 8) return -1;
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ntt_lab_buf), count * 8) != hipSuccess) return -2;
+    if (clear) { static unsigned long long zero[2 * 256 * 16 * 2 * 16]; if (hipMemcpyToSymbol(HIP_SYMBOL(ntt_lab_buf), zero, sizeof zero) != hipSuccess) return -3; }
+    return 0;
+}
+#define NTT_LAB_FLUSH(pass, it, st, nst) do { \
+    if ((blockIdx.x % NTT_LAB_WG_STRIDE) == 0u && blockIdx.x / NTT_LAB_WG_STRIDE < 256u && (it) < 2u && (threadIdx.x & 63u) == 0u) { \
+        unsigned long long* o_ = ntt_lab_buf + ((((size_t)(pass) * 256u + blockIdx.x / NTT_LAB_WG_STRIDE) * 16u + (threadIdx.x >> 6)) * 2u + (it)) * 16u; \
+        for (int k_ = 0; k_ < (nst); k_++) o_[k_] = (st)[k_]; } } while (0)
+#else
+#define NTT_LAB_FLUSH(pass, it, st, nst) ((void)0)
+#endif
 extern __shared__ __attribute__((aligned(16))) unsigned char ntt_smem[];
 
 // Both passes are persistent over `tiles_per_block` adjacent tiles.  PREFETCH instances (WPE = 4 waves per SIMD, 128 registers): the
@@ -182,8 +217,8 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
         return hh ? fe_mul_tw(fe_sub(x0, x1), a.pre_tw[row]) : fe_add(x0, x1);
     };
 #define NTT_FETCH_A1(e, var) if constexpr ((e) < EPT) { uint32_t idx = lane + (e) * THREADS; idx = idx < count ? idx : 0u; \
-        if constexpr (PRE != 0) { const uint32_t row_ = idx >> log_t; const fe x0_ = src[(row_ << a.log_n2) + NTT_COL_A(idx)], x1_ = src[((row_ + n1) << a.log_n2) + NTT_COL_A(idx)]; var = pre_stage_a(x0_, x1_, row_); } \
-        else var = src[((idx >> log_t) << a.log_n2) + NTT_COL_A(idx)]; }
+        if constexpr (PRE != 0) { const uint32_t row_ = idx >> log_t; const fe x0_ = src[NTT_LAB_SRC(row_, NTT_COL_A(idx), (row_ << a.log_n2) + NTT_COL_A(idx))], x1_ = src[NTT_LAB_SRC(row_ + 512u, NTT_COL_A(idx), ((row_ + n1) << a.log_n2) + NTT_COL_A(idx))]; var = pre_stage_a(x0_, x1_, row_); } \
+        else var = src[NTT_LAB_SRC(idx >> log_t, NTT_COL_A(idx), ((idx >> log_t) << a.log_n2) + NTT_COL_A(idx))]; }
 #define NTT_FETCH_A(tile) { const fe* __restrict__ src = src0 + (tile) * T; NTT_EACH(NTT_FETCH_A1) }
     const tw4_t* __restrict__ tw4 = a.tw4 + (size_t)jl * a.tw4_coset_stride;
     const uint32_t tile0 = group * a.tiles_per_block;
@@ -191,18 +226,25 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
     if (PREFETCH) NTT_FETCH_A(tile0)
     for (uint32_t it = 0; it < a.tiles_per_block; it++) {
         const uint32_t tile = tile0 + it;
+        unsigned long long st[16]; (void)st;               // laboratory stamps (NTT_STAMP: nothing in the product build)
+        NTT_STAMP_REAL(st, 14);
+        NTT_STAMP(st, 8);
         lane = lds_opaque_lane();                          // per-tile index arithmetic is recomputed, not kept live (and spilled) across the loop
         if (!PREFETCH) NTT_FETCH_A(tile)
+        NTT_STAMP(st, 9);
         __syncthreads();                                   // the previous tile has left LDS (and TW is complete)
+        NTT_STAMP(st, 10);
         // DISTAFF_NTT_DIF: pre-scale + DIF instead of the coset DIT
 #define NTT_PUT_A(e, var) if constexpr ((e) < EPT) { const uint32_t idx = lane + (e) * THREADS; if (idx < count) { if (a.dit) L[lds_slot(__brev(idx >> log_t) >> (32 - log_n1), NTT_COL_A(idx), log_t)] = var; else L[lds_slot(idx >> log_t, idx & (T - 1), log_t)] = scaled ? fe_mul_tw(var, a.prescale[(jg * (idx >> log_t)) & pmask]) : var; } }
         NTT_EACH(NTT_PUT_A)
 #undef NTT_PUT_A
+        NTT_STAMP(st, 11);
         __syncthreads();
+        NTT_STAMP(st, 12);
         if (PREFETCH && it + 1 < a.tiles_per_block) NTT_FETCH_A(tile + 1)
         if constexpr (LOG_LEN != 0) {
-            if (a.dit) lds_ntt_dit_fixed<THREADS, LOG_LEN, LOG_T>(L, TW, a.dit_last ? a.dit_last + (size_t)((jg << PRE) + hh) * (n1 / 2) : nullptr);
-            else lds_ntt_dif_fixed<THREADS, LOG_LEN, LOG_T>(L, TW);
+            if (a.dit) lds_ntt_dit_fixed<THREADS, LOG_LEN, LOG_T>(L, TW, a.dit_last ? a.dit_last + (size_t)((jg << PRE) + hh) * (n1 / 2) : nullptr, NttKeepInLds(), st);
+            else lds_ntt_dif_fixed<THREADS, LOG_LEN, LOG_T>(L, TW, NttKeepInLds(), st);
         } else {
             if (a.dit) lds_ntt_dit<THREADS>(L, TW, log_n1, log_t, 1u, log_n1 + 1u, a.dit_last ? a.dit_last + (size_t)((jg << PRE) + hh) * (n1 / 2) : nullptr);
             else lds_ntt_dif<THREADS>(L, TW, log_n1, log_t, 1u, log_n1 + 1u);
@@ -213,7 +255,11 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
         // live in the last round spill (13.15 / 13.3 against 13.05 ms), in the spill-free fixed-shape instance it is within the noise
         // (18.85 against 18.95 ms of extension, with the twiddle requested before or after the butterfly).
         constexpr int RB = WPE > 4 ? 1 : THREADS == 512 ? 2 : 4;
+#if defined(NTT_LAB_DST_DENSE)
+        fe* __restrict__ dst = dst_base + ((size_t)blockIdx.x * a.tiles_per_block + it) * count;
+#else
         fe* __restrict__ dst = dst0 + tile * T;          // uniform bases, 32-bit lane offsets
+#endif
         const tw4_t* __restrict__ tw = tw4 + tile * T;
         for (uint32_t base = 0; base < count; base += RB * THREADS) {
             fe v[RB]; tw4_t w[RB]; uint32_t off[RB]; bool ok[RB];
@@ -226,7 +272,10 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
                 const uint32_t k1 = ((a.dit ? r : __brev(r) >> (32 - log_n1)) << PRE) + hh;        // DIT leaves the tile in natural order; PRE: frequencies 2 k' + h
                 off[q] = (k1 << a.log_n2) + t;
                 v[q] = L[idx];
-                w[q] = tw[off[q]];
+                w[q] = tw[NTT_LAB_TW(r, t, off[q])];
+#if defined(NTT_LAB_DST_DENSE)
+                off[q] = idx;
+#endif
             });
             static_for<0, RB>([&](auto q_) {
                 constexpr int q = decltype(q_)::value;
@@ -242,6 +291,9 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_a(NttArgs a, const fe* 
 #endif
             });
         }
+        NTT_STAMP(st, 13);
+        NTT_STAMP_REAL(st, 15);
+        NTT_LAB_FLUSH(0, it, st, 16);
     }
 }
 
@@ -287,18 +339,28 @@ __global__ void __launch_bounds__(THREADS, WPE) ntt_pass_b(NttArgs a, const fe* 
     if (PREFETCH) NTT_FETCH_B(tile0)
     for (uint32_t it = 0; it < a.tiles_per_block; it++) {
         const uint32_t k1_0 = (tile0 + it) * T;
+        unsigned long long st[16]; (void)st;               // laboratory stamps (NTT_STAMP: nothing in the product build)
+        NTT_STAMP_REAL(st, 14);
+        NTT_STAMP(st, 8);
         lane = lds_opaque_lane();
         if (!PREFETCH) NTT_FETCH_B(tile0 + it)
+        NTT_STAMP(st, 9);
         __syncthreads();
+        NTT_STAMP(st, 10);
 #define NTT_PUT_B(e, var) if constexpr ((e) < EPT) { const uint32_t idx = lane + (e) * THREADS; if (idx < count) L[lds_slot(NTT_M2_B(idx), NTT_ROW_B(idx), log_t)] = var; }
         NTT_EACH(NTT_PUT_B)
 #undef NTT_PUT_B
+        NTT_STAMP(st, 11);
         __syncthreads();
+        NTT_STAMP(st, 12);
         if (PREFETCH && it + 1 < a.tiles_per_block) NTT_FETCH_B(tile0 + it + 1)
         const OutB out{dst + k1_0, (uint32_t)a.dst_k_stride, log_n2, a.has_scale != 0, a.scale, (uint32_t)PRE, hh};
         const fe_tw* Wuse = TW;
-        if constexpr (LOG_LEN != 0) lds_ntt_dif_fixed<THREADS, LOG_LEN, LOG_T, OutB>(L, Wuse, out);
+        if constexpr (LOG_LEN != 0) lds_ntt_dif_fixed<THREADS, LOG_LEN, LOG_T, OutB>(L, Wuse, out, st);
         else lds_ntt_dif<THREADS, OutB>(L, Wuse, log_n2, log_t, 1u, log_n2 + 1u, out);
+        NTT_STAMP(st, 13);
+        NTT_STAMP_REAL(st, 15);
+        NTT_LAB_FLUSH(1, it, st, 16);
     }
 }
 

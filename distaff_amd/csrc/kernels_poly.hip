@@ -8,6 +8,7 @@
 //   fri::reduce's quartic::interpolate_batch + evaluate_batch (src/stark/fri/prover.rs:23-31, src/math/quartic.rs:20,37)
 //                                                                                 -> closed-form 4-point fold
 //   utils::find_pow_nonce (src/stark/utils/proof_of_work.rs:4-32)                 -> batched nonce search with atomicMin
+#include <algorithm>
 #include "ctx.h"
 #include "blake3_dev.h"
 
@@ -719,6 +720,46 @@ int k_bench_mulmod(dst_ctx* c, uint64_t lanes, uint32_t iters, double* ms) {
     float f = 0; HIP_TRY(c, hipEventElapsedTime(&f, e0, e1));
     *ms = f;
     hipEventDestroy(e0); hipEventDestroy(e1);
+    return DST_OK;
+}
+
+// ---- the shader clock under a field-arithmetic load: the same four multiplication chains per lane as mulmod_bench_kernel on every SIMD of the
+// device, each wavefront noting s_memtime (shader cycles) and s_memrealtime (constant 100 MHz) around its loop.  The power management does not
+// hold the nominal 2.4 GHz under this path's arithmetic (profiles/r6_power_clock.md): bench.py reports what the box of the run sustains.
+__global__ void __launch_bounds__(PT) clock_probe_kernel(fe* out, unsigned long long* rec, uint32_t iters) {
+    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    fe a = fe_make(g * 2654435761u + 12345u, g ^ 0x9E3779B9u, g + 77u, 0x12345678u);
+    fe b = fe_make(g + 1u, 0xABCDEF01u, g * 3u + 5u, 0x0FEDCBA9u);
+    fe c2 = fe_make(0x11111111u + g, 0x22222222u, 0x33333333u, 0x04444444u);
+    fe d = fe_make(0x55555555u, 0x66666666u + g, 0x77777777u, 0x08888888u);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long r0 = wall_clock64(), t0 = __builtin_readcyclecounter();
+#else
+    const unsigned long long r0 = 0, t0 = 0;
+#endif
+    for (uint32_t i = 0; i < iters; i++) { a = fe_mul(a, b); b = fe_mul(b, c2); c2 = fe_mul(c2, d); d = fe_mul(d, a); }
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long t1 = __builtin_readcyclecounter(), r1 = wall_clock64();
+#else
+    const unsigned long long t1 = 2400, r1 = 100;
+#endif
+    out[g] = fe_add(fe_add(a, b), fe_add(c2, d));
+    if ((threadIdx.x & 63u) == 0u) { rec[2 * (g >> 6)] = t1 - t0; rec[2 * (g >> 6) + 1] = r1 - r0; }
+}
+int k_bench_clock(dst_ctx* c, uint64_t lanes, uint32_t iters, double* mhz) {
+    if (lanes * 2 > c->scratch_elems || lanes < PT) { c->err = "dst_bench_clock: lanes must be in [256, 2^20]"; return DST_ERR_ARG; }
+    lanes = lanes / PT * PT;
+    unsigned long long* rec = reinterpret_cast<unsigned long long*>(c->scratch + lanes);
+    hipLaunchKernelGGL(clock_probe_kernel, dim3((unsigned)(lanes / PT)), dim3(PT), 0, c->stream, c->scratch, rec, 4u);          // warm-up
+    hipLaunchKernelGGL(clock_probe_kernel, dim3((unsigned)(lanes / PT)), dim3(PT), 0, c->stream, c->scratch, rec, iters);
+    std::vector<unsigned long long> h(2 * (lanes / 64));
+    HIP_TRY(c, hipMemcpyAsync(h.data(), rec, h.size() * 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    std::vector<double> r;
+    for (size_t w = 0; w < lanes / 64; w++) if (h[2 * w + 1]) r.push_back((double)h[2 * w] / (double)h[2 * w + 1] * 100.0);      // ticks per 10 ns -> MHz
+    if (r.empty()) { c->err = "dst_bench_clock: no wave reported"; return DST_ERR_HIP; }
+    std::sort(r.begin(), r.end());
+    *mhz = r[r.size() / 2];
     return DST_OK;
 }
 

@@ -77,6 +77,17 @@ __device__ __forceinline__ uint32_t lds_opaque_lane() {
 #endif
     return lane;
 }
+// Laboratory instrument (-DNTT_LAB_STAMPS, tools/r6_pass_stamps.py; never defined in a build that ships): a wavefront notes the shader
+// clock (s_memtime) at the boundaries of a pass's phases -- load issue, barriers, LDS fill, every butterfly round, read-out -- into scalar
+// registers and writes them out once per tile.  The product build compiles the macro to nothing.
+#if defined(NTT_LAB_STAMPS) && defined(__HIP_DEVICE_COMPILE__)
+#define NTT_STAMP(arr, k) ((arr)[k] = __builtin_readcyclecounter())
+#define NTT_STAMP_REAL(arr, k) ((arr)[k] = wall_clock64())          // s_memrealtime: constant 100 MHz -- what an s_memtime tick is worth is measured, not assumed
+#else
+#define NTT_STAMP(arr, k) ((void)0)
+#define NTT_STAMP_REAL(arr, k) ((void)0)
+#endif
+
 // Consumer of the LAST round's results.  With the default the rounds leave the transformed tile in LDS.  A pass hands in an object
 // whose `pre(row, t)` may start a global load for the element (row, t) before the butterfly's arithmetic (the four-step twiddle: its
 // latency hides behind ~300 instructions) and whose `put(row, t, value, token)` finishes and stores the element: the last round then
@@ -155,9 +166,9 @@ __device__ __forceinline__ void lds_ntt_dif(fe* L, const fe_tw* W, uint32_t log_
     if (s == log_len && s < s_to) lds_dif_tail<THREADS, Out>(L, log_len, log_t, out, lane);
 }
 template <int THREADS, int LOG_LEN, int LOG_T, class Out = NttKeepInLds>
-__device__ __forceinline__ void lds_ntt_dif_fixed(fe* L, const fe_tw* W, const Out& out = Out()) {
+__device__ __forceinline__ void lds_ntt_dif_fixed(fe* L, const fe_tw* W, const Out& out = Out(), unsigned long long* stamps = nullptr) {
     const uint32_t lane = lds_opaque_lane();
-    static_for<0, LOG_LEN / 2>([&](auto r_) { constexpr uint32_t s = 1u + 2u * decltype(r_)::value; lds_dif_round<THREADS, Out>(L, W, (uint32_t)LOG_LEN, (uint32_t)LOG_T, s, out, lane); });
+    static_for<0, LOG_LEN / 2>([&](auto r_) { constexpr uint32_t s = 1u + 2u * decltype(r_)::value; lds_dif_round<THREADS, Out>(L, W, (uint32_t)LOG_LEN, (uint32_t)LOG_T, s, out, lane); (void)stamps; NTT_STAMP(stamps, decltype(r_)::value); });
     if constexpr (LOG_LEN & 1) lds_dif_tail<THREADS, Out>(L, (uint32_t)LOG_LEN, (uint32_t)LOG_T, out, lane);
 }
 
@@ -223,8 +234,8 @@ __device__ __forceinline__ void lds_ntt_dit(fe* L, const fe_tw* W, uint32_t log_
     if (s == log_len && s < s_to) lds_dit_tail<THREADS, Out>(L, W, log_len, log_t, Wlast, out, lane);
 }
 template <int THREADS, int LOG_LEN, int LOG_T, class Out = NttKeepInLds>
-__device__ __forceinline__ void lds_ntt_dit_fixed(fe* L, const fe_tw* W, const fe_tw* __restrict__ Wlast = nullptr, const Out& out = Out()) {
+__device__ __forceinline__ void lds_ntt_dit_fixed(fe* L, const fe_tw* W, const fe_tw* __restrict__ Wlast = nullptr, const Out& out = Out(), unsigned long long* stamps = nullptr) {
     const uint32_t lane = lds_opaque_lane();
-    static_for<0, LOG_LEN / 2>([&](auto r_) { constexpr uint32_t s = 1u + 2u * decltype(r_)::value; lds_dit_round<THREADS, Out>(L, W, (uint32_t)LOG_LEN, (uint32_t)LOG_T, s, Wlast, out, lane); });
+    static_for<0, LOG_LEN / 2>([&](auto r_) { constexpr uint32_t s = 1u + 2u * decltype(r_)::value; lds_dit_round<THREADS, Out>(L, W, (uint32_t)LOG_LEN, (uint32_t)LOG_T, s, Wlast, out, lane); (void)stamps; NTT_STAMP(stamps, decltype(r_)::value); });
     if constexpr (LOG_LEN & 1) lds_dit_tail<THREADS, Out>(L, W, (uint32_t)LOG_LEN, (uint32_t)LOG_T, Wlast, out, lane);
 }

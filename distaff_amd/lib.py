@@ -54,7 +54,7 @@ EXPORTS = ["dst_ctx_create", "dst_ctx_destroy", "dst_last_error", "dst_phase_ms"
            "dst_shard_commit_trace", "dst_shard_eval_constraints", "dst_shard_combine", "dst_shard_fri_layer", "dst_shard_fri_fold",
            "dst_shard_export_size", "dst_shard_export", "dst_shard_import", "dst_shard_read", "dst_shard_fri_begin", "dst_shard_fri_end", "dst_shard_fri_roots", "dst_shard_open", "dst_shard_assemble", "dst_shard_info",
            "dst_comm_unique_id", "dst_comm_init", "dst_comm_init_local", "dst_comm_init_callbacks", "dst_comm_destroy", "dst_comm_last_error", "dst_comm_copy", "dst_prove_sharded", "dst_prove_sharded_local", "dst_shard_stage_ms",
-           "dst_comm_describe", "dst_comm_trace", "dst_test_hooks", "dst_comm_set_timeout", "dst_comm_abort", "dst_shard_exchange_ms"]
+           "dst_comm_describe", "dst_comm_trace", "dst_test_hooks", "dst_comm_set_timeout", "dst_comm_abort", "dst_shard_exchange_ms", "dst_bench_clock"]
 
 
 class DistaffError(RuntimeError):
@@ -376,6 +376,12 @@ class Calibration:
 
     def bench_code(self, code_kib):
         return self.ctx.bench_code(code_kib)
+
+    def bench_clock(self, lanes=1 << 20, iters=1024):
+        """dst_bench_clock: MHz of the shader clock under four fe_mul chains per lane on every SIMD (median over the wavefronts)"""
+        mhz = ctypes.c_double(0)
+        self.ctx._check(self.ctx.lib.dst_bench_clock(self.ctx._h, ctypes.c_uint64(lanes), ctypes.c_uint32(iters), ctypes.byref(mhz)))
+        return mhz.value
 
     def close(self):
         self.ctx.close()

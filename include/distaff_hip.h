@@ -185,6 +185,10 @@ DST_API int dst_bench_mulmod(dst_ctx* ctx, uint64_t lanes, uint32_t iters, doubl
  * `lanes` lanes; returns the elapsed milliseconds (rate = lanes * iters * 32 / time).  The integer-multiplier roofline of the path.
  * (Test / bench build only: the product library returns DST_ERR_STATE.) */
 DST_API int dst_bench_mad(dst_ctx* ctx, uint64_t lanes, uint32_t iters, double* ms);
+/* the shader clock (MHz) the device sustains under this path's arithmetic: `iters` iterations of four dependent modular multiplications per lane
+ * on `lanes` lanes, every wavefront timing itself with s_memtime against the constant 100 MHz s_memrealtime; the median.  The power management
+ * does not hold the nominal clock under this load (profiles/r6_power_clock.md).  (Test / bench build only: the product library returns DST_ERR_STATE.) */
+DST_API int dst_bench_clock(dst_ctx* ctx, uint64_t lanes, uint32_t iters, double* mhz);
 /* box fingerprint: milliseconds for 2^23 lanes to run `code_kib` (16 or 176) KiB of straight-line multiply-adds once each.  The ratio
  * of the two times per instruction is 0.9 on a healthy device; a device on which code beyond the instruction cache is slow shows it here.
  * code_kib = 177: the 176 KiB kernel in its convoy form (256 lanes per workgroup, a workgroup barrier every 16 KiB: the wavefronts share
