@@ -192,6 +192,7 @@ def valu_issue(stats, proof_ms, steps):
     """Share of the VALU issue slots the kernels of one proof fill: SQ_INSTS_VALU per launch (committed, stamped PMC summary) x the
     launches of this run, against 1024 SIMDs x 2.4 GHz / 4 cycles.  `stats`: {kernel: {"launches", "ms"}} over `steps` proofs."""
     per_kernel, total, missing, refused = {}, 0.0, [], []
+    clock_ms, clock_weighted, per_kernel_clock = 0.0, 0.0, {}
     for name, st in stats.items():
         row, _ = pmc_row(name)
         if row is None or not row.get("SQ_INSTS_VALU"):
@@ -200,6 +201,10 @@ def valu_issue(stats, proof_ms, steps):
             continue
         insts = float(row["SQ_INSTS_VALU"]) * st["launches"]
         total += insts
+        if row.get("sclk_MHz"):                      # the clock the kernel ran at during the counter pass (GRBM_GUI_ACTIVE / duration: tools/summarize_profile.py)
+            clock_ms += st["ms"]; clock_weighted += st["ms"] * float(row["sclk_MHz"])
+            if st["ms"] / steps >= 0.5:
+                per_kernel_clock[name] = round(float(row["sclk_MHz"]))
         if st["ms"] / steps >= 0.5:
             frac = insts / (st["ms"] * 1e-3) / VALU_ISSUE_PEAK
             # a fraction above 1 is an accounting error (instruction counts of another launch mix than this run's), never a measurement
@@ -210,6 +215,7 @@ def valu_issue(stats, proof_ms, steps):
         return None
     return {"unit": "wave64 VALU instructions/s", "peak": VALU_ISSUE_PEAK, "proof_achieved": total / steps / (proof_ms * 1e-3),
             "proof_frac": round(total / steps / (proof_ms * 1e-3) / VALU_ISSUE_PEAK, 4), "kernel_frac": per_kernel,
+            "kernel_sclk_MHz": per_kernel_clock or None, "sclk_MHz_time_weighted": round(clock_weighted / clock_ms, 1) if clock_ms > 0 else None,
             "not_counted": missing, "refused_above_1": refused, "note": "instruction counts per launch from the stamped rocprofv3 summary, launch times of this run; "
             "the SQ_INSTS_VALU of a kernel name is the call-weighted average over its template instances and launches of a proof (pmc_rows), so kernels whose launches differ in size are exact for the whole proof only"}
 
@@ -271,10 +277,12 @@ def kernel_rooflines(stats, steps, default_workload, top=5):
         if row is not None and row.get("SQ_INSTS_VALU"):
             valu = round(float(row["SQ_INSTS_VALU"]) / (per_launch_ms * 1e-3) / VALU_ISSUE_PEAK, 4)
             valu = valu if valu <= 1.02 else None
+        sclk = float(row["sclk_MHz"]) if (row is not None and row.get("sclk_MHz")) else None
         rows.append({"bound": "hbm", "kernel": name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                      "traffic": traffic, "traffic_over_algorithmic": None if traffic is None else round(traffic / per_launch_bytes, 2), "traffic_source": source,
                      "traffic_fetch_factor": fetch_factor,
-                     "valu_issue_frac": valu, "ms_per_step": round(st["ms"] / steps, 3), "launches_per_step": st["launches"] / steps,
+                     "valu_issue_frac": valu, "sclk_MHz": None if sclk is None else round(sclk),
+                     "valu_issue_frac_at_measured_clock": None if (valu is None or not sclk) else round(valu * NOMINAL_SCLK_MHZ / sclk, 4), "ms_per_step": round(st["ms"] / steps, 3), "launches_per_step": st["launches"] / steps,
                      "avg_launch_ms": round(per_launch_ms, 4), "algorithmic_bytes_per_launch": per_launch_bytes})
     return rows
 
@@ -771,15 +779,17 @@ def run(args):
                     % (log_n, "default " if (blowup, args.queries) == (32, 50) else "", blowup, args.queries))
     box = box_fingerprint(cal, mad_peak, mulmod_peak)
     vi = alu.get("valu_issue")
-    if isinstance(vi, dict) and vi.get("proof_frac") is not None and box.get("sclk_under_load_MHz"):
+    if isinstance(vi, dict) and vi.get("proof_frac") is not None and (vi.get("sclk_MHz_time_weighted") or box.get("sclk_under_load_MHz")):
         # the slots the device OFFERS shrink with the clock the power management grants under this arithmetic (profiles/r6_power_clock.md):
         # the same instruction counts against 1024 SIMDs x measured clock / 4 cycles.  Above 1 is possible: ~7 % of the instructions are
-        # full-rate kinds that take half a slot (profiles/r6_issue_slots.txt).
-        scale = NOMINAL_SCLK_MHZ / box["sclk_under_load_MHz"]
-        vi["proof_frac_at_measured_clock"] = round(vi["proof_frac"] * scale, 4)
-        vi["kernel_frac_at_measured_clock"] = {k: (None if v is None else round(v * scale, 4)) for k, v in vi["kernel_frac"].items()}
-        vi["measured_clock_note"] = ("sclk_under_load_MHz = %.0f of %.0f nominal, from the calibration kernel of the test build (field multiplications on every SIMD); "
-                                     "the transform passes themselves were measured at 1870 / 1980 MHz (profiles/r6_pass_stamps.md)" % (box["sclk_under_load_MHz"], NOMINAL_SCLK_MHZ))
+        # full-rate kinds that take half a slot (profiles/r6_issue_slots.txt).  Clock: per kernel from the committed counter summary
+        # (GRBM_GUI_ACTIVE / launch duration) when it has one, else this run's calibration kernel.
+        mean_clock = vi.get("sclk_MHz_time_weighted") or box["sclk_under_load_MHz"]
+        vi["proof_frac_at_measured_clock"] = round(vi["proof_frac"] * NOMINAL_SCLK_MHZ / mean_clock, 4)
+        kc = vi.get("kernel_sclk_MHz") or {}
+        vi["kernel_frac_at_measured_clock"] = {k: (None if v is None else round(v * NOMINAL_SCLK_MHZ / (kc.get(k) or mean_clock), 4)) for k, v in vi["kernel_frac"].items()}
+        vi["measured_clock_note"] = ("clock per kernel from the stamped counter summary where present (kernel_sclk_MHz), else %s MHz from this run's calibration kernel "
+                                     "(field multiplications on every SIMD; box.sclk_under_load_MHz); nominal %.0f MHz" % (box.get("sclk_under_load_MHz"), NOMINAL_SCLK_MHZ))
     out = {
         "metric": "trace_cells_per_sec", "value": value, "unit": "trace-cells/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak" if world == 1 else "strong", "vs_baseline": None,
