@@ -10,6 +10,7 @@
 #pragma once
 #include <stddef.h>
 #include <stdint.h>
+#include <atomic>
 #include <string>
 #include <vector>
 #include "ctx.h"
@@ -24,11 +25,15 @@ struct dst_comm {
     // A dead communicator refuses every further collective at once, so the rank leaves dst_prove_sharded through its ordinary error path.
     double timeout_s = 60.0;               // DISTAFF_COMM_TIMEOUT_S at creation, dst_comm_set_timeout afterwards; <= 0: wait without limit
     bool dead = false;
+    std::atomic<bool> abort_requested{false};     // dst_comm_abort from ANOTHER thread: the rank's own thread performs the abort at its next check
     uint64_t issued = 0;                   // collectives issued so far (counted whether or not the record below is on)
     char last_kind = 0; uint64_t last_bytes = 0;
     virtual ~dst_comm() { if (stall_flag) { *(volatile uint32_t*)stall_flag = 1u; (void)hipHostFree(stall_flag); } }
     int wait_stream(hipStream_t stream, const char* what);      // comm.hip: bounded wait for everything queued on `stream`
     void abort(const std::string& why) { if (stall_flag) *(volatile uint32_t*)stall_flag = 1u; if (!dead) { dead = true; abort_impl(); } err = why; }
+    // the host's side (dst_comm_abort; any thread): mark, and wake whoever can be woken without touching the transport's state
+    void request_abort() { abort_requested.store(true); if (stall_flag) *(volatile uint32_t*)stall_flag = 1u; wake_impl(); }
+    bool check_requested() { if (!dead && abort_requested.load()) abort("the host aborted the communicator (dst_comm_abort)"); return dead; }
     std::string last_collective() const;   // "collective #k (all-to-all, 1048576 bytes per rank)"
     // Fault injection of the TEST build (DISTAFF_TEST_STALL_COLLECTIVE=k at creation; nothing in the product library): before this rank's
     // device collective number k a kernel is queued on the collective's stream that waits for a host flag only abort() sets -- the stream
@@ -41,11 +46,11 @@ struct dst_comm {
     // collectives overlap with kernels of other streams); the others return when the exchange is complete.  The host synchronises the
     // stream before it reads results.  all_gather may be in place: send == recv + rank * bytes_per_rank.
     virtual bool stream_ordered() const { return false; }
-    int all_gather(const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream) { if (dead) return refused(); test_stall(stream); note('G', bytes_per_rank, stream); return all_gather_impl(send, recv, bytes_per_rank, stream); }   // recv = [world][bytes]
-    int all_to_all(const void* send, void* recv, size_t chunk_bytes, hipStream_t stream) { if (dead) return refused(); test_stall(stream); note('A', chunk_bytes, stream); return all_to_all_impl(send, recv, chunk_bytes, stream); }           // chunk g of send -> rank g; chunk r of recv <- rank r
+    int all_gather(const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream) { if (check_requested()) return refused(); test_stall(stream); note('G', bytes_per_rank, stream); return all_gather_impl(send, recv, bytes_per_rank, stream); }   // recv = [world][bytes]
+    int all_to_all(const void* send, void* recv, size_t chunk_bytes, hipStream_t stream) { if (check_requested()) return refused(); test_stall(stream); note('A', chunk_bytes, stream); return all_to_all_impl(send, recv, chunk_bytes, stream); }           // chunk g of send -> rank g; chunk r of recv <- rank r
     // small host values (status words, lengths, opening blobs); complete on return.  `stream`: the caller's stream -- a transport that moves
     // the values through the device (RCCL) queues them THERE, so that a communicator sees its collectives on the streams of the prover only
-    int all_gather_host(const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream) { if (dead) return refused(); note('H', bytes_per_rank, nullptr); return all_gather_host_impl(send, recv, bytes_per_rank, stream); }
+    int all_gather_host(const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream) { if (check_requested()) return refused(); note('H', bytes_per_rank, nullptr); return all_gather_host_impl(send, recv, bytes_per_rank, stream); }
     int refused() { if (err.empty()) err = "the communicator was aborted"; return DST_ERR_COMM; }       // err keeps the reason of the abort
 
     // Issue-order record (dst_comm_trace; DISTAFF_SHARD_DEBUG=1 switches it on at creation): one entry per collective -- kind, bytes per
@@ -73,7 +78,8 @@ struct dst_comm {
     virtual void fill_info(dst_comm_info* out) const {}
 protected:
     virtual int poll_async() { return DST_OK; }                   // RCCL: ncclCommGetAsyncError; != DST_OK with `err` set when the transport has failed
-    virtual void abort_impl() {}                                  // transport-specific part of abort()
+    virtual void abort_impl() {}                                  // transport-specific part of abort() (the rank's own thread)
+    virtual void wake_impl() {}                                   // request_abort(): thread-safe wake-up of ranks blocked in this transport
     virtual int all_gather_impl(const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream) = 0;
     virtual int all_to_all_impl(const void* send, void* recv, size_t chunk_bytes, hipStream_t stream) = 0;
     virtual int all_gather_host_impl(const void* send, void* recv, size_t bytes_per_rank, hipStream_t stream) = 0;

@@ -167,6 +167,7 @@ struct LocalComm : dst_comm {
         return DST_ERR_COMM;
     }
     void abort_impl() override { sh->abort(); }
+    void wake_impl() override { sh->abort(); }         // LocalShared::abort takes the group's mutex: safe from any thread
     int transport_kind() const override { return DST_COMM_LOCAL; }
     int my_device = -1;
     bool peers_checked = false;
@@ -276,6 +277,7 @@ int dst_comm::wait_stream(hipStream_t stream, const char* what) {
         (void)hipGetLastError();                           // "not ready" is not an error of this call site
         if (e != hipErrorNotReady) { err = std::string("waiting for ") + what + ": " + hipGetErrorString(e); return DST_ERR_HIP; }
         if (spins & 63u) continue;
+        if (check_requested()) return DST_ERR_COMM;        // dst_comm_abort from another thread
         if (poll_async() != DST_OK) { const std::string why = err + " (while waiting for " + what + ", last issued: " + last_collective() + ")"; abort(why); return DST_ERR_COMM; }
         const double waited = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (timeout_s > 0 && waited > timeout_s) {
@@ -357,7 +359,9 @@ void dst_comm_destroy(dst_comm* comm) { delete comm; }
 int dst_comm_set_timeout(dst_comm* comm, double seconds) { if (!comm) return DST_ERR_ARG; comm->timeout_s = seconds; return DST_OK; }
 // Gives the communicator up from the host's side (a watchdog that learnt of a dead peer, a shutdown): RCCL's kernels end, in-process peers
 // leave their barriers, every later collective of this handle returns DST_ERR_COMM.  The handle still has to be destroyed.
-int dst_comm_abort(dst_comm* comm) { if (!comm) return DST_ERR_ARG; comm->abort("the host aborted the communicator (dst_comm_abort)"); return DST_OK; }
+// May be called from another thread than the one inside dst_prove_sharded: it only marks the handle (and wakes in-process peers); the rank's
+// own thread tears the transport down at its next poll or collective.
+int dst_comm_abort(dst_comm* comm) { if (!comm) return DST_ERR_ARG; comm->request_abort(); return DST_OK; }
 
 int dst_comm_describe(const dst_comm* comm, dst_comm_info* out) {
     if (!comm || !out) return DST_ERR_ARG;

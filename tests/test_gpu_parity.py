@@ -1308,6 +1308,50 @@ def test_prove_sharded_stalled_collective_is_aborted(oracle, monkeypatch, stall_
         ctx.close()
 
 
+def test_host_side_abort_from_another_thread(oracle, monkeypatch):
+    """dst_comm_abort is the host's way out before the limit expires (a watchdog that learnt of a dead peer): called from ANOTHER thread while
+    the ranks are inside dst_prove_sharded -- one waiting in a barrier for a peer that never comes, one (test build) polling a stream that a
+    stalled collective holds -- it ends both within a moment although their limits are a minute away."""
+    import threading
+    import time
+    import distaff_amd as D
+    O = oracle
+    t = O.fibonacci_trace(128)
+    op = O.Prover.from_trace(t, 1, grinding=8)
+    expected = op.prove()
+    ctxs = []
+    for r in range(2):
+        ctx = D.Context(7, t.width, t.ctx_depth, t.loop_depth, rank=r, world=2, grinding=8)
+        ctx.upload(t.columns)
+        ctxs.append(ctx)
+    hooks = bool(D.load().dst_test_hooks()) and "emu" not in D.library_path()
+    for case in (["absent peer"] + (["stalled stream"] if hooks else [])):
+        if case == "stalled stream":
+            monkeypatch.setenv("DISTAFF_TEST_STALL_COLLECTIVE", "4@1")
+        comms = D.Comm.local(2)
+        monkeypatch.delenv("DISTAFF_TEST_STALL_COLLECTIVE", raising=False)
+        for cm in comms:
+            cm.set_timeout(60.0)
+        victim = 0 if case == "absent peer" else 1
+        timer = threading.Timer(1.0, comms[victim].abort)
+        t0 = time.time()
+        timer.start()
+        proofs, errors, took = _thread_ranks(ctxs, comms, t.public_inputs, op.outputs, skip=((1,) if case == "absent peer" else ()))
+        timer.join()
+        assert errors and all(e.code == D.DST_ERR_COMM for e in errors.values()), (case, errors)
+        assert victim in errors and 0.5 < time.time() - t0 < 20.0, (case, took)
+        assert "dst_comm_abort" in comms[victim].last_error() or "left the group" in comms[victim].last_error(), comms[victim].last_error()
+        for cm in comms:
+            cm.close()
+    comms = D.Comm.local(2)
+    proofs, errors, took = _thread_ranks(ctxs, comms, t.public_inputs, op.outputs)
+    assert not errors and proofs[0] == expected and proofs[1] == expected
+    for cm in comms:
+        cm.close()
+    for ctx in ctxs:
+        ctx.close()
+
+
 _STALLED_PEER_WORKER = r"""
 import datetime, json, os, sys, time
 sys.path.insert(0, %r)
@@ -1734,6 +1778,10 @@ def test_bench_line_contract(tmp_path):
     assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "traffic" in r
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and "sample" in c and c["unit"] == d["unit"]
+    # round 6: the CPU figure at the HEADLINE size is quoted beside the bounded sample, and the box says what clock it sustains under this arithmetic
+    ref = c["same_size_reference"]
+    assert ref["log_n"] == 20 and ref["value"] > 0 and ref["source"].startswith("profiles/") and ref["kind"] == "port"
+    assert d["box"]["sclk_nominal_MHz"] == 2400.0 and 500.0 < d["box"]["sclk_under_load_MHz"] <= 2500.0, d["box"]
 
 
 @pytest.mark.parametrize("steps,log_blowup", [(128, 7), (256, 8)])
