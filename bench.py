@@ -574,6 +574,9 @@ def run(args):
                 transport = "dst_prove_sharded over the callback transport (torch.distributed %s%s)" % (
                     dist.get_backend(), ", host-staged, ranks sharing %d device(s)" % ndev if shared_devices else "")
 
+            # every host wait behind a collective is bounded by the library (DST_ERR_COMM on expiry); the first proof of a fresh RCCL communicator
+            # also pays its lazy connection set-up, so the bench grants more than the library's 60 s -- and less than its own watchdog
+            comm.set_timeout(float(os.environ.get("BENCH_COMM_TIMEOUT_S", "180")))
             # what the transport says about itself, from every rank: for RCCL the number of ranks the live communicator connected
             # (ncclCommCount), each rank's index in it and the device it runs on -- the line's proof that RCCL saw `world` ranks
             infos = [None] * world

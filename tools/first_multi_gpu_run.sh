@@ -6,7 +6,10 @@
 #   3. the same with the collectives carried by torch.distributed instead of the library's RCCL binding (DISTAFF_SHARD_TRANSPORT=callbacks)
 #   4. the all-gather-only tree form of BASELINE's north_star (DISTAFF_SHARD_TREE_GATHER=1)
 #   5. configs 4 and 5 at N = max
-# Compare `phase_ms` / `shard_stage_ms_rank0` with the per-rank models of DESIGN.md section 6.
+# Compare `phase_ms` (events on the prover's stream), `exchange_ms_rank0` (enqueue -> completion of every collective kind, i.e. incl. the wait for
+# the slowest peer) and `shard_stage_ms_rank0` with the per-rank models of DESIGN.md section 6.  No rank can hang: every host wait behind a collective
+# is bounded (DISTAFF_COMM_TIMEOUT_S, 60 s by default; on expiry the rank aborts its communicator and bench.py prints ONE line with the error, which
+# names the collective the rank was stuck behind -- dst_comm_last_error).
 set -u
 export TMPDIR=/tmp BENCH_TRACE_CACHE=${BENCH_TRACE_CACHE:-/tmp/dtc}
 R=$(cd "$(dirname "$0")/.." && pwd); cd "$R"
@@ -22,6 +25,7 @@ import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     print(sys.argv[1], d.get("error") or "%.2f ms  %.3e cells/s" % (d["ms_per_step"], d["value"]), (d.get("comm") or {}).get("transport"), (d.get("comm") or {}).get("ranks_per_rank"), d.get("shard_stage_ms_rank0"))
+    print("    phases", d.get("phase_ms"), "\n    exchanges", d.get("exchange_ms_rank0"))
 except Exception as e:
     print(sys.argv[1], "no line:", e)
 PY
