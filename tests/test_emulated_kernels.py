@@ -45,6 +45,7 @@ SELECTION = [
     "test_prove_sharded_rank_without_a_trace_on_fresh_contexts",
     "test_prove_sharded_peer_that_never_arrives",
     "test_host_side_abort_from_another_thread",
+    "test_sharded_phase_and_exchange_times",
     "test_prove_sharded_in_separate_processes_sharing_the_gpu[2-12-one]",
     "test_prove_sharded_in_separate_processes_sharing_the_gpu[8-12-overlap]",
     "test_bench_with_n_processes_on_one_device[2]",

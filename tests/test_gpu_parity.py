@@ -1308,6 +1308,45 @@ def test_prove_sharded_stalled_collective_is_aborted(oracle, monkeypatch, stall_
         ctx.close()
 
 
+def test_sharded_phase_and_exchange_times(oracle):
+    """dst_phase_ms of the sharded prover comes from events on the prover's stream (the host only enqueues between two waits, its own clock says
+    nothing about the phases) and dst_shard_exchange_ms from events around every collective: every phase is accounted for, the nine add up to
+    the call's wall time, and the collectives counted are exactly those the communicator's issue-order record lists."""
+    import time
+    import distaff_amd as D
+    O = oracle
+    t = O.fibonacci_trace(1 << 12)
+    op = O.Prover.from_trace(t, 1, grinding=8)
+    expected = op.prove()
+    comms = D.Comm.local(2)
+    ctxs = []
+    for r in range(2):
+        ctx = D.Context(12, t.width, t.ctx_depth, t.loop_depth, rank=r, world=2, grinding=8)
+        ctx.upload(t.columns)
+        ctxs.append(ctx)
+    _thread_ranks(ctxs, comms, t.public_inputs, op.outputs)                 # warm-up: buffers, events, code
+    for cm in comms:
+        cm.trace(1)
+    t0 = time.time()
+    proofs, errors, took = _thread_ranks(ctxs, comms, t.public_inputs, op.outputs)
+    wall_ms = (time.time() - t0) * 1e3
+    assert not errors and proofs[0] == expected and proofs[1] == expected
+    for r in range(2):
+        ph = ctxs[r].phase_ms()
+        assert len(ph) == 9 and all(v >= 0 for v in ph), ph
+        assert ph[0] > 0 and ph[1] > 0 and ph[2] > 0 and ph[4] > 0 and ph[5] > 0 and ph[6] > 0, ph      # extension, trees, constraints, DEEP, FRI all have device time
+        assert 0.5 * took[r] * 1e3 < sum(ph) < 1.05 * wall_ms, (sum(ph), took[r] * 1e3, wall_ms)
+        ex = ctxs[r].shard_exchange_ms()
+        rec = comms[r].trace(0)
+        assert ex["collectives"] == len(rec) and ex["timed_by_events"] == sum(1 for k, _, _ in rec if k != "H"), (ex, len(rec))
+        assert ex["coefficients"] > 0 and ex["tree_all_to_all"] > 0 and ex["tree_all_gather"] > 0 and ex["constraint_evaluations"] > 0 and ex["host_values"] > 0, ex
+        assert sum(v for k, v in ex.items() if k not in ("collectives", "timed_by_events")) < sum(ph), (ex, ph)
+    for cm in comms:
+        cm.close()
+    for ctx in ctxs:
+        ctx.close()
+
+
 def test_host_side_abort_from_another_thread(oracle, monkeypatch):
     """dst_comm_abort is the host's way out before the limit expires (a watchdog that learnt of a dead peer): called from ANOTHER thread while
     the ranks are inside dst_prove_sharded -- one waiting in a barrier for a peer that never comes, one (test build) polling a stream that a
