@@ -135,7 +135,28 @@ struct LocalShared {
     std::vector<const void*> ptr;
     std::vector<int> device;                          // device of every rank's thread (-1 until its first device collective)
     uint32_t refs;
-    explicit LocalShared(uint32_t w) : world(w), ptr(w, nullptr), device(w, -1), refs(w) {}
+    // stream-ordered form (LocalComm::exchange_ordered): collective number k of every rank uses slot k % RING -- the rank's send pointer, an event
+    // recorded on its stream when that buffer is ready, one recorded when the rank has queued its copies out of the peers' buffers; `posted` /
+    // `copied`: how many collectives a rank has published / has queued the copies of (host side, under `mu`)
+    static constexpr uint32_t RING = 4;
+    std::vector<const void*> sptr;                    // [RING][world]
+    std::vector<hipEvent_t> ready, done;              // [RING][world], created by the owning rank's thread on its device
+    std::vector<uint64_t> posted, copied;             // [world]
+    explicit LocalShared(uint32_t w) : world(w), ptr(w, nullptr), device(w, -1), refs(w), sptr((size_t)RING * w, nullptr),
+                                       ready((size_t)RING * w, nullptr), done((size_t)RING * w, nullptr), posted(w, 0), copied(w, 0) {}
+    ~LocalShared() { for (hipEvent_t e : ready) if (e) hipEventDestroy(e); for (hipEvent_t e : done) if (e) hipEventDestroy(e); }
+    // host-side rendezvous WITHOUT touching the device: returns when every rank's counter has reached `value` (true), when the group was
+    // aborted (false) or after `limit_s` seconds (false, *timed_out; the group is marked aborted so that every peer leaves as well)
+    bool wait_counters(const std::vector<uint64_t>& counter, uint64_t value, double limit_s, bool* timed_out) {
+        std::unique_lock<std::mutex> lk(mu);
+        *timed_out = false;
+        auto all = [&] { if (aborted) return true; for (uint64_t c : counter) if (c < value) return false; return true; };
+        if (limit_s > 0) {
+            if (!cv.wait_for(lk, std::chrono::duration<double>(limit_s), all)) { *timed_out = true; aborted = true; cv.notify_all(); return false; }
+        } else cv.wait(lk, all);
+        return !aborted;
+    }
+    void publish(std::vector<uint64_t>& counter, uint32_t rank, uint64_t value) { { std::lock_guard<std::mutex> lk(mu); counter[rank] = value; } cv.notify_all(); }
     // false: another rank gave up (dst_comm_destroy / abort while peers wait) or did not arrive within `limit_s` seconds (<= 0: no limit);
     // *timed_out tells the two apart.  Whoever times out marks the group aborted: every peer leaves its barrier with an error too.
     bool barrier(double limit_s, bool* timed_out) {
@@ -169,6 +190,52 @@ struct LocalComm : dst_comm {
     void abort_impl() override { sh->abort(); }
     void wake_impl() override { sh->abort(); }         // LocalShared::abort takes the group's mutex: safe from any thread
     int transport_kind() const override { return DST_COMM_LOCAL; }
+    // Stream-ordered form (the default; DISTAFF_LOCAL_TRANSPORT=blocking keeps the older one): a collective is only ENQUEUED.  The ranks' host
+    // threads meet twice per collective, but only to hand over pointers and events -- nobody waits for a stream, so the devices keep working
+    // through the exchanges exactly as under RCCL (dst_prove_sharded runs its two-stream choreography over this transport as well):
+    //   record "my send buffer is ready" on my stream | publish | wait until every peer has published | on my stream: wait for each peer's event,
+    //   copy its piece (device to device, peer access on a multi-GPU node) | record "I have read" | publish | wait until every peer has |
+    //   on my stream: wait for the peers' "have read" events, so that work queued behind the collective may overwrite the send buffer.
+    // The blocking form drained every rank's stream twice per collective: measured with 8 thread-ranks sharing one GPU it cost 3.2 - 3.4 ms per
+    // rank and proof at config 3 beyond the repeated kernels.
+    bool ordered = true;
+    uint64_t seq = 0;                                  // device collectives this rank has issued in ordered form
+    bool events_made = false;
+    bool stream_ordered() const override { return ordered; }
+    hipEvent_t& ev(std::vector<hipEvent_t>& v, uint32_t slot, uint32_t r) { return v[(size_t)slot * world + r]; }
+    int ensure_events() {
+        if (events_made) return DST_OK;
+        for (uint32_t s2 = 0; s2 < LocalShared::RING; s2++) {
+            if (hipEventCreateWithFlags(&ev(sh->ready, s2, rank), hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&ev(sh->done, s2, rank), hipEventDisableTiming) != hipSuccess) {
+                (void)hipGetLastError(); err = "local collective: event creation failed"; return DST_ERR_HIP;
+            }
+        }
+        events_made = true;
+        return DST_OK;
+    }
+    int exchange_ordered(const void* send, hipStream_t stream, const std::function<hipError_t(uint32_t peer, const void* peer_send)>& take) {
+        const uint64_t k = seq++;
+        const uint32_t slot = (uint32_t)(k % LocalShared::RING);
+        if (my_device < 0) { if (hipGetDevice(&my_device) != hipSuccess) my_device = -1; sh->device[rank] = my_device; }
+        int r = ensure_events();
+        hipError_t e = hipSuccess;
+        if (r == DST_OK && (e = hipEventRecord(ev(sh->ready, slot, rank), stream)) != hipSuccess) { err = std::string("local collective: ") + hipGetErrorString(e); r = DST_ERR_HIP; }
+        if (r != DST_OK) { const std::string why = err; abort(why); return r; }       // this rank cannot take part: its peers must not wait for it
+        { std::lock_guard<std::mutex> lk(sh->mu); sh->sptr[(size_t)slot * world + rank] = send; }
+        sh->publish(sh->posted, rank, k + 1);
+        bool late = false;
+        if (!sh->wait_counters(sh->posted, k + 1, timeout_s, &late)) return broken(late);
+        if (!peers_checked && my_device >= 0) enable_peer_access();                  // every rank has published its device before its first collective
+        for (uint32_t p = 0; p < world && e == hipSuccess; p++) if (p != rank) e = hipStreamWaitEvent(stream, ev(sh->ready, slot, p), 0);
+        for (uint32_t p = 0; p < world && e == hipSuccess; p++) e = take(p, sh->sptr[(size_t)slot * world + p]);
+        if (e == hipSuccess) e = hipEventRecord(ev(sh->done, slot, rank), stream);
+        if (e != hipSuccess) { abort(std::string("local collective: ") + hipGetErrorString(e)); return DST_ERR_HIP; }
+        sh->publish(sh->copied, rank, k + 1);
+        if (!sh->wait_counters(sh->copied, k + 1, timeout_s, &late)) return broken(late);
+        for (uint32_t p = 0; p < world && e == hipSuccess; p++) if (p != rank) e = hipStreamWaitEvent(stream, ev(sh->done, slot, p), 0);
+        if (e != hipSuccess) { abort(std::string("local collective: ") + hipGetErrorString(e)); return DST_ERR_HIP; }
+        return DST_OK;
+    }
     int my_device = -1;
     bool peers_checked = false;
     uint32_t peers_enabled = 0, peers_other_device = 0;
@@ -205,13 +272,15 @@ struct LocalComm : dst_comm {
         return DST_OK;
     }
     int all_gather_impl(const void* send, void* recv, size_t bytes, hipStream_t stream) override {
-        return exchange(send, stream, false, [&](uint32_t p, const void* src) {
+        auto take = [&](uint32_t p, const void* src) {
             uint8_t* dst = (uint8_t*)recv + (size_t)p * bytes;
             return dst == src ? hipSuccess : hipMemcpyAsync(dst, src, bytes, hipMemcpyDefault, stream);          // in place: the own piece is already there
-        });
+        };
+        return ordered ? exchange_ordered(send, stream, take) : exchange(send, stream, false, take);
     }
     int all_to_all_impl(const void* send, void* recv, size_t chunk, hipStream_t stream) override {
-        return exchange(send, stream, false, [&](uint32_t p, const void* src) { return hipMemcpyAsync((uint8_t*)recv + (size_t)p * chunk, (const uint8_t*)src + (size_t)rank * chunk, chunk, hipMemcpyDefault, stream); });
+        auto take = [&](uint32_t p, const void* src) { return hipMemcpyAsync((uint8_t*)recv + (size_t)p * chunk, (const uint8_t*)src + (size_t)rank * chunk, chunk, hipMemcpyDefault, stream); };
+        return ordered ? exchange_ordered(send, stream, take) : exchange(send, stream, false, take);
     }
     int all_gather_host_impl(const void* send, void* recv, size_t bytes, hipStream_t) override {
         return exchange(send, nullptr, true, [&](uint32_t p, const void* src) { memcpy((uint8_t*)recv + (size_t)p * bytes, src, bytes); return hipSuccess; });
@@ -303,6 +372,7 @@ int ctx_sync(dst_ctx* c, const char* what) {
 }
 
 static double comm_timeout_env() { const char* e = getenv("DISTAFF_COMM_TIMEOUT_S"); if (!e || !e[0]) return 60.0; char* end = nullptr; const double v = strtod(e, &end); return end == e ? 60.0 : v; }
+static bool local_blocking_env() { const char* e = getenv("DISTAFF_LOCAL_TRANSPORT"); return e && !strcmp(e, "blocking"); }
 static bool shard_debug_env() { const char* e = getenv("DISTAFF_SHARD_DEBUG"); return e && e[0] && e[0] != '0'; }
 static thread_local std::string g_comm_error;      // errors before a communicator exists, per calling thread (ranks may be threads)
 
@@ -332,6 +402,10 @@ int dst_comm_init(const uint8_t id[128], uint32_t rank, uint32_t world, int devi
     int r = api->CommInitRank(&c->comm, (int)world, u, (int)rank);
     if (r != ncclSuccess) { g_comm_error = std::string("ncclCommInitRank: ") + api->GetErrorString(r); c->comm = nullptr; delete c; return DST_ERR_HIP; }
     if (hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking) != hipSuccess) { g_comm_error = "dst_comm_init: stream creation failed"; delete c; return DST_ERR_HIP; }
+    // the staging area of the host-value all-gathers, NOW: hipMalloc synchronises the device, and in the middle of a proof that would be an
+    // unbounded wait behind whatever collectives are in flight (1 MiB holds the opening blobs of 8 ranks several times over; it still grows on demand)
+    c->staging_bytes = (size_t)1 << 20;
+    if (hipMalloc((void**)&c->staging, c->staging_bytes) != hipSuccess) { (void)hipGetLastError(); c->staging = nullptr; c->staging_bytes = 0; }
     c->tracing = shard_debug_env(); c->timeout_s = comm_timeout_env(); c->stall_at = comm_stall_env(c->rank);
     *out = c;
     return DST_OK;
@@ -340,7 +414,7 @@ int dst_comm_init(const uint8_t id[128], uint32_t rank, uint32_t world, int devi
 int dst_comm_init_local(uint32_t world, dst_comm** out) {
     if (!out || world == 0 || world > 64) { g_comm_error = "dst_comm_init_local: bad arguments"; return DST_ERR_ARG; }
     LocalShared* sh = new LocalShared(world);
-    for (uint32_t r = 0; r < world; r++) { LocalComm* c = new LocalComm(); c->rank = r; c->world = world; c->sh = sh; c->tracing = shard_debug_env(); c->timeout_s = comm_timeout_env(); c->stall_at = comm_stall_env(c->rank); out[r] = c; }
+    for (uint32_t r = 0; r < world; r++) { LocalComm* c = new LocalComm(); c->rank = r; c->world = world; c->sh = sh; c->tracing = shard_debug_env(); c->timeout_s = comm_timeout_env(); c->stall_at = comm_stall_env(c->rank); c->ordered = !local_blocking_env(); out[r] = c; }
     return DST_OK;
 }
 

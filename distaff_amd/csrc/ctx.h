@@ -44,13 +44,14 @@ typedef fe tw4_t;
 // choices every build honours; the others select alternative formulations that exist for the tests to compare with the default ones and are
 // honoured only by the test / bench build (libdistaff_hip_hooks.so, -DDISTAFF_TEST_HOOKS): the product library does not even read them.
 // (DISTAFF_SHARD_DEBUG is also looked at by dst_comm_init*, which has no context: once, when the communicator is created; DISTAFF_COMM_TIMEOUT_S
-// and the test build's DISTAFF_TEST_STALL_COLLECTIVE are communicator settings read at the same moment and nowhere else.)
+// DISTAFF_LOCAL_TRANSPORT and the test build's DISTAFF_TEST_STALL_COLLECTIVE are communicator settings read at the same moment and nowhere else.)
 struct dst_switch_def { const char* name; bool product; const char* values; const char* what; };
 static const dst_switch_def DST_SWITCHES[] = {
     {"DISTAFF_SHARD_DEBUG",        true,  "1",               "stderr line per tree exchange on rank 0; communicators record the order of their collectives (dst_comm_trace)"},
     {"DISTAFF_SHARD_TREE_GATHER",  true,  "1",               "sharded Merkle trees: all-gather of all boundary nodes + upper levels repeated on every rank (BASELINE north_star's all-gather-only form) instead of the k-range all-to-all"},
     {"DISTAFF_SHARD_NO_OVERLAP",   true,  "1",               "sharded prover: every collective on the context's main stream (no second stream / events) also on a stream-ordered transport"},
     {"DISTAFF_COMM_TIMEOUT_S",     true,  "seconds",         "communicators: limit of every host wait behind a collective (default 60; <= 0: none); on expiry the rank aborts the communicator and returns DST_ERR_COMM (dst_comm_set_timeout changes it per handle)"},
+    {"DISTAFF_LOCAL_TRANSPORT",    true,  "blocking",        "in-process transport (dst_comm_init_local, dst_prove_sharded_local): drain every rank's stream around each collective instead of the stream-ordered form (events between the ranks' streams, nothing waited for)"},
     {"DISTAFF_TMP_REGS",           true,  "4..W",            "registers per transform launch = size of the staging array (default: as many as 12 GiB hold, at most W)"},
     {"DISTAFF_AIR",                false, "small|deep|generic", "force a more general constraint-kernel instance set than the trace shape needs (generic = per-operation formulation)"},
     {"DISTAFF_BOUNDARY",           false, "eval",            "boundary combinations by evaluation on the 8n domain (the reference's route) instead of coefficient form"},
@@ -93,6 +94,11 @@ enum : size_t {
     HS_COMPOSE_BYTES = 516 * 16,
     HS_STATUS = 65536 + 8192 + 8320,   // upload of this rank's status record of a tree exchange: a ring of HS_STATUS_SLOTS records of 64 bytes
     HS_STATUS_SLOTS = 32,
+    // read-backs that sit BEHIND collectives of the sharded prover: into page-locked memory, because a device-to-host copy into pageable
+    // memory blocks the host inside hipMemcpyAsync -- an unbounded wait in front of the bounded one (comm.h wait_stream)
+    HS_TREE_READBACK = 65536 + 8192 + 8320 + 2048,     // tree exchange: G records of 96 bytes + the 32-byte root               (shard.hip tree_exchange)
+    HS_TAIL_ROOTS = HS_TREE_READBACK + 1024,           // roots of the FRI layers committed in one launch, 32 bytes per layer     (kernels_poly.hip k_fri_tail)
+    HS_POW = HS_TAIL_ROOTS + 1024,                     // the nonce found by the proof-of-work search                            (kernels_poly.hip k_pow)
     HS_TOTAL = 131072
 };
 static_assert(HS_WEIGHTS + HS_WEIGHTS_BYTES <= HS_DEEP, "boundary weights overlap the DEEP values");
@@ -101,6 +107,7 @@ static_assert(HS_FRI_ROOTS + DST_MAX_FRI_LAYERS * 32 <= HS_FRI_SLOTS, "FRI roots
 static_assert(8 * 96 + 32 <= HS_FRI_SLOT_BYTES && HS_FRI_SLOTS + DST_MAX_FRI_LAYERS * HS_FRI_SLOT_BYTES <= HS_AIR_FLAG, "FRI layer slots: G <= 8 ranks, DST_MAX_FRI_LAYERS layers");
 static_assert(HS_DRAWS + HS_DRAWS_BYTES <= HS_COMPOSE && HS_COMPOSE + HS_COMPOSE_BYTES <= HS_STATUS && HS_STATUS + HS_STATUS_SLOTS * 64 <= HS_TOTAL, "upload regions overlap");
 static_assert(HS_STATUS_SLOTS >= 2 + DST_MAX_FRI_LAYERS, "one status slot per tree exchange of a proof");
+static_assert(HS_STATUS + HS_STATUS_SLOTS * 64 <= HS_TREE_READBACK && 8 * 96 + 32 <= 1024 && DST_MAX_FRI_LAYERS * 32 <= 1024 && HS_POW + 64 <= HS_TOTAL, "read-back regions overlap");
 
 #ifdef DISTAFF_TEST_HOOKS
 #define DST_TEST_HOOKS 1

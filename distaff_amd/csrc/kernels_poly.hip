@@ -609,9 +609,13 @@ int k_fri_tail(dst_ctx* c, int first, uint8_t* roots_out) {
     a.fold.itw_lo = c->itw_lo; a.fold.itw_hi = c->itw_hi; a.fold.lo_bits = c->tw_lo_bits; a.fold.log_N = c->log_N;
     a.fold.alpha = fe_zero(); a.fold.iota = c->iota; a.fold.quarter = c->four_inv;
     { KScope ks_(c, "fri_tail_kernel", 0.0); hipLaunchKernelGGL(fri_tail_kernel, dim3(1), dim3(FRI_TAIL_THREADS), 0, c->stream, a); }
-    HIP_TRY(c, hipMemcpyAsync(roots_out, a.roots, (size_t)count * 32, hipMemcpyDeviceToHost, c->stream));
+    // read back into page-locked memory (the sharded prover queues this behind its exchanges: a pageable destination would make the host
+    // wait inside hipMemcpyAsync, in front of the bounded wait below)
+    uint8_t* pinned = c->h_stage + HS_TAIL_ROOTS;
+    HIP_TRY(c, hipMemcpyAsync(pinned, a.roots, (size_t)count * 32, hipMemcpyDeviceToHost, c->stream));
     CTX_SYNC(c, "the last FRI layers");
     HIP_TRY(c, hipGetLastError());
+    memcpy(roots_out, pinned, (size_t)count * 32);
     return DST_OK;
 }
 
@@ -641,9 +645,10 @@ int k_pow(dst_ctx* c, const uint8_t seed[32], uint32_t grinding, uint64_t* nonce
     const uint64_t batch = (uint64_t)1 << 22;
     for (uint64_t base = 1;; base += batch) {
         { KScope ks_(c, "pow_kernel", 0.0); hipLaunchKernelGGL(pow_kernel, dim3((unsigned)(batch / PT)), dim3(PT), 0, c->stream, (const uint32_t*)d_seed, base, grinding, d_best); }
-        unsigned long long best = 0;
-        HIP_TRY(c, hipMemcpyAsync(&best, d_best, 8, hipMemcpyDeviceToHost, c->stream));
+        unsigned long long* h_best = reinterpret_cast<unsigned long long*>(c->h_stage + HS_POW);      // page-locked: queued, then waited for with a bound
+        HIP_TRY(c, hipMemcpyAsync(h_best, d_best, 8, hipMemcpyDeviceToHost, c->stream));
         CTX_SYNC(c, "the proof-of-work search");
+        const unsigned long long best = *h_best;
         if (best != ~0ull) { *nonce = best; return DST_OK; }
         if (base > ((uint64_t)1 << 40)) { c->err = "proof-of-work search exhausted"; return DST_ERR_ARG; }
     }

@@ -851,17 +851,19 @@ void tree_exchange(Sharded& S, uint32_t what, uint32_t arg, uint8_t root[32], co
         return;
     }
     const double t_wait = wall_ms_shard();
-    std::vector<uint8_t> host(G * sizeof(TreeRec) + 32);
-    bool ok = hipMemcpyAsync(host.data(), recs, G * sizeof(TreeRec), hipMemcpyDeviceToHost, c->stream) == hipSuccess;
-    ok = ok && hipMemcpyAsync(host.data() + G * sizeof(TreeRec), upper + 1, 32, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+    // into PAGE-LOCKED memory: a copy into pageable memory would make the host wait inside hipMemcpyAsync for everything queued before it --
+    // the exchange included -- without any bound (found by the stalled-collective test over the stream-ordered in-process transport)
+    uint8_t* const host = c->h_stage + HS_TREE_READBACK;
+    bool ok = hipMemcpyAsync(host, recs, G * sizeof(TreeRec), hipMemcpyDeviceToHost, c->stream) == hipSuccess;
+    ok = ok && hipMemcpyAsync(host + G * sizeof(TreeRec), upper + 1, 32, hipMemcpyDeviceToHost, c->stream) == hipSuccess;
     // the host waits here for everything queued before the root, kernels and exchanges: a bounded poll (a peer that never joined the
     // exchange would otherwise hold this rank for ever); on expiry the communicator is aborted and the rank returns DST_ERR_COMM
     const int rw = ok ? ctx_sync(c, what == SH_TRACE_TREE ? "the root of the trace tree" : what == SH_CONSTRAINT_TREE ? "the root of the constraint tree" : "the root of a FRI tree") : DST_ERR_HIP;
     ok = ok && rw == DST_OK && hipGetLastError() == hipSuccess;
     c->shard_ms[1] += wall_ms_shard() - t_wait;
     if (!ok) { const int code = rw ? rw : DST_ERR_HIP; S.fail(code, rw ? c->err : std::string("tree_exchange: root read-back failed")); S.agreed = S.agreed ? S.agreed : code; return; }
-    tree_exchange_finish(S, what, arg, host.data(), payload_out, first_bad);
-    if (root) memcpy(root, host.data() + G * sizeof(TreeRec), 32);
+    tree_exchange_finish(S, what, arg, host, payload_out, first_bad);
+    if (root) memcpy(root, host + G * sizeof(TreeRec), 32);
 }
 // the ranks' records and the root of a tree exchange, once they are on the host: first failing rank's code into S.agreed, else the root is filed
 void tree_exchange_finish(Sharded& S, uint32_t what, uint32_t arg, const uint8_t* slot, fe* payload_out, int64_t* first_bad) {

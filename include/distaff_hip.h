@@ -213,7 +213,10 @@ DST_API int dst_kernel_stats(dst_ctx* ctx, char* json_out, size_t cap, int reset
  * One communicator handle per rank.  RCCL transport (one process per GPU, xGMI): the rank-0 host calls dst_comm_unique_id and hands
  * the 128 bytes to the other ranks through its own channel; every rank then calls dst_comm_init with the device it created its
  * context on.  librccl.so is bound at run time, a single-GPU host never needs it.  In-process transport (dst_comm_init_local fills
- * `world` handles): the ranks are threads of one process, e.g. a host that drives all GPUs of a node itself, or tests.
+ * `world` handles): the ranks are threads of one process, e.g. a host that drives all GPUs of a node itself, or tests; stream-ordered like
+ * RCCL -- a collective is enqueued on the ranks' streams (events between them, device-to-device copies over peer access), the host threads
+ * only hand over pointers and never wait for a stream (DISTAFF_LOCAL_TRANSPORT=blocking: the older form that drains the streams around
+ * every collective).
  * dst_prove_sharded is stark::prove on context `ctx` (created with rank / world in dst_params, trace uploaded on EVERY rank): all ranks
  * call it, all ranks receive the same proof bytes; when any rank fails every rank returns an error.  dst_prove_sharded_local is the
  * one-call form for a single-process host: `world` contexts, one thread each. */

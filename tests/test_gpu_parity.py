@@ -1147,8 +1147,9 @@ def test_prove_sharded_over_rccl_with_one_rank(oracle):
     comm.close()
 
 
+@pytest.mark.parametrize("transport", ["ordered", "blocking"])
 @pytest.mark.parametrize("world", [2, 8])
-def test_thread_rank_transport_issue_order_and_peer_access(oracle, world):
+def test_thread_rank_transport_issue_order_and_peer_access(oracle, monkeypatch, world, transport):
     """The in-process transport with one Python thread per rank (what dst_prove_sharded_local does with C++ threads): every rank issues
     the same collective sequence, and each reports the peer-access picture of its device -- on this box all ranks share GPU 0, so no
     peer is on another device (on a multi-GPU node every other rank's device is enabled with hipDeviceEnablePeerAccess once, so that the
@@ -1159,6 +1160,10 @@ def test_thread_rank_transport_issue_order_and_peer_access(oracle, world):
     t = O.fibonacci_trace(1 << 9)
     op = O.Prover.from_trace(t, 1, grinding=8)
     expected = op.prove()
+    # `ordered` = the default: collectives only enqueued, events between the ranks' streams, and therefore the two-stream choreography of the
+    # RCCL transport; `blocking` = every rank's stream drained around each collective, everything on the main stream
+    if transport == "blocking":
+        monkeypatch.setenv("DISTAFF_LOCAL_TRANSPORT", "blocking")
     comms = D.Comm.local(world)
     ctxs = []
     for r in range(world):
@@ -1182,6 +1187,7 @@ def test_thread_rank_transport_issue_order_and_peer_access(oracle, world):
     assert all(p == expected for p in proofs)
     records = [cm.trace(0) for cm in comms]
     assert all(rec == records[0] for rec in records) and len(records[0]) > 10
+    assert {st for _, _, st in records[0] if st is not None} == ({0, 1} if transport == "ordered" else {0})
     for r, cm in enumerate(comms):
         info = cm.describe()
         assert info["transport"] == "local" and (info["rank"], info["world"]) == (r, world)
@@ -1265,14 +1271,19 @@ def test_prove_sharded_peer_that_never_arrives(oracle):
         ctx.close()
 
 
+@pytest.mark.parametrize("transport", ["ordered", "blocking"])
 @pytest.mark.parametrize("stall_at", [0, 3, 11])
-def test_prove_sharded_stalled_collective_is_aborted(oracle, monkeypatch, stall_at):
+def test_prove_sharded_stalled_collective_is_aborted(oracle, monkeypatch, stall_at, transport):
     """What a collective whose peer never arrives does to a rank -- its stream stops -- reproduced on ONE GPU by the test build's fault
     injection (DISTAFF_TEST_STALL_COLLECTIVE=k@r: before rank r's device collective number k a kernel is queued that holds the stream
     until the communicator is aborted).  The rank's next host wait is a bounded poll: after the limit it aborts the communicator (which
     releases the stream, as ncclCommAbort ends RCCL's kernels), returns DST_ERR_COMM and names the wait and the last collective it issued;
-    its peer, waiting for it in the exchange, is woken and returns DST_ERR_COMM as well.  With 2 ranks: collectives 0 - 9 = the coefficient
-    all-gathers, 10 = the all-to-all of the trace tree's boundary nodes, 11 = the all-gather of its root records."""
+    its peer returns DST_ERR_COMM as well.  With 2 ranks: collectives 0 - 9 = the coefficient all-gathers, 10 = the all-to-all of the trace
+    tree's boundary nodes, 11 = the all-gather of its root records, then the first host wait (the trace root).
+    `ordered` (the default in-process transport, stream-ordered like RCCL): the collectives behind the stalled one are ENQUEUED regardless, the
+    rank notices at the root wait and the last collective it ISSUED is 11 whichever stalled; the peer's stream waits for the stalled rank's
+    events, so it times out by itself or is woken by the abort.  `blocking` (DISTAFF_LOCAL_TRANSPORT=blocking): the rank drains its stream
+    inside the stalled collective and names exactly that one."""
     import distaff_amd as D
     if not D.load().dst_test_hooks():
         pytest.skip("fault injection exists in the test build only")
@@ -1286,6 +1297,8 @@ def test_prove_sharded_stalled_collective_is_aborted(oracle, monkeypatch, stall_
         ctx.upload(t.columns)
         ctxs.append(ctx)
     monkeypatch.setenv("DISTAFF_TEST_STALL_COLLECTIVE", "%d@1" % stall_at)
+    if transport == "blocking":
+        monkeypatch.setenv("DISTAFF_LOCAL_TRANSPORT", "blocking")
     comms = D.Comm.local(2)
     monkeypatch.delenv("DISTAFF_TEST_STALL_COLLECTIVE")
     for cm in comms:
@@ -1294,8 +1307,12 @@ def test_prove_sharded_stalled_collective_is_aborted(oracle, monkeypatch, stall_
     assert set(errors) == {0, 1} and all(e.code == D.DST_ERR_COMM for e in errors.values()), errors
     msg = comms[1].last_error()
     assert "no completion within 2.0 s" in msg and "the communicator was aborted" in msg, msg
-    assert ("collective #%d (%s" % (stall_at, "all-gather" if stall_at != 10 else "all-to-all")) in msg, msg
-    assert "left the group" in comms[0].last_error() or "did not reach" in comms[0].last_error(), comms[0].last_error()
+    named = stall_at if transport == "blocking" else 11
+    assert ("collective #%d (%s" % (named, "all-gather" if named != 10 else "all-to-all")) in msg, msg
+    if transport == "ordered":
+        assert "the root of the trace tree" in msg, msg
+    peer = comms[0].last_error()
+    assert "left the group" in peer or "did not reach" in peer or "no completion within" in peer, peer
     assert 1.5 < max(took) < 25.0, took
     for cm in comms:
         cm.close()

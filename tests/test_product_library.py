@@ -48,7 +48,7 @@ def test_environment_is_read_once_per_context_and_documented():
     dst_ctx::read_switches (context creation) and the communicator constructors (DISTAFF_SHARD_DEBUG, the wait limit, the test build's
     fault injection: a communicator has no context)"""
     table = _switch_table()
-    assert len(table) >= 20 and sum(table.values()) == 5
+    assert len(table) >= 20 and sum(table.values()) == 6
     used, getenv_sites = set(), []
     for f in sorted(os.listdir(CSRC)):
         if not f.endswith((".hip", ".h")):
@@ -56,9 +56,9 @@ def test_environment_is_read_once_per_context_and_documented():
         text = open(os.path.join(CSRC, f)).read()
         used |= set(re.findall(r'sw(?:_is|_flag)?\("(DISTAFF_[A-Z0-9_]+)"', text))
         getenv_sites += [(f, m) for m in re.findall(r'getenv\(([^)]*)\)', text)]
-    comm_only = {"DISTAFF_COMM_TIMEOUT_S", "DISTAFF_TEST_STALL_COLLECTIVE"}
+    comm_only = {"DISTAFF_COMM_TIMEOUT_S", "DISTAFF_LOCAL_TRANSPORT", "DISTAFF_TEST_STALL_COLLECTIVE"}
     assert used | comm_only == set(table) and not (used & comm_only), (used ^ set(table))
-    assert sorted(getenv_sites) == [("comm.hip", '"DISTAFF_COMM_TIMEOUT_S"'), ("comm.hip", '"DISTAFF_SHARD_DEBUG"'), ("comm.hip", '"DISTAFF_TEST_STALL_COLLECTIVE"'), ("ctx.h", "d.name")], getenv_sites
+    assert sorted(getenv_sites) == [("comm.hip", '"DISTAFF_COMM_TIMEOUT_S"'), ("comm.hip", '"DISTAFF_LOCAL_TRANSPORT"'), ("comm.hip", '"DISTAFF_SHARD_DEBUG"'), ("comm.hip", '"DISTAFF_TEST_STALL_COLLECTIVE"'), ("ctx.h", "d.name")], getenv_sites
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     for name, product in table.items():
         row = re.search(r"^\| `%s` \| (product \+ test|test only) \|" % name, doc, flags=re.M)
