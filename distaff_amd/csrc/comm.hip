@@ -70,10 +70,12 @@ struct RcclComm : dst_comm {
     int device = 0;
     hipStream_t own_stream = nullptr;      // host-value gathers
     uint8_t* staging = nullptr; size_t staging_bytes = 0;
+    uint8_t* h_land = nullptr; size_t h_land_bytes = 0;          // page-locked landing area of the host-value gathers
     int fail(int r, const char* what) { err = std::string(what) + ": " + (api && api->GetErrorString ? api->GetErrorString(r) : "RCCL error"); return DST_ERR_COMM; }
     ~RcclComm() override {
         if (comm && api) api->CommDestroy(comm);
         if (staging) hipFree(staging);
+        if (h_land) hipHostFree(h_land);
         if (own_stream) hipStreamDestroy(own_stream);
     }
     bool stream_ordered() const override { return true; }
@@ -119,11 +121,22 @@ struct RcclComm : dst_comm {
             staging_bytes = need < 65536 ? 65536 : need;
             if (hipMalloc((void**)&staging, staging_bytes) != hipSuccess) { staging = nullptr; staging_bytes = 0; err = "all_gather_host: out of device memory"; return DST_ERR_HIP; }
         }
-        if (hipMemcpyAsync(staging, send, bytes, hipMemcpyHostToDevice, own_stream) != hipSuccess) { err = "all_gather_host: upload failed"; return DST_ERR_HIP; }
+        // both directions go through PAGE-LOCKED memory of the communicator ([0, bytes): this rank's values, behind them the gathered ones): a copy
+        // from or into the caller's pageable buffer may block inside hipMemcpyAsync until the stream has run that far -- the all-gather included,
+        // i.e. for ever if a peer is missing -- in front of the bounded wait below
+        if (need > h_land_bytes) {
+            if (h_land) hipHostFree(h_land);
+            h_land_bytes = need < ((size_t)1 << 20) ? ((size_t)1 << 20) : need;
+            if (hipHostMalloc((void**)&h_land, h_land_bytes, hipHostMallocDefault) != hipSuccess) { h_land = nullptr; h_land_bytes = 0; err = "all_gather_host: out of page-locked memory"; return DST_ERR_HIP; }
+        }
+        memcpy(h_land, send, bytes);
+        if (hipMemcpyAsync(staging, h_land, bytes, hipMemcpyHostToDevice, own_stream) != hipSuccess) { err = "all_gather_host: upload failed"; return DST_ERR_HIP; }
         int r = api->AllGather(staging, staging + bytes, bytes, ncclUint8, comm, own_stream);
         if (r != ncclSuccess) return fail(r, "ncclAllGather");
-        if (hipMemcpyAsync(recv, staging + bytes, bytes * world, hipMemcpyDeviceToHost, own_stream) != hipSuccess) { err = "all_gather_host: download failed"; return DST_ERR_HIP; }
-        return wait_stream(own_stream, "the all-gather of host values");
+        if (hipMemcpyAsync(h_land + bytes, staging + bytes, bytes * world, hipMemcpyDeviceToHost, own_stream) != hipSuccess) { err = "all_gather_host: download failed"; return DST_ERR_HIP; }
+        const int w = wait_stream(own_stream, "the all-gather of host values");
+        if (w == DST_OK) memcpy(recv, h_land + bytes, bytes * world);
+        return w;
     }
 };
 
@@ -406,6 +419,8 @@ int dst_comm_init(const uint8_t id[128], uint32_t rank, uint32_t world, int devi
     // unbounded wait behind whatever collectives are in flight (1 MiB holds the opening blobs of 8 ranks several times over; it still grows on demand)
     c->staging_bytes = (size_t)1 << 20;
     if (hipMalloc((void**)&c->staging, c->staging_bytes) != hipSuccess) { (void)hipGetLastError(); c->staging = nullptr; c->staging_bytes = 0; }
+    c->h_land_bytes = (size_t)1 << 20;
+    if (hipHostMalloc((void**)&c->h_land, c->h_land_bytes, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); c->h_land = nullptr; c->h_land_bytes = 0; }
     c->tracing = shard_debug_env(); c->timeout_s = comm_timeout_env(); c->stall_at = comm_stall_env(c->rank);
     *out = c;
     return DST_OK;
