@@ -199,6 +199,55 @@ def test_bench_control_flow_on_cpu_stand_ins(emulated_library, ranks, orch):
         assert out["prover_ms_incl_upload"] and out["phase_hbm"] and "frac" in out["alu_roofline"]
 
 
+SILENT_PEER_WORKER = r'''
+import datetime, json, os, sys, time
+sys.path.insert(0, %(root)r)
+import torch.distributed as dist
+import distaff_amd as D
+dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=8))       # the HOST's channel carries its own limit
+rank, world = dist.get_rank(), dist.get_world_size()
+cols, program_hash, result = D.fibonacci_trace(8)
+ctx = D.Context(8, 20, 1, 0, rank=rank, world=world, grinding=8)
+ctx.upload(cols)
+comm = D.Comm.over_torch(dist)                                               # dst_comm_init_callbacks: gloo carries the library's collectives
+out = {"rank": rank}
+if rank == 1:
+    time.sleep(16)                                                           # this rank never enters the proof and stops answering
+    out["code"] = None
+else:
+    t0 = time.time()
+    try:
+        ctx.prove_sharded(comm, [1, 0], [result])
+        out["code"] = 0
+    except D.DistaffError as e:
+        out["code"], out["message"] = e.code, str(e)
+    out["seconds"], out["comm_error"] = time.time() - t0, comm.last_error()
+json.dump(out, open(os.path.join(sys.argv[1], "result_%%d.json" %% rank), "w"))
+os._exit(0)                                                                  # no orderly shutdown of a broken group
+'''
+
+
+def test_peer_process_that_stops_answering_over_gloo(emulated_library, tmp_path):
+    """Containment of the N-process path without a GPU: two real processes over torch.distributed (gloo), the library's collectives carried by
+    the callback transport; rank 1 never enters dst_prove_sharded.  Rank 0 does not hang: when the host's channel gives up (gloo, 8 s) its
+    callback reports failure, the communicator is dead and dst_prove_sharded returns DST_ERR_COMM naming the collective (the first one)."""
+    import json
+    import socket
+    sock = socket.socket(); sock.bind(("127.0.0.1", 0)); port = sock.getsockname()[1]; sock.close()
+    script = tmp_path / "silent_peer_worker.py"
+    script.write_text(SILENT_PEER_WORKER % {"root": ROOT})
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK=str(r), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   DISTAFF_HIP_LIB=emulated_library, DISTAFF_HIP_RUNTIME="none", DISTAFF_EMU_THREADS="2")
+        procs.append(subprocess.Popen([sys.executable, str(script), str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT))
+    outs = [p.communicate(timeout=300)[0].decode() for p in procs]
+    res = json.load(open(tmp_path / "result_0.json"))
+    assert res["code"] == -5, (res, outs)                                    # DST_ERR_COMM
+    assert "callback returned" in res["comm_error"] and "collective #0 (all-gather" in res["comm_error"], res
+    assert res["seconds"] < 60.0, res
+
+
 THREE_PASS_WORKER = r'''
 import os, sys
 sys.path.insert(0, %(root)r)
