@@ -69,8 +69,11 @@ int main(int argc, char** argv) {
         dst_comm_info info;                                    /* what RCCL itself says about the communicator it built */
         if (dst_comm_describe(comm, &info) == DST_OK)
             fprintf(stderr, "rank %u: RCCL %u connected %u ranks, this rank is %u on device %d\n", rank, info.rccl_version, info.rccl_ranks, info.rccl_rank, (int)info.device);
+        /* no rank waits for ever: after 120 s without completion behind a collective (a peer that died or never started) the rank aborts its
+           communicator and dst_prove_sharded returns DST_ERR_COMM; dst_comm_last_error names the collective it was stuck behind */
+        dst_comm_set_timeout(comm, 120.0);
         rc = dst_prove_sharded(ctx, comm, &pub, proof, cap, &len);
-        if (rc != DST_OK) { fprintf(stderr, "rank %u: dst_prove_sharded: %d %s\n", rank, rc, dst_last_error(ctx)); return 1; }
+        if (rc != DST_OK) { fprintf(stderr, "rank %u: dst_prove_sharded: %d %s%s%s\n", rank, rc, dst_last_error(ctx), rc == DST_ERR_COMM ? " | " : "", rc == DST_ERR_COMM ? dst_comm_last_error(comm) : ""); return 1; }
         dst_comm_destroy(comm);
         dst_ctx_destroy(ctx);
     } else {
