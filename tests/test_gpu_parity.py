@@ -1413,7 +1413,7 @@ import datetime, json, os, sys, time
 sys.path.insert(0, %r)
 import torch.distributed as dist
 import distaff_amd as D
-dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=12))      # the HOST's channel carries its own limit
+dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=6))       # the HOST's channel carries its own limit
 rank, world = dist.get_rank(), dist.get_world_size()
 cols, program_hash, result = D.fibonacci_trace(10)
 ctx = D.Context(10, 20, 1, 0, device=0, rank=rank, world=world)
@@ -1433,7 +1433,7 @@ out["seconds"] = time.time() - t0
 out["comm_error"] = comm.last_error()
 json.dump(out, open(os.path.join(sys.argv[1], "result_%%d.json" %% rank), "w"))
 if rank == 1:
-    time.sleep(20)                                                            # the stalled rank stops answering: rank 0 has only its own limits
+    time.sleep(9)                                                             # the stalled rank stops answering: rank 0 has only its own limits
 os._exit(0)                                                                   # no orderly shutdown of a broken group
 """
 
@@ -1442,7 +1442,7 @@ def test_stalled_peer_process_over_the_callback_transport(tmp_path):
     """Two OS processes on GPU 0 over the callback transport (gloo carries the collectives): rank 1's stream stalls in the middle of the
     proof (fault injection of the test build) and the process then stops answering.  Rank 1 returns DST_ERR_COMM after ITS communicator's
     limit (3 s: bounded poll, abort); rank 0, inside the host's collective callback, returns DST_ERR_COMM when the host's channel gives up
-    (gloo's 12 s) -- nobody hangs, both name the collective."""
+    (gloo's 6 s) -- nobody hangs, both name the collective."""
     import json
     import os
     import socket
